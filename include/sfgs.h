@@ -1,0 +1,176 @@
+/*
+ * sfgs.h -- C ABI of libsfgs.so, the MI355X (gfx950) Gaussian-splat rasterizer hot path.
+ *
+ * This header is the drop-in boundary. Everything here is plain C: device pointers, sizes and
+ * a HIP stream handle passed as void*. No torch types, no C++ types. The Python packages
+ * diff_gauss / fused_ssim / simple_knn (skyfall-gs_amd/) bind these symbols with ctypes; the
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Reference interface each entry point replaces (paths relative to the reference tree):
+ *
+ *   sfgs_raster_*      diff_gauss.GaussianRasterizer.__call__      gaussian_renderer/__init__.py:57,132-140
+ *                      diff_gauss.GaussianRasterizationSettings    gaussian_renderer/__init__.py:40-55
+ *                      autograd backward of that call              train.py:279,845
+ *   sfgs_ssim_*        fused_ssim.fused_ssim(img1, img2)           train.py:42,222,778
+ *   sfgs_knn_dist2     simple_knn._C.distCUDA2(points)             scene/gaussian_model.py:25,324
+ *
+ * Ownership: every buffer (inputs, outputs, gradients, scratch "blobs") is allocated by the
+ * caller (PyTorch's caching allocator on the right device). The library never allocates or
+ * frees device memory and keeps no device state between calls, so it is thread-safe per
+ * stream by construction (the autograd backward runs on a different host thread).
+ *
+ * Errors: every function returns SFGS_OK (0) or a negative SfgsStatus. Nothing throws across
+ * the ABI, nothing calls exit(). sfgs_last_error() returns a thread-local message.
+ */
+#ifndef SFGS_H
+#define SFGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFGS_ABI_VERSION 1
+
+typedef enum SfgsStatus {
+  SFGS_OK = 0,
+  SFGS_E_ARG = -1,         /* bad argument (null pointer, negative size, struct_size mismatch) */
+  SFGS_E_HIP = -2,         /* a HIP runtime call or kernel launch failed                       */
+  SFGS_E_CAPACITY = -3,    /* a caller-owned blob is smaller than the plan requires            */
+  SFGS_E_UNSUPPORTED = -4  /* e.g. sh_degree > 3, image wider than 65535 tiles                 */
+} SfgsStatus;
+
+/* Depth output convention (SURVEY 8c "unpinned semantic decisions"). */
+#define SFGS_DEPTH_NORMALISED 0 /* depth = sum(T a z) / (1 - T_final); NaN where nothing hit (default) */
+#define SFGS_DEPTH_RAW 1        /* depth = sum(T a z)                                                  */
+
+/* One camera frame = diff_gauss.GaussianRasterizationSettings (14 fields,
+ * gaussian_renderer/__init__.py:40-55). Matrix pointers are DEVICE pointers to the 16 floats of
+ * the reference's row-major *transposed* matrices (scene/cameras.py:62-73):
+ * p_view = [p,1] * viewmatrix, p_hom = [p,1] * projmatrix. */
+typedef struct SfgsFrame {
+  uint32_t struct_size;          /* = sizeof(SfgsFrame), ABI versioning                         */
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  float kernel_size;             /* Mip-Splatting 2D filter variance (arguments/__init__.py:111) */
+  float scale_modifier;
+  int32_t sh_degree;             /* active SH degree 0..3                                        */
+  int32_t sh_coeffs;             /* coefficients stored per Gaussian in `shs` (max_degree+1)^2   */
+  int32_t prefiltered;           /* accepted, ignored (reference always passes False)            */
+  int32_t debug;                 /* !=0: synchronise + check after every launch                  */
+  int32_t depth_mode;            /* SFGS_DEPTH_*                                                 */
+  const float* subpixel_offset;  /* device [H,W,2] or NULL (= zeros)                             */
+  const float* bg;               /* device [3]                                                   */
+  const float* viewmatrix;       /* device [16]                                                  */
+  const float* projmatrix;       /* device [16]                                                  */
+  const float* campos;           /* device [3]                                                   */
+} SfgsFrame;
+
+/* Per-Gaussian inputs = keyword arguments of GaussianRasterizer.__call__
+ * (gaussian_renderer/__init__.py:132-140). All float32, contiguous, device memory.
+ * Exactly one of colors_precomp / shs is non-NULL. cov3Ds_precomp must be NULL: that path is
+ * dead in the reference (scales.float() at :138 dereferences None when it would be used). */
+typedef struct SfgsGaussians {
+  uint32_t struct_size;
+  int32_t count;                 /* N                                              */
+  const float* means3D;          /* [N,3]                                          */
+  const float* scales;           /* [N,3]  (already 3D-filtered, activated)        */
+  const float* rotations;        /* [N,4]  (w,x,y,z), normalised by the caller     */
+  const float* opacities;        /* [N,1]  (already 3D-filter compensated)         */
+  const float* colors_precomp;   /* [N,3] or NULL                                  */
+  const float* shs;              /* [N,sh_coeffs,3] or NULL                        */
+} SfgsGaussians;
+
+/* Gradient outputs of the backward pass (all device, float32, fully overwritten). */
+typedef struct SfgsGaussianGrads {
+  uint32_t struct_size;
+  float* means3D;        /* [N,3] */
+  float* means2D;        /* [N,3]: cols 0:2 = dL/dmean2D in NDC units, col 2 = abs-grad magnitude
+                            (scene/gaussian_model.py:744-749)                                    */
+  float* scales;         /* [N,3] */
+  float* rotations;      /* [N,4] */
+  float* opacities;      /* [N,1] */
+  float* colors_precomp; /* [N,3] or NULL */
+  float* shs;            /* [N,sh_coeffs,3] or NULL */
+} SfgsGaussianGrads;
+
+/* Sizes (bytes) of the caller-owned scratch blobs. */
+typedef struct SfgsRasterSizes {
+  uint32_t struct_size;
+  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile rects, duplicate offsets       */
+  size_t tiles_bytes;    /* f(W,H): counters, per-tile counts/offsets                            */
+  size_t bins_bytes;     /* f(D):   duplicate keys, sorted per-tile lists                        */
+  size_t image_bytes;    /* f(W,H): per-pixel last-contributor index (needed by backward)        */
+  size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
+} SfgsRasterSizes;
+
+/* Counters produced by the plan stage (host copy). */
+typedef struct SfgsRasterCounters {
+  int64_t num_duplicates;      /* D_eff: (Gaussian,tile) pairs actually binned (opacity-aware rect) */
+  int64_t num_duplicates_ref;  /* D:     sum of tiles_touched by the reference 3-sigma rule          */
+  int64_t num_visible;         /* N_vis: count(radii > 0)                                            */
+  int64_t max_tile_list;       /* longest per-tile list                                              */
+} SfgsRasterCounters;
+
+int sfgs_abi_version(void);
+const char* sfgs_last_error(void);
+
+/* Blob sizes for N Gaussians, a W x H image and (for bins/dupgrad) a duplicate capacity D. */
+int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, SfgsRasterSizes* out);
+
+/* Forward, stage 1 ("plan"): preprocess every Gaussian (cull, EWA projection, 2D mip filter,
+ * radius, SH->RGB), write radii[N] (int32), count duplicates per tile and scan the counts.
+ * Asynchronous on `stream`. */
+int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii,
+                             void* geom, size_t geom_bytes, void* tiles, size_t tiles_bytes,
+                             void* stream);
+
+/* Copies the plan counters to the host. SYNCHRONISES `stream` (the one host sync of the forward,
+ * as in the reference, where the duplicate total sizes the sort buffers). */
+int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream);
+
+/* Forward, stage 2 ("render"): scatter duplicates into per-tile segments, sort each segment by
+ * (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
+ * out_depth[1,H,W], out_alpha[1,H,W]. `bins` must hold `dup_capacity` >= D_eff duplicates.
+ * `image` may be NULL when no backward will follow. Asynchronous on `stream`. */
+int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
+                               void* bins, size_t bins_bytes, int64_t dup_capacity,
+                               float* out_color, float* out_depth, float* out_alpha,
+                               void* image, size_t image_bytes, void* stream);
+
+/* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
+ * be NULL (= zeros). Needs the forward's blobs and outputs unchanged. Asynchronous. */
+int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
+                         const void* geom, const void* tiles, const void* bins, const void* image,
+                         const float* out_color, const float* out_depth, const float* out_alpha,
+                         const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                         void* dupgrad, size_t dupgrad_bytes, const SfgsGaussianGrads* grads,
+                         void* stream);
+
+/* fused_ssim: mean SSIM (11x11 Gaussian window, sigma 1.5, zero "same" padding, C1=0.01^2,
+ * C2=0.03^2 == utils/loss_utils.py:23-63) of img1,img2 [B,C,H,W] float32.
+ * forward: writes the per-element SSIM map sum into *ssim_sum (device float, must be zeroed by
+ * the library: it is) and, when partials != NULL, the three [B,C,H,W] partial-derivative maps the
+ * backward consumes. backward: dL_dimg1 = dL_dmean_ssim * d(mean ssim)/d(img1). */
+size_t sfgs_ssim_partials_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+int sfgs_ssim_forward(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H,
+                      int32_t W, float* ssim_map_or_null, float* ssim_sum, float* partials_or_null,
+                      void* stream);
+int sfgs_ssim_backward(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H,
+                       int32_t W, const float* partials, const float* dL_dmean, float* dL_dimg1,
+                       void* stream);
+
+/* simple_knn distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other
+ * points. scratch: sfgs_knn_scratch_bytes(N). */
+size_t sfgs_knn_scratch_bytes(int32_t N);
+int sfgs_knn_dist2(const float* xyz, int32_t N, float* out, void* scratch, size_t scratch_bytes,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFGS_H */

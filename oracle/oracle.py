@@ -1,0 +1,164 @@
+"""ctypes front-end of the CPU oracle (oracle/sfgs_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (skyfall-gs_amd/) never does. PARITY UNPINNED: see the header of sfgs_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "sfgs_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("kernel_size", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
+                ("sh_coeffs", C.c_int32), ("depth_mode", C.c_int32), ("subpix", C.c_void_p),
+                ("bg", C.c_void_p), ("view", C.c_void_p), ("proj", C.c_void_p), ("campos", C.c_void_p)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_forward.restype = C.c_void_p
+        _lib.orc_forward.argtypes = [C.POINTER(OrcFrame), C.c_int32] + [C.c_void_p] * 10
+        _lib.orc_backward.restype = C.c_int
+        _lib.orc_backward.argtypes = [C.c_void_p, C.POINTER(OrcFrame)] + [C.c_void_p] * 17
+        _lib.orc_free.argtypes = [C.c_void_p]
+        _lib.orc_get_counts.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_get_tiles_touched.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_get_n_contrib.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_get_tile_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_get_geom.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_ssim.restype = C.c_double
+        _lib.orc_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p]
+        _lib.orc_knn_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    return _lib
+
+
+def _f32(x):
+    if x is None:
+        return None
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleRender:
+    """One forward pass of the oracle; keeps the state the backward needs."""
+
+    def __init__(self, frame, means3D, scales, rotations, opacities, colors_precomp=None, shs=None):
+        L = lib()
+        self.H, self.W = int(frame["H"]), int(frame["W"])
+        self.N = int(means3D.shape[0])
+        self._keep = dict(means3D=_f32(means3D), scales=_f32(scales), rotations=_f32(rotations),
+                          opacities=_f32(opacities).reshape(-1), colors=_f32(colors_precomp), shs=_f32(shs),
+                          subpix=_f32(frame.get("subpix")), bg=_f32(frame["bg"]), view=_f32(frame["view"]),
+                          proj=_f32(frame["proj"]), campos=_f32(frame["campos"]))
+        k = self._keep
+        self.sh_coeffs = 0 if k["shs"] is None else int(k["shs"].shape[1])
+        self.frame = OrcFrame(self.H, self.W, float(frame["tanfovx"]), float(frame["tanfovy"]),
+                              float(frame["kernel_size"]), float(frame.get("scale_modifier", 1.0)),
+                              int(frame.get("sh_degree", 0)), self.sh_coeffs, int(frame.get("depth_mode", 0)),
+                              _ptr(k["subpix"]), _ptr(k["bg"]), _ptr(k["view"]), _ptr(k["proj"]),
+                              _ptr(k["campos"]))
+        P = self.H * self.W
+        self.color = np.zeros((3, self.H, self.W), np.float32)
+        self.depth = np.zeros((1, self.H, self.W), np.float32)
+        self.alpha = np.zeros((1, self.H, self.W), np.float32)
+        self.radii = np.zeros((self.N,), np.int32)
+        self._st = L.orc_forward(C.byref(self.frame), self.N, _ptr(k["means3D"]), _ptr(k["scales"]),
+                                 _ptr(k["rotations"]), _ptr(k["opacities"]), _ptr(k["colors"]), _ptr(k["shs"]),
+                                 _ptr(self.color), _ptr(self.depth), _ptr(self.alpha), _ptr(self.radii))
+        cnt = np.zeros(4, np.int64)
+        L.orc_get_counts(self._st, _ptr(cnt))
+        self.num_duplicates, self.num_visible, self.max_tile_list, self.num_tiles = [int(v) for v in cnt]
+        assert P >= 0
+
+    def tiles_touched(self):
+        out = np.zeros(self.N, np.int32)
+        lib().orc_get_tiles_touched(self._st, _ptr(out))
+        return out
+
+    def n_contrib(self):
+        out = np.zeros((self.H, self.W), np.uint32)
+        lib().orc_get_n_contrib(self._st, _ptr(out))
+        return out
+
+    def tile_lists(self):
+        starts = np.zeros(self.num_tiles + 1, np.int64)
+        lst = np.zeros(max(self.num_duplicates, 1), np.uint32)
+        lib().orc_get_tile_lists(self._st, _ptr(starts), _ptr(lst))
+        return starts, lst[: self.num_duplicates]
+
+    def geom(self):
+        out = np.zeros((self.N, 12), np.float32)
+        lib().orc_get_geom(self._st, _ptr(out))
+        return out
+
+    def backward(self, dL_dcolor=None, dL_ddepth=None, dL_dalpha=None):
+        k = self._keep
+        N = self.N
+        g = dict(means3D=np.zeros((N, 3), np.float32), means2D=np.zeros((N, 3), np.float32),
+                 scales=np.zeros((N, 3), np.float32), rotations=np.zeros((N, 4), np.float32),
+                 opacities=np.zeros((N, 1), np.float32))
+        gcol = np.zeros((N, 3), np.float32) if k["colors"] is not None else None
+        gsh = np.zeros((N, self.sh_coeffs, 3), np.float32) if k["shs"] is not None else None
+        dc, dd, da = _f32(dL_dcolor), _f32(dL_ddepth), _f32(dL_dalpha)
+        rc = lib().orc_backward(self._st, C.byref(self.frame), _ptr(k["means3D"]), _ptr(k["scales"]),
+                                _ptr(k["rotations"]), _ptr(k["opacities"]), _ptr(k["colors"]), _ptr(k["shs"]),
+                                _ptr(self.alpha), _ptr(dc), _ptr(dd), _ptr(da), _ptr(g["means3D"]),
+                                _ptr(g["means2D"]), _ptr(g["scales"]), _ptr(g["rotations"]),
+                                _ptr(g["opacities"]), _ptr(gcol), _ptr(gsh))
+        assert rc == 0
+        if gcol is not None:
+            g["colors_precomp"] = gcol
+        if gsh is not None:
+            g["shs"] = gsh
+        return g
+
+    def close(self):
+        if self._st:
+            lib().orc_free(self._st)
+            self._st = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ssim(img1, img2, want_grad=False):
+    a, b = _f32(img1), _f32(img2)
+    assert a.ndim == 4 and a.shape == b.shape
+    B, Cc, H, W = a.shape
+    smap = np.zeros_like(a)
+    grad = np.zeros_like(a) if want_grad else None
+    val = lib().orc_ssim(_ptr(a), _ptr(b), B, Cc, H, W, _ptr(smap), _ptr(grad))
+    return (val, smap, grad) if want_grad else (val, smap)
+
+
+def knn_dist2(xyz):
+    a = _f32(xyz)
+    out = np.zeros(a.shape[0], np.float32)
+    lib().orc_knn_dist2(_ptr(a), a.shape[0], _ptr(out))
+    return out

@@ -1,0 +1,75 @@
+"""Seeded synthetic scenes of BASELINE.md section 4 / SURVEY 8(d) (host logic, CPU tensors).
+
+Inputs are generated on the CPU with torch.Generator().manual_seed(seed) in float32 so that every
+backend (oracle, HIP) sees bit-identical data; callers move them to the device.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .camera import fovy_from_fovx, make_frame
+
+
+def _unit_quats(n, gen):
+    q = torch.randn(n, 4, generator=gen)
+    return q / q.norm(dim=1, keepdim=True)
+
+
+def scene(n, W, H, seed=0, zrange=(250.0, 350.0), scale_range=(0.05, 0.6), fovx_deg=60.0, mode="precomp",
+          sh_degree=1, xy_fill=1.0, pitch_deg=0.0, jitter=False, opacity_range=(0.05, 0.95), kernel_size=0.1):
+    """cfg 2-style scene: pinhole at the origin, COLMAP axes, z ~ U(zrange), x,y fill the frustum,
+    scales = exp(U(ln lo, ln hi)) per axis, unit quaternions, opacity ~ U(0.05,0.95).
+    mode 'precomp' -> colors_precomp ~ U(0,1)^3 ; mode 'sh' -> shs deg `sh_degree`."""
+    gen = torch.Generator().manual_seed(seed)
+    fovx = math.radians(fovx_deg)
+    fovy = fovy_from_fovx(fovx, W, H)
+    z = torch.empty(n).uniform_(zrange[0], zrange[1], generator=gen)
+    u = torch.empty(n, 2).uniform_(-1.0, 1.0, generator=gen) * xy_fill
+    x = u[:, 0] * z * math.tan(fovx / 2)
+    y = u[:, 1] * z * math.tan(fovy / 2)
+    means = torch.stack([x, y, z], 1).contiguous()
+    lo, hi = math.log(scale_range[0]), math.log(scale_range[1])
+    scales = torch.exp(torch.empty(n, 3).uniform_(lo, hi, generator=gen))
+    rots = _unit_quats(n, gen)
+    opac = torch.empty(n, 1).uniform_(opacity_range[0], opacity_range[1], generator=gen)
+    out = dict(means3D=means, scales=scales, rotations=rots, opacities=opac, colors_precomp=None, shs=None)
+    if mode == "precomp":
+        out["colors_precomp"] = torch.rand(n, 3, generator=gen)
+    else:
+        K = (sh_degree + 1) ** 2
+        shs = torch.randn(n, K, 3, generator=gen)
+        shs[:, 1:] *= 0.3
+        out["shs"] = shs.contiguous()
+    R = np.eye(3)
+    if pitch_deg:
+        # rotate the camera about its x axis (low-elevation variant): world points stay in front
+        a = math.radians(pitch_deg)
+        R = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+        out["means3D"] = (means @ torch.tensor(R.T, dtype=torch.float32)).contiguous()  # camera -> world
+    subpix = None
+    if jitter:
+        subpix = (torch.rand(H, W, 2, generator=gen) - 0.5).contiguous()
+    frame = make_frame(R, np.zeros(3), fovx, fovy, W, H, kernel_size=kernel_size,
+                       sh_degree=sh_degree if mode == "sh" else 0, subpix=subpix)
+    return frame, out
+
+
+def upstream_grads(W, H, seed=0):
+    """dL/dimage, dL/ddepth ~ N(0,1)/P."""
+    gen = torch.Generator().manual_seed(1000 + seed)
+    P = W * H
+    return torch.randn(3, H, W, generator=gen) / P, torch.randn(1, H, W, generator=gen) / P
+
+
+# BASELINE.json configs -----------------------------------------------------------------------
+def cfg1(seed=0, n=50_000):
+    return scene(n, 800, 800, seed, zrange=(4.0, 8.0), scale_range=(0.005, 0.05))
+
+
+def cfg2(seed=0, n=2_000_000, W=1920, H=1080):
+    return scene(n, W, H, seed)
+
+
+def cfg4(seed=0, n=5_000_000):
+    return scene(n, 2560, 1440, seed, zrange=(500.0, 700.0))
