@@ -101,10 +101,10 @@ typedef struct SfgsGaussianGrads {
 /* Sizes (bytes) of the caller-owned scratch blobs. */
 typedef struct SfgsRasterSizes {
   uint32_t struct_size;
-  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile rects, duplicate offsets       */
-  size_t tiles_bytes;    /* f(W,H): counters, per-tile counts/offsets                            */
+  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile ranges, duplicate offsets      */
+  size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials */
   size_t bins_bytes;     /* f(D):   duplicate keys, sorted per-tile lists                        */
-  size_t image_bytes;    /* f(W,H): per-pixel last-contributor index (needed by backward)        */
+  size_t image_bytes;    /* f(W,H): per-pixel last contributor, final T, raw depth (for backward)*/
   size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
 } SfgsRasterSizes;
 
@@ -118,6 +118,15 @@ typedef struct SfgsRasterCounters {
 
 int sfgs_abi_version(void);
 const char* sfgs_last_error(void);
+
+/* Optional per-kernel timing (bench.py's roofline leg): when enabled, every kernel launch of the
+ * library is bracketed by HIP events recorded on the launch stream. sfgs_profile_collect waits for
+ * the recorded events, returns per-kernel summed milliseconds and launch counts (arrays of
+ * sfgs_profile_kernel_count() entries) and clears the record. Off by default; costs nothing then. */
+int sfgs_profile_enable(int32_t on);
+int sfgs_profile_kernel_count(void);
+const char* sfgs_profile_kernel_name(int32_t id);
+int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);
 
 /* Blob sizes for N Gaussians, a W x H image and (for bins/dupgrad) a duplicate capacity D. */
 int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, SfgsRasterSizes* out);
@@ -137,35 +146,39 @@ int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* 
  * (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
  * out_depth[1,H,W], out_alpha[1,H,W]. `bins` must hold `dup_capacity` >= D_eff duplicates.
  * `image` may be NULL when no backward will follow. Asynchronous on `stream`. */
-int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
+int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, void* geom, void* tiles,
                                void* bins, size_t bins_bytes, int64_t dup_capacity,
                                float* out_color, float* out_depth, float* out_alpha,
                                void* image, size_t image_bytes, void* stream);
 
 /* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
- * be NULL (= zeros). Needs the forward's blobs and outputs unchanged. Asynchronous. */
+ * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same dup_capacity, image)
+ * and radii unchanged. `dupgrad` is scratch for dup_capacity duplicates (sfgs_raster_sizes). Every
+ * gradient tensor in `grads` is fully overwritten. Deterministic (no float atomics). Asynchronous. */
 int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
-                         const void* geom, const void* tiles, const void* bins, const void* image,
-                         const float* out_color, const float* out_depth, const float* out_alpha,
-                         const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                         void* dupgrad, size_t dupgrad_bytes, const SfgsGaussianGrads* grads,
-                         void* stream);
+                         const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
+                         const void* image, const float* dL_dcolor, const float* dL_ddepth,
+                         const float* dL_dalpha, void* dupgrad, size_t dupgrad_bytes,
+                         const SfgsGaussianGrads* grads, void* stream);
 
 /* fused_ssim: mean SSIM (11x11 Gaussian window, sigma 1.5, zero "same" padding, C1=0.01^2,
  * C2=0.03^2 == utils/loss_utils.py:23-63) of img1,img2 [B,C,H,W] float32.
- * forward: writes the per-element SSIM map sum into *ssim_sum (device float, must be zeroed by
- * the library: it is) and, when partials != NULL, the three [B,C,H,W] partial-derivative maps the
- * backward consumes. backward: dL_dimg1 = dL_dmean_ssim * d(mean ssim)/d(img1). */
-size_t sfgs_ssim_partials_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+ * forward: writes the mean into *ssim_mean (device float), the per-element map into ssim_map when
+ * non-NULL and, when with_grad != 0, the three partial-derivative maps the backward consumes into
+ * `scratch` (sfgs_ssim_scratch_bytes). The mean is reduced in a fixed order (bit-reproducible).
+ * backward: dL_dimg1 = *dL_dmean (device float) * d(mean ssim)/d(img1); img2 gets no gradient
+ * (it is the ground truth, train.py:222). */
+size_t sfgs_ssim_scratch_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t with_grad);
 int sfgs_ssim_forward(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H,
-                      int32_t W, float* ssim_map_or_null, float* ssim_sum, float* partials_or_null,
-                      void* stream);
+                      int32_t W, float* ssim_map_or_null, float* ssim_mean, void* scratch,
+                      size_t scratch_bytes, int32_t with_grad, void* stream);
 int sfgs_ssim_backward(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H,
-                       int32_t W, const float* partials, const float* dL_dmean, float* dL_dimg1,
+                       int32_t W, const void* scratch, const float* dL_dmean, float* dL_dimg1,
                        void* stream);
 
 /* simple_knn distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other
- * points. scratch: sfgs_knn_scratch_bytes(N). */
+ * points (index-excluded; fewer than 3 others: mean over those that exist). Exact. scratch:
+ * sfgs_knn_scratch_bytes(N) bytes (currently 0; may be NULL). */
 size_t sfgs_knn_scratch_bytes(int32_t N);
 int sfgs_knn_dist2(const float* xyz, int32_t N, float* out, void* scratch, size_t scratch_bytes,
                    void* stream);

@@ -1,0 +1,241 @@
+// raster_bwd.hip -- backward of the Gaussian-splat rasterizer for gfx950 (MI355X).
+//
+// Replaces the autograd backward of diff_gauss.GaussianRasterizer (reference: triggered at
+// train.py:279,845; gradient contract scene/gaussian_model.py:744-749). Two kernels:
+//
+//   composite_bwd   one wave per 8x8 tile, back to front over the tile's sorted list;
+//                   the 12 per-pixel partial gradients of every (splat, tile) pair are reduced across
+//                   the wave with DPP row operations and written as ONE 64-byte line per duplicate
+//                   (no float atomics: the result is bit-reproducible).
+//   preprocess_bwd  one thread per Gaussian: sums its duplicates' lines in a fixed order and applies
+//                   the 2D -> 3D chain rule (raster_math.h: preprocess_backward_one).
+//
+// Compile with -ffp-contract=off (the forward's alpha/skip decisions must be reproduced exactly; FMA
+// only where spelled fmaf, identically to raster_fwd.hip).
+#include "sfgs_internal.h"
+
+namespace sfgs {
+
+// sum over the 64 lanes of a wave; the total is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32_t* __restrict__ tile_start,
+                     const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
+                     const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
+                     const float* __restrict__ final_T, const float* __restrict__ dacc,
+                     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                     const float* __restrict__ dL_dalpha, float4* __restrict__ dupgrad) {
+  __shared__ float4 stage[4][64 * 3];
+  __shared__ float4 gstage[4][64 * 3];
+  const unsigned sb = xcd_remap(blockIdx.x, nblk);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
+  if (tx >= TX8 || ty >= TY8) return;
+  const int W = kf.W, H = kf.H;
+  const size_t P = (size_t)W * H;
+  const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const size_t pix = (size_t)py * W + px;
+  const int t = ty * TX8 + tx;
+  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const unsigned L = e - s;
+  if (L == 0) return;
+
+  float sx = (float)px, sy = (float)py;
+  unsigned last = 0;
+  PixelBwd ps;
+  {
+    float T_final = 1.f, dac = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gdep = 0.f, galp = 0.f;
+    if (inside) {
+      if (kf.subpix) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
+      last = n_contrib[pix];
+      T_final = final_T[pix];
+      dac = dacc[pix];
+      if (dL_dcolor) { gr = dL_dcolor[pix]; gg = dL_dcolor[P + pix]; gb = dL_dcolor[2 * P + pix]; }
+      if (dL_ddepth) gdep = dL_ddepth[pix];
+      if (dL_dalpha) galp = dL_dalpha[pix];
+    }
+    const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
+    pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
+  }
+  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+  unsigned kmax = last;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, d));
+
+  // list entries behind every pixel's last contributor receive zero gradient
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (unsigned k = kmax + lane; k < L; k += 64) {
+    float4* dst = dupgrad + (size_t)sorted_dup[s + k] * 4;
+    dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
+  }
+  if (kmax == 0) return;
+
+  float4* st = stage[wave];
+  float4* gs = gstage[wave];
+
+  const int nbatch = (int)((kmax + 63) / 64);
+  for (int bi = nbatch - 1; bi >= 0; --bi) {
+    const unsigned b0 = (unsigned)bi * 64;
+    const unsigned cnt = min(64u, kmax - b0);
+    unsigned my_dup = 0;
+    if ((unsigned)lane < cnt) {
+      const unsigned id = sorted_id[s + b0 + lane];
+      my_dup = sorted_dup[s + b0 + lane];
+      const float4 a0 = rec[3 * (size_t)id], a1 = rec[3 * (size_t)id + 1], a2 = rec[3 * (size_t)id + 2];
+      st[lane * 3] = a0; st[lane * 3 + 1] = a1; st[lane * 3 + 2] = a2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = (int)cnt - 1; j >= 0; --j) {
+      const unsigned k = b0 + (unsigned)j;  // 0-based list position
+      const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
+      const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
+      const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
+      const bool act = k < last && ev.ok;
+      float v[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) v[i] = 0.f;
+      if (act) pixel_bwd_step(ps, ev, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, ddelx_dx, ddely_dy, v);
+      if (__ballot(act) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = wave_sum_to_lane63(v[i]);
+      }
+      if (lane == 63) {
+        gs[j * 3] = make_float4(v[0], v[1], v[2], v[3]);
+        gs[j * 3 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        gs[j * 3 + 2] = make_float4(v[8], v[9], v[10], v[11]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((unsigned)lane < cnt) {
+      float4* dst = dupgrad + (size_t)my_dup * 4;
+      dst[0] = gs[lane * 3]; dst[1] = gs[lane * 3 + 1]; dst[2] = gs[lane * 3 + 2];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// one thread per Gaussian
+__global__ void __launch_bounds__(PRE_BLOCK)
+preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
+                      const float* __restrict__ rots, const float* __restrict__ opac,
+                      const float* __restrict__ shs, const int* __restrict__ radii,
+                      const uint32_t* __restrict__ dupoff, const float4* __restrict__ dupgrad,
+                      float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
+                      float* __restrict__ g_rots, float* __restrict__ g_opac, float* __restrict__ g_colors,
+                      float* __restrict__ g_shs) {
+  const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (g >= N) return;
+  const FrameParams f = load_frame(kf);
+  GaussGrads out;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { out.means3D[i] = 0.f; out.means2D[i] = 0.f; out.scales[i] = 0.f; out.rgb[i] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out.rot[i] = 0.f;
+  out.opacity = 0.f;
+  const bool vis = radii[g] > 0;
+  float* gsh = g_shs ? g_shs + 3 * (size_t)f.sh_coeffs * g : nullptr;
+  if (vis) {
+    const unsigned d0 = dupoff[g], d1 = dupoff[g + 1];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    for (unsigned d = d0; d < d1; ++d) {
+      const float4 x0 = dupgrad[(size_t)d * 4], x1 = dupgrad[(size_t)d * 4 + 1], x2 = dupgrad[(size_t)d * 4 + 2];
+      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+    }
+    Grad2D A;
+    A.gmx = a0.x; A.gmy = a0.y; A.absx = a0.z; A.absy = a0.w;
+    A.gA = a1.x; A.gB = a1.y; A.gC = a1.z; A.gop = a1.w;
+    A.grgb[0] = a2.x; A.grgb[1] = a2.y; A.grgb[2] = a2.z; A.gdepth = a2.w;
+    const float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
+    const float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
+    const float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
+    const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    float shl[48];
+    if (shs) {
+      for (int i = 0; i < 3 * f.sh_coeffs; ++i) shl[i] = shs[3 * (size_t)f.sh_coeffs * g + i];
+    }
+    float gshl[48];
+    preprocess_backward_one(f, p, s, q, opac[g], shs ? shl : nullptr, A, out, gshl);
+    if (gsh) for (int i = 0; i < 3 * f.sh_coeffs; ++i) gsh[i] = gshl[i];
+  } else if (gsh) {
+    for (int i = 0; i < 3 * f.sh_coeffs; ++i) gsh[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g_means3D[3 * (size_t)g + i] = out.means3D[i];
+    g_means2D[3 * (size_t)g + i] = out.means2D[i];
+    g_scales[3 * (size_t)g + i] = out.scales[i];
+  }
+  *reinterpret_cast<float4*>(g_rots + 4 * (size_t)g) = make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]);
+  g_opac[g] = out.opacity;
+  if (g_colors) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g_colors[3 * (size_t)g + i] = out.rgb[i];
+  }
+}
+
+}  // namespace sfgs
+
+using namespace sfgs;
+
+extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
+                                    const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
+                                    const void* image, const float* dL_dcolor, const float* dL_ddepth,
+                                    const float* dL_dalpha, void* dupgrad, size_t dupgrad_sz,
+                                    const SfgsGaussianGrads* grads, void* stream_) {
+  SFGS_REQUIRE(frame && frame->struct_size == sizeof(SfgsFrame), SFGS_E_ARG, "SfgsFrame.struct_size mismatch");
+  SFGS_REQUIRE(g && g->struct_size == sizeof(SfgsGaussians), SFGS_E_ARG, "SfgsGaussians.struct_size mismatch");
+  SFGS_REQUIRE(grads && grads->struct_size == sizeof(SfgsGaussianGrads), SFGS_E_ARG,
+               "SfgsGaussianGrads.struct_size mismatch");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = g->count, W = frame->image_width, H = frame->image_height;
+  if (N == 0) return SFGS_OK;
+  SFGS_REQUIRE(radii && geom && tiles && image, SFGS_E_ARG, "forward state pointer is NULL");
+  SFGS_REQUIRE(grads->means3D && grads->means2D && grads->scales && grads->rotations && grads->opacities, SFGS_E_ARG,
+               "gradient output pointer is NULL");
+  SFGS_REQUIRE((g->colors_precomp != nullptr) == (grads->colors_precomp != nullptr) &&
+                   (g->shs != nullptr) == (grads->shs != nullptr),
+               SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
+  SFGS_REQUIRE(dup_capacity >= 0 && dupgrad_sz >= dupgrad_bytes(dup_capacity), SFGS_E_CAPACITY,
+               "dupgrad blob: %zu bytes given, %zu needed", dupgrad_sz, dupgrad_bytes(dup_capacity));
+  SFGS_REQUIRE(dup_capacity == 0 || (bins && dupgrad), SFGS_E_ARG, "bins / dupgrad is NULL");
+  const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
+  const GeomView gv = geom_view(const_cast<void*>(geom), N);
+  const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity);
+  const ImageView iv = image_view(const_cast<void*>(image), W, H);
+  const KFrame kf = make_kframe(frame);
+  const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
+  const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
+  { ProfScope ps_(KID_COMPOSITE_BWD, stream);
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+                       bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
+                       dL_dalpha, (float4*)dupgrad); }
+  SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
+  const int NB = (int)pre_blocks(N);
+  { ProfScope ps_(KID_PREPROCESS_BWD, stream);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
+                       g->rotations, g->opacities, g->shs, radii, gv.dupoff, (const float4*)dupgrad, grads->means3D,
+                       grads->means2D, grads->scales, grads->rotations, grads->opacities, grads->colors_precomp,
+                       grads->shs); }
+  SFGS_POST_LAUNCH("preprocess_bwd", stream, frame->debug);
+  return SFGS_OK;
+}

@@ -1,0 +1,502 @@
+// raster_fwd.hip -- forward of the Gaussian-splat rasterizer for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces diff_gauss.GaussianRasterizer.__call__ (reference: gaussian_renderer/__init__.py:132-140)
+// behind the C ABI of include/sfgs.h. Kernel chain (all wave64, no MFMA: the path is gather/sort/VALU
+// bound):
+//
+//   plan:    subpix_bound  -> preprocess (per Gaussian: project, radii, record, opacity-aware
+//            8x8-tile count) -> plan_scan (tile starts, per-block duplicate bases, counters)
+//   render:  scatter (per Gaussian: emit (depth|dup) keys into per-tile segments)
+//            -> sort_tiles (per tile: normalised bitonic network in LDS / global for long lists)
+//            -> composite (one wave per 8x8 tile, front to back, records staged through LDS)
+//
+// Compile with -ffp-contract=off: integer outputs depend on exact float32 sequences (raster_math.h).
+#include <algorithm>
+
+#include "sfgs_internal.h"
+
+namespace sfgs {
+
+// ------------------------------------------------------------------------------------------------
+// max |subpixel_offset| -> header (float bits; non-negative floats order like unsigned ints)
+__global__ void __launch_bounds__(256) subpix_bound_kernel(const float* __restrict__ subpix, int64_t n,
+                                                           unsigned long long* __restrict__ hdr) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(subpix[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if (lane_id() == 0) atomicMax((unsigned int*)&hdr[HDR_SUBPIX_BOUND], __float_as_uint(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one thread per Gaussian.
+__global__ void __launch_bounds__(PRE_BLOCK)
+preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
+                  const float* __restrict__ rots, const float* __restrict__ opac,
+                  const float* __restrict__ colors, const float* __restrict__ shs, int* __restrict__ radii,
+                  float4* __restrict__ rec_out, uint32_t* __restrict__ dupcnt, uint2* __restrict__ brange,
+                  uint32_t* __restrict__ tile_count,
+                  uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_nvis,
+                  unsigned long long* __restrict__ block_dref, const unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
+  const FrameParams f = load_frame(kf);
+  const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
+  const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  unsigned n_dup = 0, vis = 0, dref = 0;
+  if (g < N) {
+    float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
+    float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
+    const float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
+    float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    const Projected pr = project_gaussian(f, p, s, q);
+    radii[g] = pr.radius;
+    if (pr.visible) {
+      vis = 1;
+      dref = (unsigned)((pr.rmaxx - pr.rminx) * (pr.rmaxy - pr.rminy));
+      float rgb[3];
+      if (colors) {
+        rgb[0] = colors[3 * (size_t)g]; rgb[1] = colors[3 * (size_t)g + 1]; rgb[2] = colors[3 * (size_t)g + 2];
+      } else {
+        unsigned mask; float dir[3], len;
+        sh_to_rgb(f.sh_degree, shs + 3 * (size_t)f.sh_coeffs * g, p, f.campos, rgb, &mask, dir, &len);
+      }
+      const SplatRec r = make_record(pr, opac[g], rgb);
+      rec_out[3 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
+      rec_out[3 * (size_t)g + 1] = make_float4(r.qc, r.op, r.depth, r.r);
+      rec_out[3 * (size_t)g + 2] = make_float4(r.g, r.b, r.ex, r.ey);
+      const BinRange br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
+      brange[g] = make_uint2((unsigned)br.x0 | ((unsigned)br.x1 << 16), (unsigned)br.y0 | ((unsigned)br.y1 << 16));
+      const float thr = alpha_threshold_log2(r.op);
+      const int TX8 = (f.W + TILE_BIN - 1) / TILE_BIN;
+      for (int ty = br.y0; ty < br.y1; ++ty)
+        for (int tx = br.x0; tx < br.x1; ++tx)
+          if (bin_test(r, thr, tx, ty, f.W, f.H, bound)) {
+            atomicAdd(&tile_count[ty * TX8 + tx], 1u);
+            ++n_dup;
+          }
+    }
+    dupcnt[g] = n_dup;
+  }
+  // per-block totals (no contended atomics: plan_scan sums them)
+  unsigned total;
+  block_excl_scan_u32<PRE_BLOCK>(n_dup, &total, s_red);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  block_excl_scan_u32<PRE_BLOCK>(vis, &total, s_red);
+  if (threadIdx.x == 0) block_nvis[blockIdx.x] = total;
+  block_excl_scan_u32<PRE_BLOCK>(dref, &total, s_red);
+  if (threadIdx.x == 0) block_dref[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: single workgroup. Exclusive scans of tile_count -> tile_start and block_sums -> block_base,
+// plus the counters the host reads back.
+constexpr int SCAN_NT = 1024;
+__global__ void __launch_bounds__(SCAN_NT)
+plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_base,
+                 const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
+                 unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_red[SCAN_NT / 64 + 1];
+  __shared__ unsigned long long s_acc[SCAN_NT / 64];
+  unsigned carry = 0, maxlen = 0;
+  for (int base = 0; base < T8; base += SCAN_NT) {
+    const int i = base + threadIdx.x;
+    const unsigned v = i < T8 ? tile_count[i] : 0u;
+    maxlen = max(maxlen, v);
+    unsigned total;
+    const unsigned ex = block_excl_scan_u32<SCAN_NT>(v, &total, s_red);
+    if (i < T8) tile_start[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) { tile_start[T8] = carry; hdr[HDR_D_EFF] = carry; }
+  // max list length
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (unsigned)__shfl_xor((int)maxlen, d));
+  if (lane_id() == 0) s_red[threadIdx.x >> 6] = maxlen;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned m = 0;
+    for (int w = 0; w < SCAN_NT / 64; ++w) m = max(m, s_red[w]);
+    hdr[HDR_MAX_LIST] = m;
+  }
+  __syncthreads();
+  // per-block duplicate bases
+  carry = 0;
+  unsigned long long nvis = 0, dref = 0;
+  for (int base = 0; base < NB; base += SCAN_NT) {
+    const int i = base + threadIdx.x;
+    const unsigned v = i < NB ? block_sums[i] : 0u;
+    if (i < NB) { nvis += block_nvis[i]; dref += block_dref[i]; }
+    unsigned total;
+    const unsigned ex = block_excl_scan_u32<SCAN_NT>(v, &total, s_red);
+    if (i < NB) block_base[i] = carry + ex;
+    carry += total;
+  }
+  // reduce nvis / dref
+  for (int pass = 0; pass < 2; ++pass) {
+    unsigned long long v = pass == 0 ? nvis : dref;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane_id() == 0) s_acc[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < SCAN_NT / 64; ++w) t += s_acc[w];
+      hdr[pass == 0 ? HDR_N_VIS : HDR_D_REF] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: scatter. Thread g re-walks its tile range (same deterministic test as K1) and emits one key per
+// binned tile. dupoff[g] (count) becomes the exclusive duplicate offset of Gaussian g.
+__global__ void __launch_bounds__(PRE_BLOCK)
+scatter_kernel(KFrame kf, int N, const float4* __restrict__ rec_in, const uint2* __restrict__ brange,
+               uint32_t* __restrict__ dupoff, const uint32_t* __restrict__ block_base,
+               const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+               unsigned long long* __restrict__ keys, uint32_t* __restrict__ dup_gauss,
+               unsigned long long dup_capacity, unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
+  const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const unsigned cnt = g < N ? dupoff[g] : 0u;
+  unsigned total;
+  const unsigned off = block_base[blockIdx.x] + block_excl_scan_u32<PRE_BLOCK>(cnt, &total, s_red);
+  if (g >= N) return;
+  dupoff[g] = off;
+  if (g == N - 1) dupoff[N] = off + cnt;
+  if (cnt == 0) return;
+  if ((unsigned long long)off + cnt > dup_capacity) {
+    hdr[HDR_OVERFLOW] = 1ull;
+    return;
+  }
+  const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
+  const int W = kf.W, H = kf.H;
+  const float4 r0 = rec_in[3 * (size_t)g], r1 = rec_in[3 * (size_t)g + 1], r2 = rec_in[3 * (size_t)g + 2];
+  SplatRec r;
+  r.mx = r0.x; r.my = r0.y; r.qa = r0.z; r.qb = r0.w;
+  r.qc = r1.x; r.op = r1.y; r.depth = r1.z; r.r = r1.w;
+  r.g = r2.x; r.b = r2.y; r.ex = r2.z; r.ey = r2.w;
+  const uint2 pk = brange[g];
+  BinRange br;
+  br.x0 = (int)(pk.x & 0xffffu); br.x1 = (int)(pk.x >> 16);
+  br.y0 = (int)(pk.y & 0xffffu); br.y1 = (int)(pk.y >> 16);
+  const float thr = alpha_threshold_log2(r.op);
+  const int TX8 = (W + TILE_BIN - 1) / TILE_BIN;
+  const unsigned long long khi = (unsigned long long)__float_as_uint(r.depth) << 32;
+  unsigned j = 0;
+  for (int ty = br.y0; ty < br.y1; ++ty)
+    for (int tx = br.x0; tx < br.x1; ++tx)
+      if (bin_test(r, thr, tx, ty, W, H, bound)) {
+        const int t = ty * TX8 + tx;
+        const unsigned pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+        const unsigned d = off + j;
+        keys[pos] = khi | d;
+        dup_gauss[d] = (unsigned)g;
+        ++j;
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-tile sort of 64-bit keys (depth bits, duplicate index) == ascending (depth, Gaussian id),
+// SURVEY A.3. Normalised bitonic network: every comparator sorts ascending, so +inf padding stays at
+// the tail. One wave per tile, list in LDS.
+template <int CAP>
+__global__ void __launch_bounds__(64)
+sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_start,
+                      const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ dup_gauss,
+                      uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
+  __shared__ unsigned long long k[CAP];
+  const int t = blockIdx.x;
+  if (t >= T8) return;
+  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const int L = (int)(e - s);
+  if (L <= lo || L > hi) return;
+  const int lane = threadIdx.x;
+  int n = 1;
+  while (n < L) n <<= 1;
+  for (int i = lane; i < n; i += 64) k[i] = i < L ? keys[s + i] : ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= n; size <<= 1) {
+    const int half = size >> 1;
+    for (int c = lane; c < (n >> 1); c += 64) {
+      const int blk = c / half, o = c - blk * half;
+      const int i = blk * size + o, j = blk * size + size - 1 - o;
+      const unsigned long long a = k[i], b = k[j];
+      if (a > b) { k[i] = b; k[j] = a; }
+    }
+    __syncthreads();
+    for (int stride = half >> 1; stride >= 1; stride >>= 1) {
+      for (int c = lane; c < (n >> 1); c += 64) {
+        const int i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
+        const unsigned long long a = k[i], b = k[j];
+        if (a > b) { k[i] = b; k[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = lane; i < L; i += 64) {
+    const unsigned d = (unsigned)(k[i] & 0xffffffffull);
+    sorted_dup[s + i] = d;
+    sorted_id[s + i] = dup_gauss[d];
+  }
+}
+
+// Long lists: same network on the tile's segment in global memory (virtual padding: comparators that
+// reach past the end are no-ops). Rare path; agent-scope relaxed accesses bypass the per-CU L1 so
+// that waves of the block see each other's exchanges after the barrier.
+__global__ void __launch_bounds__(256)
+sort_tiles_global_kernel(int T8, int lo, const uint32_t* __restrict__ tile_start, unsigned long long* keys,
+                         const uint32_t* __restrict__ dup_gauss, uint32_t* __restrict__ sorted_id,
+                         uint32_t* __restrict__ sorted_dup) {
+  const int t = blockIdx.x;
+  if (t >= T8) return;
+  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const long long L = (long long)e - s;
+  if (L <= lo) return;
+  unsigned long long* k = keys + s;
+  long long n = 1;
+  while (n < L) n <<= 1;
+  auto ld = [&](long long i) { return __hip_atomic_load(&k[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st = [&](long long i, unsigned long long v) {
+    __hip_atomic_store(&k[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (long long size = 2; size <= n; size <<= 1) {
+    const long long half = size >> 1;
+    for (long long c = threadIdx.x; c < (n >> 1); c += 256) {
+      const long long blk = c / half, o = c - blk * half;
+      const long long i = blk * size + o, j = blk * size + size - 1 - o;
+      if (j < L) {
+        const unsigned long long a = ld(i), b = ld(j);
+        if (a > b) { st(i, b); st(j, a); }
+      }
+    }
+    __syncthreads();
+    for (long long stride = half >> 1; stride >= 1; stride >>= 1) {
+      for (long long c = threadIdx.x; c < (n >> 1); c += 256) {
+        const long long i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
+        if (j < L) {
+          const unsigned long long a = ld(i), b = ld(j);
+          if (a > b) { st(i, b); st(j, a); }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (long long i = threadIdx.x; i < L; i += 256) {
+    const unsigned d = (unsigned)(ld(i) & 0xffffffffull);
+    sorted_dup[s + i] = d;
+    sorted_id[s + i] = dup_gauss[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: compositing. Workgroup = 4 independent waves = a 2x2 block of 8x8 tiles; lane l of
+// a wave owns pixel (l & 7, l >> 3) of its tile. Records of 64 list entries at a time are gathered
+// (48 B each) into a wave-private LDS stage and consumed with uniform-address (broadcast) reads.
+// No barriers: a wave only ever reads what it wrote itself.
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32_t* __restrict__ tile_start,
+                     const uint32_t* __restrict__ sorted_id, const float4* __restrict__ rec,
+                     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                     uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out) {
+  __shared__ float4 stage[4][64 * 3];
+  const unsigned sb = xcd_remap(blockIdx.x, nblk);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
+  if (tx >= TX8 || ty >= TY8) return;
+  const int W = kf.W, H = kf.H;
+  const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const size_t pix = (size_t)py * W + px;
+  float sx = (float)px, sy = (float)py;
+  if (kf.subpix && inside) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
+
+  const int t = ty * TX8 + tx;
+  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  PixelFwd ps;
+  ps.T = 1.f; ps.C0 = ps.C1 = ps.C2 = ps.D = 0.f; ps.last = 0; ps.done = !inside;
+  float4* st = stage[wave];
+  for (unsigned b = s; b < e; b += 64) {
+    if (__ballot(!ps.done) == 0ull) break;
+    const unsigned cnt = min(64u, e - b);
+    if ((unsigned)lane < cnt) {
+      const unsigned id = sorted_id[b + lane];
+      const float4 a0 = rec[3 * (size_t)id], a1 = rec[3 * (size_t)id + 1], a2 = rec[3 * (size_t)id + 2];
+      st[lane * 3] = a0; st[lane * 3 + 1] = a1; st[lane * 3 + 2] = a2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (unsigned j = 0; j < cnt; ++j) {
+      const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
+      const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
+      const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
+      pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, b - s + j);
+      if (__ballot(!ps.done) == 0ull) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float T = ps.T, C0 = ps.C0, C1 = ps.C1, C2 = ps.C2, D = ps.D;
+  const unsigned last = ps.last;
+  if (inside) {
+    const size_t P = (size_t)W * H;
+    out_color[pix] = fmaf(T, kf.bg[0], C0);
+    out_color[P + pix] = fmaf(T, kf.bg[1], C1);
+    out_color[2 * P + pix] = fmaf(T, kf.bg[2], C2);
+    const float a = 1.0f - T;
+    out_alpha[pix] = a;
+    out_depth[pix] = kf.depth_mode == SFGS_DEPTH_NORMALISED ? D / a : D;
+    if (n_contrib) { n_contrib[pix] = last; final_T[pix] = T; dacc_out[pix] = D; }
+  }
+}
+
+}  // namespace sfgs
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace sfgs;
+
+static int check_frame(const SfgsFrame* f) {
+  SFGS_REQUIRE(f != nullptr, SFGS_E_ARG, "frame is NULL");
+  SFGS_REQUIRE(f->struct_size == sizeof(SfgsFrame), SFGS_E_ARG, "SfgsFrame.struct_size %u != %zu (ABI mismatch)",
+               f->struct_size, sizeof(SfgsFrame));
+  SFGS_REQUIRE(f->image_width > 0 && f->image_height > 0, SFGS_E_ARG, "image size %dx%d", f->image_width,
+               f->image_height);
+  SFGS_REQUIRE(f->bg && f->viewmatrix && f->projmatrix && f->campos, SFGS_E_ARG, "frame tensor pointer is NULL");
+  SFGS_REQUIRE(f->sh_degree >= 0 && f->sh_degree <= 3, SFGS_E_UNSUPPORTED, "sh_degree %d not in 0..3", f->sh_degree);
+  SFGS_REQUIRE(f->tanfovx > 0.f && f->tanfovy > 0.f, SFGS_E_ARG, "tanfov must be positive");
+  SFGS_REQUIRE((int64_t)f->image_width * f->image_height < (1ll << 31), SFGS_E_UNSUPPORTED, "image too large");
+  return SFGS_OK;
+}
+
+static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
+  SFGS_REQUIRE(g != nullptr, SFGS_E_ARG, "gaussians is NULL");
+  SFGS_REQUIRE(g->struct_size == sizeof(SfgsGaussians), SFGS_E_ARG, "SfgsGaussians.struct_size mismatch");
+  SFGS_REQUIRE(g->count >= 0, SFGS_E_ARG, "negative Gaussian count");
+  if (g->count > 0) {
+    SFGS_REQUIRE(g->means3D && g->scales && g->rotations && g->opacities, SFGS_E_ARG, "Gaussian tensor pointer is NULL");
+    SFGS_REQUIRE((g->colors_precomp != nullptr) != (g->shs != nullptr), SFGS_E_ARG,
+                 "provide exactly one of colors_precomp / shs");
+    if (g->shs)
+      SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) && f->sh_coeffs <= 16, SFGS_E_ARG,
+                   "sh_coeffs %d too small for degree %d (or > 16)", f->sh_coeffs, f->sh_degree);
+  }
+  return SFGS_OK;
+}
+
+extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, SfgsRasterSizes* out) {
+  SFGS_REQUIRE(out && out->struct_size == sizeof(SfgsRasterSizes), SFGS_E_ARG, "SfgsRasterSizes.struct_size mismatch");
+  SFGS_REQUIRE(N >= 0 && W > 0 && H > 0 && D >= 0, SFGS_E_ARG, "bad sizes N=%d W=%d H=%d D=%lld", N, W, H, (long long)D);
+  SFGS_REQUIRE(D < (1ll << 32), SFGS_E_UNSUPPORTED, "more than 2^32 duplicates");
+  size_t tb = 0;
+  tiles_view(nullptr, W, H, N, &tb);
+  out->geom_bytes = geom_bytes(N);
+  out->tiles_bytes = tb;
+  out->bins_bytes = bins_bytes(D);
+  out->image_bytes = image_bytes(W, H);
+  out->dupgrad_bytes = dupgrad_bytes(D);
+  return SFGS_OK;
+}
+
+extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* geom,
+                                        size_t geom_sz, void* tiles, size_t tiles_sz, void* stream_) {
+  if (int rc = check_frame(frame)) return rc;
+  if (int rc = check_gaussians(frame, g)) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = g->count, W = frame->image_width, H = frame->image_height;
+  size_t tb = 0;
+  SFGS_REQUIRE(tiles != nullptr, SFGS_E_ARG, "tiles blob is NULL");
+  const TilesView tv = tiles_view(tiles, W, H, N, &tb);
+  SFGS_REQUIRE(tiles_sz >= tb, SFGS_E_CAPACITY, "tiles blob: %zu bytes given, %zu needed", tiles_sz, tb);
+  SFGS_REQUIRE(geom_sz >= geom_bytes(N), SFGS_E_CAPACITY, "geom blob: %zu bytes given, %zu needed", geom_sz, geom_bytes(N));
+  SFGS_REQUIRE(N == 0 || (radii && geom), SFGS_E_ARG, "radii / geom is NULL");
+  const GeomView gv = geom_view(geom, N);
+  const KFrame kf = make_kframe(frame);
+  const int T8 = (int)tiles8(W, H), NB = (int)pre_blocks(N);
+  SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
+  if (frame->subpixel_offset) {
+    const int64_t n = (int64_t)W * H * 2;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    { ProfScope ps_(KID_SUBPIX, stream);
+      hipLaunchKernelGGL(subpix_bound_kernel, dim3(blocks), dim3(256), 0, stream, frame->subpixel_offset, n, tv.hdr); }
+    SFGS_POST_LAUNCH("subpix_bound", stream, frame->debug);
+  }
+  if (NB > 0) {
+    { ProfScope ps_(KID_PREPROCESS, stream);
+      hipLaunchKernelGGL(preprocess_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
+                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dupoff, gv.brange,
+                         tv.tile_count,
+                         tv.block_sums, tv.block_nvis, tv.block_dref, tv.hdr); }
+    SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
+  }
+  { ProfScope ps_(KID_PLAN_SCAN, stream);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, T8, NB, tv.tile_count, tv.tile_start,
+                       tv.block_sums, tv.block_base, tv.block_nvis, tv.block_dref, tv.hdr); }
+  SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
+  return SFGS_OK;
+}
+
+extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream_) {
+  SFGS_REQUIRE(tiles && out, SFGS_E_ARG, "NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned long long h[8];
+  SFGS_CHECK_HIP(hipMemcpyAsync(h, tiles, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SFGS_CHECK_HIP(hipStreamSynchronize(stream));
+  out->num_duplicates = (int64_t)h[HDR_D_EFF];
+  out->num_duplicates_ref = (int64_t)h[HDR_D_REF];
+  out->num_visible = (int64_t)h[HDR_N_VIS];
+  out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
+  return SFGS_OK;
+}
+
+constexpr int SORT_SMALL = 512, SORT_CAP = 4096;
+
+extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, void* geom,
+                                          void* tiles, void* bins, size_t bins_sz, int64_t dup_capacity,
+                                          float* out_color, float* out_depth, float* out_alpha, void* image,
+                                          size_t image_sz, void* stream_) {
+  if (int rc = check_frame(frame)) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int W = frame->image_width, H = frame->image_height;
+  SFGS_REQUIRE(N >= 0 && tiles && out_color && out_depth && out_alpha, SFGS_E_ARG, "NULL argument");
+  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32), SFGS_E_ARG, "bad dup_capacity");
+  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity), SFGS_E_CAPACITY, "bins blob: %zu bytes given, %zu needed", bins_sz,
+               bins_bytes(dup_capacity));
+  SFGS_REQUIRE(image == nullptr || image_sz >= image_bytes(W, H), SFGS_E_CAPACITY, "image blob too small");
+  SFGS_REQUIRE(dup_capacity == 0 || bins, SFGS_E_ARG, "bins blob is NULL");
+  const TilesView tv = tiles_view(tiles, W, H, N, nullptr);
+  const GeomView gv = geom_view(const_cast<void*>(geom), N);
+  const BinsView bv = bins_view(bins, dup_capacity);
+  const KFrame kf = make_kframe(frame);
+  const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN, T8 = TX8 * TY8;
+  const int NB = (int)pre_blocks(N);
+  if (NB > 0) {
+    { ProfScope ps_(KID_SCATTER, stream);
+      hipLaunchKernelGGL(scatter_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, gv.rec, gv.brange, gv.dupoff,
+                         tv.block_base, tv.tile_start, tv.tile_cursor, bv.keys, bv.dup_gauss,
+                         (unsigned long long)dup_capacity, tv.hdr); }
+    SFGS_POST_LAUNCH("scatter", stream, frame->debug);
+    { ProfScope ps_(KID_SORT_SMALL, stream);
+      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_SMALL>, dim3(T8), dim3(64), 0, stream, T8, 0, SORT_SMALL,
+                         tv.tile_start, bv.keys, bv.dup_gauss, bv.sorted_id, bv.sorted_dup); }
+    SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
+    { ProfScope ps_(KID_SORT_MEDIUM, stream);
+      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(T8), dim3(64), 0, stream, T8, SORT_SMALL, SORT_CAP,
+                         tv.tile_start, bv.keys, bv.dup_gauss, bv.sorted_id, bv.sorted_dup); }
+    SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
+    { ProfScope ps_(KID_SORT_GLOBAL, stream);
+      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_start, bv.keys,
+                         bv.dup_gauss, bv.sorted_id, bv.sorted_dup); }
+    SFGS_POST_LAUNCH("sort_tiles_global", stream, frame->debug);
+  }
+  ImageView iv = {nullptr, nullptr, nullptr};
+  if (image) iv = image_view(image, W, H);
+  const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
+  { ProfScope ps_(KID_COMPOSITE_FWD, stream);
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+                       bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T, iv.dacc); }
+  SFGS_POST_LAUNCH("composite_fwd", stream, frame->debug);
+  return SFGS_OK;
+}

@@ -1,0 +1,627 @@
+// raster_math.h -- per-Gaussian math of the rasterizer hot path (pure functions, no memory traffic).
+//
+// Everything here is SFGS_HD (= __host__ __device__ under hipcc, nothing under g++) so that the
+// same source is (a) inlined into the gfx950 kernels of raster_fwd.hip / raster_bwd.hip and (b)
+// compiled by g++ into tests/host_check (CPU "host logic" tests, no GPU needed).
+//
+// Reference behaviour implemented (paths relative to the reference tree; [UPSTREAM] = public
+// 3DGS / Mip-Splatting algorithm, SURVEY Appendix A -- the rasterizer source itself is an
+// un-vendored submodule):
+//   conventions        scene/cameras.py:62-73, utils/graphics_utils.py:106-126
+//   quaternion -> R    utils/general_utils.py:78-99
+//   Sigma packing      utils/general_utils.py:64-76
+//   SH basis           utils/sh_utils.py:57-112 ; +0.5 / clamp gaussian_renderer/__init__.py:116-117
+//   near plane 0.2     scene/gaussian_model.py:276
+//
+// Every value that decides an INTEGER output (radius, tile rectangle, visibility) is computed as
+// a fixed sequence of IEEE-754 float32 operations: this file must be compiled with
+// -ffp-contract=off, and FMA is only used where spelled fmaf().
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define SFGS_HD __host__ __device__ __forceinline__
+#else
+#define SFGS_HD static inline
+#endif
+
+namespace sfgs {
+
+constexpr int TILE_REF = 16;  // tile edge of the visibility rule ([UPSTREAM] BLOCK_X/Y)
+constexpr int TILE_BIN = 8;   // tile edge of OUR binning: one wave64 = one 8x8 pixel tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct FrameParams {  // host-side scalars + the three small camera tensors copied to kernel args
+  int W, H;
+  float tanfovx, tanfovy, kernel_size, scale_modifier;
+  int sh_degree, sh_coeffs, depth_mode;
+  float view[16], proj[16], campos[3], bg[3];
+};
+
+// 12-float record consumed by the compositing kernels (one 48-byte gather per list entry).
+struct SplatRec {
+  float mx, my;       // pixel-space mean
+  float qa, qb;       // log2-domain conic: p2 = qa dx^2 + qb dx dy + qc dy^2 ; alpha = op * 2^p2
+  float qc, op;       // op = opacity * mip coefficient
+  float depth, r;     // view-space z ; colour r
+  float g, b;         // colour g, b
+  float ex, ey;       // half extents (pixels) of the region where alpha can reach 1/255 (-1: nowhere)
+};
+
+struct Projected {
+  bool visible;
+  int radius;
+  int rminx, rminy, rmaxx, rmaxy;  // 16x16 tile rectangle [min,max)
+  float mx, my;
+  float a, b, c;      // filtered 2D covariance
+  float a0, b0, c0;   // unfiltered
+  float cA, cB, cC;   // conic
+  float coef;
+  float tx, ty, tz;
+  float cov3d[6];
+};
+
+SFGS_HD int f2i_sat(float v) {
+  if (v >= 2147483520.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)v;
+}
+SFGS_HD int imin(int a, int b) { return a < b ? a : b; }
+SFGS_HD int imax(int a, int b) { return a > b ? a : b; }
+
+SFGS_HD void quat_to_rot(const float* q, float R[9]) {
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1.f - 2.f * (y * y + z * z);
+  R[1] = 2.f * (x * y - r * z);
+  R[2] = 2.f * (x * z + r * y);
+  R[3] = 2.f * (x * y + r * z);
+  R[4] = 1.f - 2.f * (x * x + z * z);
+  R[5] = 2.f * (y * z - r * x);
+  R[6] = 2.f * (x * z - r * y);
+  R[7] = 2.f * (y * z + r * x);
+  R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+SFGS_HD void cov3d_of(const float* s, float mod, const float* q, float cov[6]) {
+  float R[9];
+  quat_to_rot(q, R);
+  const float S0 = mod * s[0], S1 = mod * s[1], S2 = mod * s[2];
+  const float M0 = R[0] * S0, M1 = R[1] * S1, M2 = R[2] * S2;
+  const float M3 = R[3] * S0, M4 = R[4] * S1, M5 = R[5] * S2;
+  const float M6 = R[6] * S0, M7 = R[7] * S1, M8 = R[8] * S2;
+  cov[0] = M0 * M0 + M1 * M1 + M2 * M2;
+  cov[1] = M0 * M3 + M1 * M4 + M2 * M5;
+  cov[2] = M0 * M6 + M1 * M7 + M2 * M8;
+  cov[3] = M3 * M3 + M4 * M4 + M5 * M5;
+  cov[4] = M3 * M6 + M4 * M7 + M5 * M8;
+  cov[5] = M6 * M6 + M7 * M7 + M8 * M8;
+}
+
+// rows of T = J * W2C (2x3), shared by forward and backward
+struct Jac {
+  float T0[3], T1[3];
+  float ux, uy, fx, fy, x_mul, y_mul;
+};
+
+SFGS_HD Jac ewa_jacobian(const FrameParams& f, float tx, float ty, float tz) {
+  Jac j;
+  const float limx = 1.3f * f.tanfovx, limy = 1.3f * f.tanfovy;
+  const float txtz = tx / tz, tytz = ty / tz;
+  j.ux = fminf(limx, fmaxf(-limx, txtz)) * tz;
+  j.uy = fminf(limy, fmaxf(-limy, tytz)) * tz;
+  j.x_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  j.y_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  j.fx = (float)f.W / (2.0f * f.tanfovx);
+  j.fy = (float)f.H / (2.0f * f.tanfovy);
+  const float J00 = j.fx / tz, J02 = -(j.fx * j.ux) / (tz * tz);
+  const float J11 = j.fy / tz, J12 = -(j.fy * j.uy) / (tz * tz);
+  for (int k = 0; k < 3; ++k) {
+    j.T0[k] = J00 * f.view[k * 4 + 0] + J02 * f.view[k * 4 + 2];
+    j.T1[k] = J11 * f.view[k * 4 + 1] + J12 * f.view[k * 4 + 2];
+  }
+  return j;
+}
+
+// SURVEY Appendix A.2 steps 1-8. Returns visible=false for culled Gaussians (radius 0).
+SFGS_HD Projected project_gaussian(const FrameParams& f, const float* p, const float* s, const float* q) {
+  Projected o;
+  o.visible = false;
+  o.radius = 0;
+  o.rminx = o.rminy = o.rmaxx = o.rmaxy = 0;
+  const float* V = f.view;
+  const float* PM = f.proj;
+  const float tx = V[0] * p[0] + V[4] * p[1] + V[8] * p[2] + V[12];
+  const float ty = V[1] * p[0] + V[5] * p[1] + V[9] * p[2] + V[13];
+  const float tz = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+  o.tx = tx; o.ty = ty; o.tz = tz;
+  if (!(tz > 0.2f)) return o;
+
+  const float hx = PM[0] * p[0] + PM[4] * p[1] + PM[8] * p[2] + PM[12];
+  const float hy = PM[1] * p[0] + PM[5] * p[1] + PM[9] * p[2] + PM[13];
+  const float hw = PM[3] * p[0] + PM[7] * p[1] + PM[11] * p[2] + PM[15];
+  const float pw = 1.0f / (hw + 0.0000001f);
+  const float ndcx = hx * pw, ndcy = hy * pw;
+
+  cov3d_of(s, f.scale_modifier, q, o.cov3d);
+  const float* c3 = o.cov3d;
+  const Jac j = ewa_jacobian(f, tx, ty, tz);
+  float v0[3], v1[3];
+  v0[0] = c3[0] * j.T0[0] + c3[1] * j.T0[1] + c3[2] * j.T0[2];
+  v0[1] = c3[1] * j.T0[0] + c3[3] * j.T0[1] + c3[4] * j.T0[2];
+  v0[2] = c3[2] * j.T0[0] + c3[4] * j.T0[1] + c3[5] * j.T0[2];
+  v1[0] = c3[0] * j.T1[0] + c3[1] * j.T1[1] + c3[2] * j.T1[2];
+  v1[1] = c3[1] * j.T1[0] + c3[3] * j.T1[1] + c3[4] * j.T1[2];
+  v1[2] = c3[2] * j.T1[0] + c3[4] * j.T1[1] + c3[5] * j.T1[2];
+  const float a0 = j.T0[0] * v0[0] + j.T0[1] * v0[1] + j.T0[2] * v0[2];
+  const float b0 = j.T0[0] * v1[0] + j.T0[1] * v1[1] + j.T0[2] * v1[2];
+  const float c0 = j.T1[0] * v1[0] + j.T1[1] * v1[1] + j.T1[2] * v1[2];
+  o.a0 = a0; o.b0 = b0; o.c0 = c0;
+
+  // Mip-Splatting 2D filter + opacity compensation [UPSTREAM]
+  const float ks = f.kernel_size;
+  const float det0 = fmaxf(1e-6f, a0 * c0 - b0 * b0);
+  const float a = a0 + ks, c = c0 + ks, b = b0;
+  const float det1 = fmaxf(1e-6f, a * c - b * b);
+  float coef = sqrtf(det0 / (det1 + 1e-6f) + 1e-6f);
+  if (det0 <= 1e-6f || det1 <= 1e-6f) coef = 0.0f;
+  o.a = a; o.b = b; o.c = c; o.coef = coef;
+
+  const float det = a * c - b * b;
+  if (det == 0.0f) return o;
+  const float det_inv = 1.0f / det;
+  o.cA = c * det_inv; o.cB = -b * det_inv; o.cC = a * det_inv;
+  const float mid = 0.5f * (a + c);
+  const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float l1 = mid + disc, l2 = mid - disc;
+  const float radf = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
+  const float mx = ((ndcx + 1.0f) * (float)f.W - 1.0f) * 0.5f;
+  const float my = ((ndcy + 1.0f) * (float)f.H - 1.0f) * 0.5f;
+  // non-finite projections are culled (x - x == 0 only for finite x)
+  if (!((mx - mx) == 0.0f && (my - my) == 0.0f && (radf - radf) == 0.0f)) return o;
+
+  const int TX = (f.W + TILE_REF - 1) / TILE_REF, TY = (f.H + TILE_REF - 1) / TILE_REF;
+  o.rminx = imin(TX, imax(0, f2i_sat((mx - radf) / (float)TILE_REF)));
+  o.rminy = imin(TY, imax(0, f2i_sat((my - radf) / (float)TILE_REF)));
+  o.rmaxx = imin(TX, imax(0, f2i_sat((mx + radf + (float)(TILE_REF - 1)) / (float)TILE_REF)));
+  o.rmaxy = imin(TY, imax(0, f2i_sat((my + radf + (float)(TILE_REF - 1)) / (float)TILE_REF)));
+  if ((o.rmaxx - o.rminx) * (o.rmaxy - o.rminy) == 0) return o;
+  o.mx = mx; o.my = my;
+  o.radius = f2i_sat(radf);
+  o.visible = true;
+  return o;
+}
+
+// ---- spherical harmonics (utils/sh_utils.py:57-112) ------------------------------------------
+constexpr float SH0 = 0.28209479177387814f;
+constexpr float SH1 = 0.4886025119029199f;
+constexpr float SH2_0 = 1.0925484305920792f, SH2_1 = -1.0925484305920792f, SH2_2 = 0.31539156525252005f,
+                SH2_3 = -1.0925484305920792f, SH2_4 = 0.5462742152960396f;
+constexpr float SH3_0 = -0.5900435899266435f, SH3_1 = 2.890611442640554f, SH3_2 = -0.4570457994644658f,
+                SH3_3 = 0.3731763325901154f, SH3_4 = -0.4570457994644658f, SH3_5 = 1.445305721320277f,
+                SH3_6 = -0.5900435899266435f;
+
+// basis[k] for k < (deg+1)^2 at unit direction (x,y,z); colour = sum_k basis[k] * sh[k]
+SFGS_HD void sh_basis(int deg, float x, float y, float z, float* Bk) {
+  Bk[0] = SH0;
+  if (deg > 0) {
+    Bk[1] = -SH1 * y; Bk[2] = SH1 * z; Bk[3] = -SH1 * x;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      Bk[4] = SH2_0 * xy; Bk[5] = SH2_1 * yz; Bk[6] = SH2_2 * (2.0f * zz - xx - yy);
+      Bk[7] = SH2_3 * xz; Bk[8] = SH2_4 * (xx - yy);
+      if (deg > 2) {
+        Bk[9] = SH3_0 * y * (3.0f * xx - yy);
+        Bk[10] = SH3_1 * xy * z;
+        Bk[11] = SH3_2 * y * (4.0f * zz - xx - yy);
+        Bk[12] = SH3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        Bk[13] = SH3_4 * x * (4.0f * zz - xx - yy);
+        Bk[14] = SH3_5 * z * (xx - yy);
+        Bk[15] = SH3_6 * x * (xx - 3.0f * yy);
+      }
+    }
+  }
+}
+
+// d basis[k] / d(x,y,z) (direction treated as free variables; the normalisation Jacobian is applied
+// by the caller)
+SFGS_HD void sh_basis_grad(int deg, float x, float y, float z, float* dBx, float* dBy, float* dBz) {
+  dBx[0] = dBy[0] = dBz[0] = 0.f;
+  if (deg > 0) {
+    dBx[1] = 0.f; dBy[1] = -SH1; dBz[1] = 0.f;
+    dBx[2] = 0.f; dBy[2] = 0.f; dBz[2] = SH1;
+    dBx[3] = -SH1; dBy[3] = 0.f; dBz[3] = 0.f;
+    if (deg > 1) {
+      dBx[4] = SH2_0 * y; dBy[4] = SH2_0 * x; dBz[4] = 0.f;
+      dBx[5] = 0.f; dBy[5] = SH2_1 * z; dBz[5] = SH2_1 * y;
+      dBx[6] = SH2_2 * -2.f * x; dBy[6] = SH2_2 * -2.f * y; dBz[6] = SH2_2 * 4.f * z;
+      dBx[7] = SH2_3 * z; dBy[7] = 0.f; dBz[7] = SH2_3 * x;
+      dBx[8] = SH2_4 * 2.f * x; dBy[8] = SH2_4 * -2.f * y; dBz[8] = 0.f;
+      if (deg > 2) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        dBx[9] = SH3_0 * 6.f * xy; dBy[9] = SH3_0 * 3.f * (xx - yy); dBz[9] = 0.f;
+        dBx[10] = SH3_1 * yz; dBy[10] = SH3_1 * xz; dBz[10] = SH3_1 * xy;
+        dBx[11] = SH3_2 * -2.f * xy; dBy[11] = SH3_2 * (4.f * zz - xx - 3.f * yy); dBz[11] = SH3_2 * 8.f * yz;
+        dBx[12] = SH3_3 * -6.f * xz; dBy[12] = SH3_3 * -6.f * yz; dBz[12] = SH3_3 * 3.f * (2.f * zz - xx - yy);
+        dBx[13] = SH3_4 * (4.f * zz - 3.f * xx - yy); dBy[13] = SH3_4 * -2.f * xy; dBz[13] = SH3_4 * 8.f * xz;
+        dBx[14] = SH3_5 * 2.f * xz; dBy[14] = SH3_5 * -2.f * yz; dBz[14] = SH3_5 * (xx - yy);
+        dBx[15] = SH3_6 * 3.f * (xx - yy); dBy[15] = SH3_6 * -6.f * xy; dBz[15] = 0.f;
+      }
+    }
+  }
+}
+
+// colour of one Gaussian from its SH coefficients [M,3] (coefficient-major), +0.5, clamp at 0.
+// clamp_mask bit c set <=> channel c was clamped (its gradient is zero).
+SFGS_HD void sh_to_rgb(int deg, const float* sh, const float* p, const float* campos, float rgb[3],
+                       unsigned* clamp_mask, float dir[3], float* len_out) {
+  const float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
+  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float x = dx / len, y = dy / len, z = dz / len;
+  dir[0] = x; dir[1] = y; dir[2] = z;
+  *len_out = len;
+  float Bk[16];
+  sh_basis(deg, x, y, z, Bk);
+  const int M = (deg + 1) * (deg + 1);
+  unsigned mask = 0;
+  for (int c = 0; c < 3; ++c) {
+    float r = 0.f;
+    for (int k = 0; k < M; ++k) r += Bk[k] * sh[k * 3 + c];
+    r += 0.5f;
+    if (r < 0.f) { mask |= 1u << c; r = 0.f; }
+    rgb[c] = r;
+  }
+  *clamp_mask = mask;
+}
+
+// ---- opacity-aware binning -------------------------------------------------------------------
+// A (Gaussian, 8x8 tile) pair is binned iff the tile lies inside the reference's 16x16-tile
+// rectangle AND alpha = op * 2^p2 can reach 1/255 somewhere on the tile's sample rectangle. The
+// second test is conservative (margins below), so the set of per-pixel contributors is exactly
+// the reference's.
+SFGS_HD float alpha_threshold_log2(float op) {
+  // p2 >= thr  <=  op * 2^p2 >= 0.999/255 (margin 0.1 % in alpha + 2e-3 absolute in p2)
+  return log2f(0.999f / (255.0f * op)) - 2e-3f;
+}
+
+SFGS_HD void fill_extents(SplatRec& r, float cov_a, float cov_c) {
+  const float thr = alpha_threshold_log2(r.op);  // <= 0 when the splat can be seen at all
+  if (!(r.op > 0.f) || thr > 0.f) { r.ex = -1.f; r.ey = -1.f; return; }
+  // power = ln2 * p2 >= ln2 * thr  <=>  d^T conic d <= tau2 = -2 ln2 thr ; bbox = sqrt(tau2 * cov_xx)
+  const float tau2 = -2.0f * LN2 * thr;
+  r.ex = sqrtf(tau2 * cov_a) * 1.001f + 1e-3f;
+  r.ey = sqrtf(tau2 * cov_c) * 1.001f + 1e-3f;
+}
+
+SFGS_HD float p2_at(const SplatRec& r, float dx, float dy) {
+  return r.qa * dx * dx + r.qc * dy * dy + r.qb * dx * dy;
+}
+
+// sample rectangle [x0,x1] x [y0,y1] in pixel coordinates (already widened by the subpixel bound)
+SFGS_HD bool tile_can_contribute(const SplatRec& r, float thr, float x0, float x1, float y0, float y1) {
+  const float dxl = r.mx - x1, dxh = r.mx - x0, dyl = r.my - y1, dyh = r.my - y0;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;  // centre inside: p2 = 0
+  float best = fmaxf(fmaxf(p2_at(r, dxl, dyl), p2_at(r, dxl, dyh)), fmaxf(p2_at(r, dxh, dyl), p2_at(r, dxh, dyh)));
+  // stationary points of the four edges (only a maximum when the 1-D coefficient is negative)
+  if (r.qc < 0.f) {
+    const float inv = -0.5f / r.qc;
+    float dy = fminf(dyh, fmaxf(dyl, r.qb * dxl * inv));
+    best = fmaxf(best, p2_at(r, dxl, dy));
+    dy = fminf(dyh, fmaxf(dyl, r.qb * dxh * inv));
+    best = fmaxf(best, p2_at(r, dxh, dy));
+  }
+  if (r.qa < 0.f) {
+    const float inv = -0.5f / r.qa;
+    float dx = fminf(dxh, fmaxf(dxl, r.qb * dyl * inv));
+    best = fmaxf(best, p2_at(r, dx, dyl));
+    dx = fminf(dxh, fmaxf(dxl, r.qb * dyh * inv));
+    best = fmaxf(best, p2_at(r, dx, dyh));
+  }
+  return !(best < thr);  // NaN keeps the pair
+}
+
+struct BinRange { int x0, x1, y0, y1; };  // 8x8-tile index ranges [x0,x1) x [y0,y1)
+
+// tile range to visit: reference rectangle (in 16-tiles) intersected with the alpha bbox
+SFGS_HD BinRange bin_range(const SplatRec& r, int W, int H, int rminx, int rminy, int rmaxx, int rmaxy,
+                           float bound) {
+  BinRange br;
+  const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
+  br.x0 = rminx * 2; br.x1 = imin(rmaxx * 2, TX8);
+  br.y0 = rminy * 2; br.y1 = imin(rmaxy * 2, TY8);
+  if (r.ex < 0.f) { br.x1 = br.x0; br.y1 = br.y0; return br; }
+  // pixels that can be reached: [mx - ex - bound, mx + ex + bound]
+  const float lo_x = r.mx - r.ex - bound, hi_x = r.mx + r.ex + bound;
+  const float lo_y = r.my - r.ey - bound, hi_y = r.my + r.ey + bound;
+  const int tx_lo = f2i_sat(floorf(lo_x / (float)TILE_BIN));
+  const int ty_lo = f2i_sat(floorf(lo_y / (float)TILE_BIN));
+  const int tx_hi = imin(f2i_sat(floorf(hi_x / (float)TILE_BIN)), TX8 - 1);  // clamp before the +1 below
+  const int ty_hi = imin(f2i_sat(floorf(hi_y / (float)TILE_BIN)), TY8 - 1);
+  br.x0 = imax(br.x0, tx_lo); br.x1 = imin(br.x1, tx_hi + 1);
+  br.y0 = imax(br.y0, ty_lo); br.y1 = imin(br.y1, ty_hi + 1);
+  if (br.x1 < br.x0) br.x1 = br.x0;
+  if (br.y1 < br.y0) br.y1 = br.y0;
+  return br;
+}
+
+SFGS_HD bool bin_test(const SplatRec& r, float thr, int tx, int ty, int W, int H, float bound) {
+  const float x0 = (float)(tx * TILE_BIN) - bound;
+  const float x1 = (float)imin(tx * TILE_BIN + TILE_BIN - 1, W - 1) + bound;
+  const float y0 = (float)(ty * TILE_BIN) - bound;
+  const float y1 = (float)imin(ty * TILE_BIN + TILE_BIN - 1, H - 1) + bound;
+  return tile_can_contribute(r, thr, x0, x1, y0, y1);
+}
+
+// Build the compositing record of a visible Gaussian.
+SFGS_HD SplatRec make_record(const Projected& pr, float opacity, const float rgb[3]) {
+  SplatRec r;
+  r.mx = pr.mx; r.my = pr.my;
+  r.qa = -0.5f * LOG2E * pr.cA;
+  r.qb = -LOG2E * pr.cB;
+  r.qc = -0.5f * LOG2E * pr.cC;
+  r.op = opacity * pr.coef;
+  r.depth = pr.tz;
+  r.r = rgb[0]; r.g = rgb[1]; r.b = rgb[2];
+  fill_extents(r, pr.a, pr.c);
+  return r;
+}
+
+// ---- per-pixel compositing math, shared by the kernels and tests/host_check --
+SFGS_HD float fast_exp2(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_exp2f(x);  // v_exp_f32
+#else
+  return exp2f(x);
+#endif
+}
+SFGS_HD float fast_rcp(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_rcpf(x);   // v_rcp_f32 (1 ulp)
+#else
+  return 1.0f / x;
+#endif
+}
+
+struct SplatEval {
+  float dx, dy, G, alpha;
+  bool ok;  // passes the reference's per-pixel tests: power <= 0 and alpha >= 1/255
+};
+
+// the one expression both passes use to decide whether a splat touches a sample point
+SFGS_HD SplatEval eval_splat(float mx, float my, float qa, float qb, float qc, float op, float sx, float sy) {
+  SplatEval e;
+  e.dx = mx - sx; e.dy = my - sy;
+  const float p2 = fmaf(qa * e.dx, e.dx, fmaf(qc * e.dy, e.dy, (qb * e.dx) * e.dy));
+  e.G = fast_exp2(p2);
+  e.alpha = fminf(0.99f, op * e.G);
+  e.ok = !(p2 > 0.f) && !(e.alpha < 1.0f / 255.0f);
+  return e;
+}
+
+struct PixelFwd {
+  float T, C0, C1, C2, D;
+  unsigned last;
+  bool done;
+};
+
+// k = 0-based list position. Returns nothing; updates the pixel state.
+SFGS_HD void pixel_fwd_step(PixelFwd& s, const SplatEval& e, float depth, float r, float g, float b, unsigned k) {
+  const float test_T = s.T * (1.0f - e.alpha);
+  const bool hit = !s.done && e.ok;
+  const bool stop = hit && test_T < 0.0001f;
+  s.done = s.done || stop;
+  if (hit && !stop) {
+    const float w = e.alpha * s.T;
+    s.C0 = fmaf(r, w, s.C0); s.C1 = fmaf(g, w, s.C1); s.C2 = fmaf(b, w, s.C2);
+    s.D = fmaf(depth, w, s.D);
+    s.T = test_T;
+    s.last = k + 1;
+  }
+}
+
+struct PixelBwd {
+  float Tr, last_alpha;
+  float accum[5], lastv[5];  // channels: r, g, b, raw depth, alpha
+  float gch[5];              // upstream gradients of the five accumulators
+  float bg_dot, T_final;
+};
+
+// upstream gradients of one pixel -> gradients of the raw accumulators (depth normalisation folded in)
+SFGS_HD void pixel_bwd_init(PixelBwd& s, unsigned last, float T_final, float dacc, float gr, float gg, float gb,
+                            float gdep, float galp, int depth_mode, const float bg[3]) {
+  s.Tr = T_final; s.T_final = T_final; s.last_alpha = 0.f;
+  for (int i = 0; i < 5; ++i) { s.accum[i] = 0.f; s.lastv[i] = 0.f; }
+  s.gch[0] = gr; s.gch[1] = gg; s.gch[2] = gb;
+  if (depth_mode == 0) {  // depth = Dacc / a, a = 1 - T_final
+    const float a = 1.0f - T_final;
+    s.gch[3] = gdep / a;
+    s.gch[4] = galp - gdep * dacc / (a * a);
+  } else {
+    s.gch[3] = gdep;
+    s.gch[4] = galp;
+  }
+  if (last == 0) { for (int i = 0; i < 5; ++i) s.gch[i] = 0.f; }  // nothing hit (a = 0): no gradient
+  s.bg_dot = bg[0] * s.gch[0] + bg[1] * s.gch[1] + bg[2] * s.gch[2];
+}
+
+// One contributing splat, back to front. v[12] (Grad2D order) receives this pixel's partial sums.
+SFGS_HD void pixel_bwd_step(PixelBwd& s, const SplatEval& e, float qa, float qb, float qc, float op, float depth,
+                            float r, float g, float b, float ddelx_dx, float ddely_dy, float v[12]) {
+  s.Tr = s.Tr * fast_rcp(1.0f - e.alpha);
+  const float w = e.alpha * s.Tr;
+  const float val[5] = {r, g, b, depth, 1.0f};
+  float dL_dalpha = 0.f;
+  for (int ch = 0; ch < 5; ++ch) {
+    s.accum[ch] = s.last_alpha * s.lastv[ch] + (1.f - s.last_alpha) * s.accum[ch];
+    s.lastv[ch] = val[ch];
+    dL_dalpha += (val[ch] - s.accum[ch]) * s.gch[ch];
+  }
+  dL_dalpha *= s.Tr;
+  s.last_alpha = e.alpha;
+  dL_dalpha += (-s.T_final / (1.f - e.alpha)) * s.bg_dot;
+  // conic in natural-log units: A = -2 ln2 qa, B = -ln2 qb, C = -2 ln2 qc. The min(0.99, .) clamp is
+  // ignored in the derivative [UPSTREAM].
+  const float cA = -2.0f * LN2 * qa, cB = -LN2 * qb, cC = -2.0f * LN2 * qc;
+  const float dL_dG = op * dL_dalpha;
+  const float gdx = e.G * e.dx, gdy = e.G * e.dy;
+  const float dG_ddelx = -gdx * cA - gdy * cB;
+  const float dG_ddely = -gdy * cC - gdx * cB;
+  const float gx = dL_dG * dG_ddelx * ddelx_dx;
+  const float gy = dL_dG * dG_ddely * ddely_dy;
+  v[0] = gx; v[1] = gy; v[2] = fabsf(gx); v[3] = fabsf(gy);
+  v[4] = -0.5f * gdx * e.dx * dL_dG;
+  v[5] = -gdx * e.dy * dL_dG;
+  v[6] = -0.5f * gdy * e.dy * dL_dG;
+  v[7] = e.G * dL_dalpha;
+  v[8] = w * s.gch[0]; v[9] = w * s.gch[1]; v[10] = w * s.gch[2];
+  v[11] = w * s.gch[3];
+}
+
+// ---- backward of the per-Gaussian chain (second half) -------------------
+// Per-Gaussian sums of the 2D gradients produced by the compositing backward.
+struct Grad2D {
+  float gmx, gmy;     // dL/dmean2D, already in NDC units (x 0.5 W, x 0.5 H)
+  float absx, absy;   // sum |.| of the same
+  float gA, gB, gC;   // dL/dconic
+  float gop;          // dL/d(op) where op = opacity * coef
+  float grgb[3];
+  float gdepth;
+};
+
+struct GaussGrads {
+  float means3D[3], means2D[3], scales[3], rot[4], opacity, rgb[3];
+};
+
+// sh / g_sh may be null (precomputed colours). g_sh [M_total,3] is fully written (zeros above the
+// active degree).
+SFGS_HD void preprocess_backward_one(const FrameParams& f, const float* p, const float* s, const float* q,
+                                     float opacity, const float* sh, const Grad2D& A, GaussGrads& out,
+                                     float* g_sh) {
+  const float* V = f.view;
+  const float* PM = f.proj;
+  const Projected pr = project_gaussian(f, p, s, q);  // bit-identical to the forward
+  float gp[3] = {0.f, 0.f, 0.f};
+
+  out.means2D[0] = A.gmx; out.means2D[1] = A.gmy;
+  out.means2D[2] = sqrtf(A.absx * A.absx + A.absy * A.absy);
+
+  // op = opacity * coef
+  out.opacity = A.gop * pr.coef;
+  const float gcoef = A.gop * opacity;
+
+  // conic = inverse(cov): dL/d(a,b,c)
+  const float a = pr.a, b = pr.b, c = pr.c;
+  const float det = a * c - b * b;
+  const float inv2 = 1.0f / (det * det);
+  float ga = (-c * c * A.gA + b * c * A.gB - b * b * A.gC) * inv2;
+  float gb = (2.f * b * c * A.gA - (a * c + b * b) * A.gB + 2.f * a * b * A.gC) * inv2;
+  float gc = (-b * b * A.gA + a * b * A.gB - a * a * A.gC) * inv2;
+  {  // coef = sqrt(det0 / (det1 + 1e-6) + 1e-6)
+    const float det0r = pr.a0 * pr.c0 - pr.b0 * pr.b0;
+    const float det1r = det;
+    if (det0r > 1e-6f && det1r > 1e-6f && pr.coef > 0.f) {
+      const float dcoef_dr = 0.5f / pr.coef;
+      const float den = det1r + 1e-6f;
+      const float gdet0 = gcoef * dcoef_dr / den;
+      const float gdet1 = -gcoef * dcoef_dr * det0r / (den * den);
+      ga += gdet0 * pr.c0 + gdet1 * c;
+      gb += gdet0 * (-2.f * pr.b0) + gdet1 * (-2.f * b);
+      gc += gdet0 * pr.a0 + gdet1 * a;
+    }
+  }
+  // cov2D = T Sigma T^T
+  const Jac j = ewa_jacobian(f, pr.tx, pr.ty, pr.tz);
+  const float* c3 = pr.cov3d;
+  const float S3[9] = {c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]};
+  float v0[3], v1[3];
+  for (int r = 0; r < 3; ++r) {
+    v0[r] = S3[r * 3 + 0] * j.T0[0] + S3[r * 3 + 1] * j.T0[1] + S3[r * 3 + 2] * j.T0[2];
+    v1[r] = S3[r * 3 + 0] * j.T1[0] + S3[r * 3 + 1] * j.T1[1] + S3[r * 3 + 2] * j.T1[2];
+  }
+  float Gm[9];
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 3; ++k)
+      Gm[r * 3 + k] = ga * j.T0[r] * j.T0[k] + gb * j.T0[r] * j.T1[k] + gc * j.T1[r] * j.T1[k];
+  float gT0[3], gT1[3];
+  for (int k = 0; k < 3; ++k) {
+    gT0[k] = 2.f * ga * v0[k] + gb * v1[k];
+    gT1[k] = 2.f * gc * v1[k] + gb * v0[k];
+  }
+  float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    gJ00 += gT0[k] * V[k * 4 + 0];
+    gJ02 += gT0[k] * V[k * 4 + 2];
+    gJ11 += gT1[k] * V[k * 4 + 1];
+    gJ12 += gT1[k] * V[k * 4 + 2];
+  }
+  const float tz1 = 1.f / pr.tz, tz2 = tz1 * tz1, tz3 = tz2 * tz1;
+  const float gtx = j.x_mul * (-j.fx * tz2) * gJ02;
+  const float gty = j.y_mul * (-j.fy * tz2) * gJ12;
+  float gtz = -j.fx * tz2 * gJ00 - j.fy * tz2 * gJ11 + (2.f * j.fx * j.ux) * tz3 * gJ02 +
+              (2.f * j.fy * j.uy) * tz3 * gJ12;
+  gtz += A.gdepth;
+  for (int k = 0; k < 3; ++k) gp[k] = gtx * V[k * 4 + 0] + gty * V[k * 4 + 1] + gtz * V[k * 4 + 2];
+  {  // mean2D (NDC) -> p through the perspective divide
+    const float hx = PM[0] * p[0] + PM[4] * p[1] + PM[8] * p[2] + PM[12];
+    const float hy = PM[1] * p[0] + PM[5] * p[1] + PM[9] * p[2] + PM[13];
+    const float hw = PM[3] * p[0] + PM[7] * p[1] + PM[11] * p[2] + PM[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
+    for (int k = 0; k < 3; ++k)
+      gp[k] += (PM[k * 4 + 0] * pw - PM[k * 4 + 3] * mul1) * A.gmx + (PM[k * 4 + 1] * pw - PM[k * 4 + 3] * mul2) * A.gmy;
+  }
+  {  // Sigma = M M^T, M = R diag(mod s)
+    float R[9];
+    quat_to_rot(q, R);
+    const float mod = f.scale_modifier;
+    const float Sv[3] = {mod * s[0], mod * s[1], mod * s[2]};
+    float gR[9];
+    for (int jj = 0; jj < 3; ++jj) {
+      float gS = 0.f;
+      for (int r = 0; r < 3; ++r) {
+        float gM = 0.f;
+        for (int k = 0; k < 3; ++k) gM += (Gm[r * 3 + k] + Gm[k * 3 + r]) * (R[k * 3 + jj] * Sv[jj]);
+        gS += gM * R[r * 3 + jj];
+        gR[r * 3 + jj] = gM * Sv[jj];
+      }
+      out.scales[jj] = mod * gS;
+    }
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    out.rot[0] = 2.f * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+    out.rot[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] -
+                        2.f * x * gR[8]);
+    out.rot[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] -
+                        2.f * y * gR[8]);
+    out.rot[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] +
+                        x * gR[6] + y * gR[7]);
+  }
+  out.rgb[0] = A.grgb[0]; out.rgb[1] = A.grgb[1]; out.rgb[2] = A.grgb[2];
+  if (sh) {
+    float rgb[3], dir[3], len;
+    unsigned mask;
+    sh_to_rgb(f.sh_degree, sh, p, f.campos, rgb, &mask, dir, &len);
+    float Bk[16], dBx[16], dBy[16], dBz[16];
+    sh_basis(f.sh_degree, dir[0], dir[1], dir[2], Bk);
+    sh_basis_grad(f.sh_degree, dir[0], dir[1], dir[2], dBx, dBy, dBz);
+    const int M = (f.sh_degree + 1) * (f.sh_degree + 1);
+    float gd[3] = {0.f, 0.f, 0.f};
+    for (int ch = 0; ch < 3; ++ch) {
+      const float gr = ((mask >> ch) & 1u) ? 0.f : A.grgb[ch];
+      for (int k = 0; k < f.sh_coeffs; ++k) g_sh[k * 3 + ch] = (k < M) ? Bk[k] * gr : 0.f;
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int k = 0; k < M; ++k) {
+        const float cf = sh[k * 3 + ch];
+        ax += dBx[k] * cf; ay += dBy[k] * cf; az += dBz[k] * cf;
+      }
+      gd[0] += ax * gr; gd[1] += ay * gr; gd[2] += az * gr;
+    }
+    const float dot = dir[0] * gd[0] + dir[1] * gd[1] + dir[2] * gd[2];
+    gp[0] += (gd[0] - dir[0] * dot) / len;
+    gp[1] += (gd[1] - dir[1] * dot) / len;
+    gp[2] += (gd[2] - dir[2] * dot) / len;
+  }
+  out.means3D[0] = gp[0]; out.means3D[1] = gp[1]; out.means3D[2] = gp[2];
+}
+
+}  // namespace sfgs

@@ -1,0 +1,239 @@
+// sfgs_internal.h -- blob layouts, launch helpers and error plumbing shared by the .hip files.
+// Not part of the ABI (include/sfgs.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sfgs.h"
+#include "raster_math.h"
+
+namespace sfgs {
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define SFGS_CHECK_HIP(expr)                                                              \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      sfgs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SFGS_E_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define SFGS_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      sfgs::set_error(__VA_ARGS__);    \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+// ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
+enum KernelId {
+  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_SCATTER, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
+  KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN,
+  KID_COUNT
+};
+bool prof_enabled();
+void* prof_begin(int id, hipStream_t stream);
+void prof_end(void* token, hipStream_t stream);
+struct ProfScope {
+  void* tok; hipStream_t st;
+  ProfScope(int id, hipStream_t s) : tok(prof_enabled() ? prof_begin(id, s) : nullptr), st(s) {}
+  ~ProfScope() { if (tok) prof_end(tok, st); }
+};
+
+// after a launch: always catch launch errors; in debug mode also synchronise (SfgsFrame.debug)
+#define SFGS_POST_LAUNCH(name, stream, debug)                                      \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ == hipSuccess && (debug)) e_ = hipStreamSynchronize(stream);            \
+    if (e_ != hipSuccess) {                                                        \
+      sfgs::set_error("kernel %s failed: %s", name, hipGetErrorString(e_));        \
+      return SFGS_E_HIP;                                                           \
+    }                                                                              \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- kernel-side view of SfgsFrame -------------------------------------------------------------
+struct KFrame {
+  int W, H;
+  float tanfovx, tanfovy, kernel_size, scale_modifier;
+  int sh_degree, sh_coeffs, depth_mode;
+  const float* view;
+  const float* proj;
+  const float* campos;
+  const float* bg;
+  const float* subpix;
+};
+
+static inline KFrame make_kframe(const SfgsFrame* f) {
+  KFrame k;
+  k.W = f->image_width; k.H = f->image_height;
+  k.tanfovx = f->tanfovx; k.tanfovy = f->tanfovy;
+  k.kernel_size = f->kernel_size; k.scale_modifier = f->scale_modifier;
+  k.sh_degree = f->sh_degree; k.sh_coeffs = f->sh_coeffs; k.depth_mode = f->depth_mode;
+  k.view = f->viewmatrix; k.proj = f->projmatrix; k.campos = f->campos; k.bg = f->bg;
+  k.subpix = f->subpixel_offset;
+  return k;
+}
+
+__device__ __forceinline__ FrameParams load_frame(const KFrame& k) {
+  FrameParams f;
+  f.W = k.W; f.H = k.H;
+  f.tanfovx = k.tanfovx; f.tanfovy = k.tanfovy;
+  f.kernel_size = k.kernel_size; f.scale_modifier = k.scale_modifier;
+  f.sh_degree = k.sh_degree; f.sh_coeffs = k.sh_coeffs; f.depth_mode = k.depth_mode;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { f.view[i] = k.view[i]; f.proj[i] = k.proj[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { f.campos[i] = k.campos[i]; f.bg[i] = k.bg[i]; }
+  return f;
+}
+
+// ---- blob layouts -------------------------------------------------------------------------------
+constexpr int PRE_BLOCK = 256;      // threads per block of the per-Gaussian kernels
+constexpr int HDR_WORDS = 64;       // uint64 words at the head of the tiles blob
+
+enum HeaderSlot {
+  HDR_D_EFF = 0,      // binned (Gaussian, 8x8 tile) pairs
+  HDR_D_REF = 1,      // sum of the reference's tiles_touched (16x16 rule)
+  HDR_N_VIS = 2,      // count(radii > 0)
+  HDR_MAX_LIST = 3,   // longest per-tile list
+  HDR_OVERFLOW = 4,   // set by the scatter when dup_capacity is too small
+  HDR_SUBPIX_BOUND = 5  // float bits of max |subpixel_offset| (0 when none)
+};
+
+struct GeomView {
+  float4* rec;        // [N][3] float4 = SplatRec
+  uint32_t* dupoff;   // [N+1] per-Gaussian duplicate count (after plan) -> exclusive offsets (after render)
+  uint2* brange;      // [N] 8x8-tile range to walk, packed (x0 | x1 << 16, y0 | y1 << 16)
+};
+static inline size_t geom_bytes(int64_t N) {
+  return align_up((size_t)N * 48, 256) + align_up((size_t)(N + 1) * 4, 256) + align_up((size_t)N * 8, 256);
+}
+static inline GeomView geom_view(void* base, int64_t N) {
+  GeomView g;
+  char* p = (char*)base;
+  g.rec = (float4*)p; p += align_up((size_t)N * 48, 256);
+  g.dupoff = (uint32_t*)p; p += align_up((size_t)(N + 1) * 4, 256);
+  g.brange = (uint2*)p;
+  return g;
+}
+
+struct TilesView {
+  unsigned long long* hdr;  // [HDR_WORDS]
+  uint32_t* tile_count;     // [T8]   (zeroed by plan)
+  uint32_t* tile_cursor;    // [T8]   (zeroed by plan)
+  uint32_t* tile_start;     // [T8+1]
+  uint32_t* block_sums;     // [NB] duplicates emitted per preprocess block
+  uint32_t* block_base;     // [NB] exclusive scan of block_sums
+  uint32_t* block_nvis;     // [NB]
+  unsigned long long* block_dref;  // [NB]
+  size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
+};
+static inline int64_t tiles8(int W, int H) {
+  return (int64_t)((W + TILE_BIN - 1) / TILE_BIN) * ((H + TILE_BIN - 1) / TILE_BIN);
+}
+static inline int64_t pre_blocks(int64_t N) { return (N + PRE_BLOCK - 1) / PRE_BLOCK; }
+static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* total) {
+  TilesView t;
+  const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1;
+  char* p = (char*)base;
+  size_t off = 0;
+  t.hdr = (unsigned long long*)(p + off); off += HDR_WORDS * 8;
+  t.tile_count = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
+  t.tile_cursor = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
+  t.zero_bytes = off;
+  t.tile_start = (uint32_t*)(p + off); off += align_up((size_t)(T8 + 1) * 4, 256);
+  t.block_sums = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
+  t.block_base = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
+  t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
+  t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
+  if (total) *total = off;
+  return t;
+}
+
+struct BinsView {
+  unsigned long long* keys;  // [D] (depth bits << 32) | duplicate index, tile-major, unsorted
+  uint32_t* dup_gauss;       // [D] duplicate index -> Gaussian id
+  uint32_t* sorted_id;       // [D] per-tile lists of Gaussian ids, front to back
+  uint32_t* sorted_dup;      // [D] the matching duplicate indices
+};
+static inline size_t bins_bytes(int64_t D) {
+  return align_up((size_t)D * 8, 256) + 3 * align_up((size_t)D * 4, 256);
+}
+static inline BinsView bins_view(void* base, int64_t D) {
+  BinsView b;
+  char* p = (char*)base;
+  b.keys = (unsigned long long*)p; p += align_up((size_t)D * 8, 256);
+  b.dup_gauss = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
+  b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
+  b.sorted_dup = (uint32_t*)p;
+  return b;
+}
+
+struct ImageView {
+  uint32_t* n_contrib;  // [P] list position (1-based) of the last contributor
+  float* final_T;       // [P]
+  float* dacc;          // [P] un-normalised accumulated depth
+};
+static inline size_t image_bytes(int W, int H) { return 3 * align_up((size_t)W * H * 4, 256); }
+static inline ImageView image_view(void* base, int W, int H) {
+  ImageView v;
+  char* p = (char*)base;
+  const size_t plane = align_up((size_t)W * H * 4, 256);
+  v.n_contrib = (uint32_t*)p; v.final_T = (float*)(p + plane); v.dacc = (float*)(p + 2 * plane);
+  return v;
+}
+
+constexpr int DUPGRAD_FLOATS = 16;  // one 64-byte line per duplicate, 12 floats used (Grad2D order)
+static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
+
+// ---- XCD-aware block remap (bijective; guide T1) -------------------------------------------------
+// Hardware places workgroup b on XCD b % 8; give every XCD a contiguous range of logical blocks so
+// that neighbouring tiles (which gather the same splat records) share an L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
+  const unsigned xcd = b & 7u, idx = b >> 3;
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ---- small wave / block primitives ---------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+  const unsigned lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(v, d);
+    if (lane >= (unsigned)d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan across a block of NT threads; smem must hold NT/64 + 1 words. Returns the
+// exclusive prefix of `v`; *total = block sum (all threads).
+template <int NT>
+__device__ __forceinline__ unsigned block_excl_scan_u32(unsigned v, unsigned* total, unsigned* smem) {
+  const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+  const unsigned incl = wave_incl_scan_u32(v);
+  if (lane == 63) smem[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int w = 0; w < NT / 64; ++w) { const unsigned t = smem[w]; smem[w] = run; run += t; }
+    smem[NT / 64] = run;
+  }
+  __syncthreads();
+  const unsigned res = smem[wave] + incl - v;
+  *total = smem[NT / 64];
+  __syncthreads();
+  return res;
+}
+
+}  // namespace sfgs

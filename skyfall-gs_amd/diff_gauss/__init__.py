@@ -1,0 +1,227 @@
+"""diff_gauss -- drop-in for the reference's rasterizer extension, backed by libsfgs.so (gfx950 HIP).
+
+Mirrors the operator API the reference binds at gaussian_renderer/__init__.py:14,40-57,132-140:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, kernel_size,
+        subpixel_offset, bg, scale_modifier, viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None,
+        scales=None, rotations=None, cov3Ds_precomp=None)
+        -> (color[3,H,W], depth[1,H,W], norm[3,H,W], alpha[1,H,W], radii[N] int32, extra)
+
+Gradient contract (scene/gaussian_model.py:744-749): means2D.grad[:, :2] = dL/dmean2D in NDC units,
+means2D.grad[:, 2] = magnitude of the summed absolute 2D gradients. depth = sum(T a z) / (1 - T)
+(NaN where nothing was hit; consumers scrub it: train.py:229-231); norm = zeros; extra = None
+(none are consumed). All arithmetic runs in the HIP library; this file only validates
+arguments, owns the scratch tensors (PyTorch caching allocator) and plumbs the current stream.
+"""
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from sfgs import _lib as L
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_counters"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    subpixel_offset: Optional[torch.Tensor]
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    depth_mode: int = L.DEPTH_NORMALISED  # extension: L.DEPTH_RAW returns sum(T a z)
+
+
+_last_counters = {}
+
+
+def last_counters():
+    """Counters of the most recent forward on this process (D_eff, D_ref, N_vis, max list): bench/tests."""
+    return dict(_last_counters)
+
+
+def _f32c(t, name, shape_tail=None):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); this rasterizer has no CPU path")
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name}: expected shape [N,{','.join(map(str, shape_tail))}], got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _frame(settings, dev, sh_coeffs, keep):
+    H, W = int(settings.image_height), int(settings.image_width)
+    sub = settings.subpixel_offset
+    if sub is not None:
+        if tuple(sub.shape) != (H, W, 2):
+            raise ValueError(f"subpixel_offset must have shape ({H},{W},2), got {tuple(sub.shape)}")
+        sub = _f32c(sub, "subpixel_offset")
+    bg = _f32c(settings.bg, "bg")
+    view = _f32c(settings.viewmatrix, "viewmatrix")
+    proj = _f32c(settings.projmatrix, "projmatrix")
+    campos = _f32c(settings.campos, "campos")
+    if bg.numel() != 3 or view.numel() != 16 or proj.numel() != 16 or campos.numel() != 3:
+        raise ValueError("bg/campos must have 3 elements, viewmatrix/projmatrix 16")
+    for t in (sub, bg, view, proj, campos):
+        if t is not None and t.device != dev:
+            raise ValueError("all rasterizer inputs must be on the same device")
+    keep.extend([sub, bg, view, proj, campos])
+    return L.SfgsFrame(C_sizeof(L.SfgsFrame), H, W, float(settings.tanfovx), float(settings.tanfovy),
+                       float(settings.kernel_size), float(settings.scale_modifier), int(settings.sh_degree),
+                       int(sh_coeffs), int(bool(settings.prefiltered)), int(bool(settings.debug)),
+                       int(getattr(settings, "depth_mode", 0)), L.ptr(sub), L.ptr(bg), L.ptr(view), L.ptr(proj),
+                       L.ptr(campos))
+
+
+def C_sizeof(t):
+    import ctypes
+    return ctypes.sizeof(t)
+
+
+def _stream(dev):
+    return L.C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings):
+        lib = L.load()
+        dev = means3D.device
+        N = int(means3D.shape[0])
+        H, W = int(settings.image_height), int(settings.image_width)
+        sh_coeffs = 0 if shs is None else int(shs.shape[1])
+        keep = []
+        with torch.cuda.device(dev):
+            frame = _frame(settings, dev, sh_coeffs, keep)
+            stream = _stream(dev)
+            gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                                 L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
+            sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
+            L.check(lib.sfgs_raster_sizes(N, W, H, 0, L.C.byref(sizes)))
+            u8 = dict(dtype=torch.uint8, device=dev)
+            geom = torch.empty(max(sizes.geom_bytes, 1), **u8)
+            tiles = torch.empty(sizes.tiles_bytes, **u8)
+            radii = torch.empty(N, dtype=torch.int32, device=dev)
+            L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
+                                                 geom.numel(), L.ptr(tiles), tiles.numel(), stream))
+            cnt = L.SfgsRasterCounters()
+            L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))  # the one host sync
+            D = int(cnt.num_duplicates)
+            _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
+                                  num_visible=int(cnt.num_visible), max_tile_list=int(cnt.max_tile_list),
+                                  N=N, W=W, H=H)
+            L.check(lib.sfgs_raster_sizes(N, W, H, D, L.C.byref(sizes)))
+            bins = torch.empty(max(sizes.bins_bytes, 1), **u8)
+            need_bwd = any(ctx.needs_input_grad[:7])
+            image = torch.empty(sizes.image_bytes, **u8) if need_bwd else None
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins),
+                                                   bins.numel(), D, L.ptr(color), L.ptr(depth), L.ptr(alpha),
+                                                   L.ptr(image), 0 if image is None else image.numel(), stream))
+        norm = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        ctx.mark_non_differentiable(radii, norm)
+        if need_bwd:
+            ctx.settings, ctx.D, ctx.sh_coeffs = settings, D, sh_coeffs
+            ctx.keep = keep
+            ctx.has_colors, ctx.has_shs = colors_precomp is not None, shs is not None
+            ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, geom, tiles, bins,
+                                  image)
+        return color, depth, norm, alpha, radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_norm, g_alpha, g_radii):
+        lib = L.load()
+        means3D, scales, rotations, opacities, colors_precomp, shs, radii, geom, tiles, bins, image = ctx.saved_tensors
+        dev = means3D.device
+        N = int(means3D.shape[0])
+        settings, D = ctx.settings, ctx.D
+        with torch.cuda.device(dev):  # autograd worker thread: select the device, use ITS current stream
+            keep = []
+            frame = _frame(settings, dev, ctx.sh_coeffs, keep)
+            stream = _stream(dev)
+            gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                                 L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
+            f32 = dict(dtype=torch.float32, device=dev)
+            g_means3D = torch.empty(N, 3, **f32)
+            g_means2D = torch.empty(N, 3, **f32)
+            g_scales = torch.empty(N, 3, **f32)
+            g_rot = torch.empty(N, 4, **f32)
+            g_opac = torch.empty(N, 1, **f32)
+            g_col = torch.empty(N, 3, **f32) if ctx.has_colors else None
+            g_shs = torch.empty(N, ctx.sh_coeffs, 3, **f32) if ctx.has_shs else None
+            grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
+                                        L.ptr(g_scales), L.ptr(g_rot), L.ptr(g_opac), L.ptr(g_col), L.ptr(g_shs))
+            sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
+            L.check(lib.sfgs_raster_sizes(N, int(settings.image_width), int(settings.image_height), D,
+                                          L.C.byref(sizes)))
+            dupgrad = torch.empty(max(sizes.dupgrad_bytes, 1), dtype=torch.uint8, device=dev)
+            gc = None if g_color is None else g_color.contiguous().float()
+            gd = None if g_depth is None else g_depth.contiguous().float()
+            ga = None if g_alpha is None else g_alpha.contiguous().float()
+            L.check(lib.sfgs_raster_backward(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom), L.ptr(tiles),
+                                             L.ptr(bins), D, L.ptr(image), L.ptr(gc), L.ptr(gd), L.ptr(ga),
+                                             L.ptr(dupgrad), dupgrad.numel(), L.C.byref(grads), stream))
+        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None
+
+
+def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings):
+    return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3Ds_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+        if cov3Ds_precomp is not None:
+            raise ValueError("cov3Ds_precomp is not supported: that path is dead in the reference "
+                             "(gaussian_renderer/__init__.py:138 calls scales.float() unconditionally)")
+        if scales is None or rotations is None:
+            raise ValueError("Please provide scales and rotations")
+        N = int(means3D.shape[0])
+        means3D = _f32c(means3D, "means3D")
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise ValueError("means3D must be [N,3]")
+        if means2D is None:
+            means2D = torch.zeros_like(means3D)
+        scales = _f32c(scales, "scales", (3,))
+        rotations = _f32c(rotations, "rotations", (4,))
+        opacities = _f32c(opacities, "opacities")
+        if opacities.numel() != N:
+            raise ValueError(f"opacities must have N={N} elements")
+        opacities = opacities.reshape(N, 1)
+        colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
+        if shs is not None:
+            shs = _f32c(shs, "shs")
+            if shs.dim() != 3 or shs.shape[2] != 3:
+                raise ValueError("shs must be [N,K,3]")
+            deg = int(self.raster_settings.sh_degree)
+            if shs.shape[1] < (deg + 1) ** 2 or shs.shape[1] > 16:
+                raise ValueError(f"shs has {shs.shape[1]} coefficients; degree {deg} needs {(deg + 1) ** 2} (max 16)")
+        for name, t in (("scales", scales), ("rotations", rotations), ("colors_precomp", colors_precomp), ("shs", shs)):
+            if t is not None and (t.shape[0] != N or t.device != means3D.device):
+                raise ValueError(f"{name}: first dimension / device must match means3D")
+        color, depth, norm, alpha, radii = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                                               rotations, self.raster_settings)
+        return color, depth, norm, alpha, radii, None

@@ -1,0 +1,111 @@
+"""ctypes binding of libsfgs.so (C ABI: include/sfgs.h). Host-side plumbing only: every kernel lives
+in csrc/*.hip. There is NO CPU fallback: if the HIP library is missing, importing an operator fails
+loudly (build it with `python __graft_entry__.py` or `make -C skyfall-gs_amd/csrc`)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfgs.so")
+ABI_VERSION = 1
+
+SFGS_OK = 0
+DEPTH_NORMALISED, DEPTH_RAW = 0, 1
+
+
+class SfgsFrame(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("image_height", C.c_int32), ("image_width", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("kernel_size", C.c_float),
+                ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("depth_mode", C.c_int32),
+                ("subpixel_offset", C.c_void_p), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class SfgsGaussians(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("count", C.c_int32), ("means3D", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("opacities", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("shs", C.c_void_p)]
+
+
+class SfgsGaussianGrads(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("means3D", C.c_void_p), ("means2D", C.c_void_p),
+                ("scales", C.c_void_p), ("rotations", C.c_void_p), ("opacities", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("shs", C.c_void_p)]
+
+
+class SfgsRasterSizes(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("geom_bytes", C.c_size_t), ("tiles_bytes", C.c_size_t),
+                ("bins_bytes", C.c_size_t), ("image_bytes", C.c_size_t), ("dupgrad_bytes", C.c_size_t)]
+
+
+class SfgsRasterCounters(C.Structure):
+    _fields_ = [("num_duplicates", C.c_int64), ("num_duplicates_ref", C.c_int64), ("num_visible", C.c_int64),
+                ("max_tile_list", C.c_int64)]
+
+
+# every symbol include/sfgs.h declares: name -> (restype, argtypes)
+_V, _I32, _I64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+SYMBOLS = {
+    "sfgs_abi_version": (C.c_int, []),
+    "sfgs_last_error": (C.c_char_p, []),
+    "sfgs_profile_enable": (C.c_int, [_I32]),
+    "sfgs_profile_kernel_count": (C.c_int, []),
+    "sfgs_profile_kernel_name": (C.c_char_p, [_I32]),
+    "sfgs_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
+    "sfgs_raster_sizes": (C.c_int, [_I32, _I32, _I32, _I64, C.POINTER(SfgsRasterSizes)]),
+    "sfgs_raster_forward_plan": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _V, _SZ, _V]),
+    "sfgs_raster_read_counters": (C.c_int, [_V, C.POINTER(SfgsRasterCounters), _V]),
+    "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _V, _V, _V, _V, _SZ, _V]),
+    "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _V, _V,
+                                        _V, _V, _V, _SZ, C.POINTER(SfgsGaussianGrads), _V]),
+    "sfgs_ssim_scratch_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32]),
+    "sfgs_ssim_forward": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _V, _V, _V, _SZ, _I32, _V]),
+    "sfgs_ssim_backward": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _V, _V, _V, _V]),
+    "sfgs_knn_scratch_bytes": (_SZ, [_I32]),
+    "sfgs_knn_dist2": (C.c_int, [_V, _I32, _V, _V, _SZ, _V]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsfgs.so and bind every symbol of the ABI. Raises if the library is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension has not been built (run `python __graft_entry__.py` "
+                "or `make -C skyfall-gs_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        v = lib.sfgs_abi_version()
+        if v != ABI_VERSION:
+            raise ImportError(f"libsfgs.so ABI version {v}, binding expects {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != SFGS_OK:
+        raise RuntimeError(f"libsfgs error {rc}: {load().sfgs_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def profile_enable(on=True):
+    check(load().sfgs_profile_enable(int(bool(on))))
+
+
+def profile_collect():
+    """-> {kernel name: (summed ms, launches)} for the kernels launched since the last collect/enable."""
+    lib = load()
+    n = lib.sfgs_profile_kernel_count()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    check(lib.sfgs_profile_collect(ms, cnt, n))
+    return {lib.sfgs_profile_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i] > 0}
