@@ -12,26 +12,35 @@
 //
 // Compile with -ffp-contract=off (the forward's alpha/skip decisions must be reproduced exactly; FMA
 // only where spelled fmaf, identically to raster_fwd.hip).
+#include <stdlib.h>
+
 #include "sfgs_internal.h"
 
 namespace sfgs {
 
-// sum over the 64 lanes of a wave; the total is valid in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-  return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row sum
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = total
-  return v;
-}
+// Compositing backward. Workgroup = 4 independent waves = 2x2 tiles of 8x8 pixels (as the forward).
+// The tile's list is walked back to front in batches of B entries, each batch in two phases:
+//
+//   phase 1 (lane = pixel): for every entry, advance the pixel's transmittance / "colour behind"
+//            recurrences and store the two scalars all 12 gradients derive from -- u = G dL/dalpha and
+//            w = alpha T -- into wave-private LDS matrices U[j][p], Wm[j][p] (row stride 65: both the
+//            pixel-major writes and the entry-major reads below are bank-conflict free).
+//   phase 2 (lane = entry j, 64/B lanes per entry each owning B pixels): accumulate the 12 sums over
+//            pixels in registers -- the per-(splat, tile) reduction becomes in-lane adds instead of a
+//            12-value cross-lane reduction per entry -- then combine the 64/B partial lanes and write
+//            ONE 64-byte line per duplicate.
+//
+// No float atomics anywhere: gradients are bit-reproducible run to run.
+template <int B>
+struct BwdLds {
+  static constexpr int ROW = 65;
+  float U[B * ROW];
+  float Wm[B * ROW];
+  float4 recs[B * 3];
+  float4 pix[64 * 2];  // per pixel: (sx, sy, g0, g1), (g2, g3, -, -)
+};
 
+template <int B>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32_t* __restrict__ tile_start,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
@@ -39,12 +48,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, float4* __restrict__ dupgrad) {
-  __shared__ float4 stage[4][64 * 3];
-  __shared__ float4 gstage[4][64 * 3];
+  constexpr int ROW = BwdLds<B>::ROW;
+  constexpr int NGRP = 64 / B;  // lanes per entry in phase 2; each owns B pixels
+  __shared__ BwdLds<B> lds_all[4];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8) return;
+  BwdLds<B>& lds = lds_all[wave];
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
@@ -72,6 +83,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
     const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
     pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
   }
+  lds.pix[lane * 2] = make_float4(sx, sy, ps.gch[0], ps.gch[1]);
+  lds.pix[lane * 2 + 1] = make_float4(ps.gch[2], ps.gch[3], 0.f, 0.f);
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
   unsigned kmax = last;
@@ -86,47 +99,80 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
   }
   if (kmax == 0) return;
 
-  float4* st = stage[wave];
-  float4* gs = gstage[wave];
-
-  const int nbatch = (int)((kmax + 63) / 64);
+  const int ej = lane & (B - 1), grp = lane / B;  // phase-2 role of this lane
+  const int nbatch = (int)((kmax + B - 1) / B);
   for (int bi = nbatch - 1; bi >= 0; --bi) {
-    const unsigned b0 = (unsigned)bi * 64;
-    const unsigned cnt = min(64u, kmax - b0);
+    const unsigned b0 = (unsigned)bi * B;
+    const unsigned cnt = min((unsigned)B, kmax - b0);
     unsigned my_dup = 0;
     if ((unsigned)lane < cnt) {
       const unsigned id = sorted_id[s + b0 + lane];
       my_dup = sorted_dup[s + b0 + lane];
       const float4 a0 = rec[3 * (size_t)id], a1 = rec[3 * (size_t)id + 1], a2 = rec[3 * (size_t)id + 2];
-      st[lane * 3] = a0; st[lane * 3 + 1] = a1; st[lane * 3 + 2] = a2;
+      lds.recs[lane * 3] = a0; lds.recs[lane * 3 + 1] = a1; lds.recs[lane * 3 + 2] = a2;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- phase 1: lane = pixel -------------------------------------------------------------------
     for (int j = (int)cnt - 1; j >= 0; --j) {
-      const unsigned k = b0 + (unsigned)j;  // 0-based list position
-      const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
-      const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
+      const unsigned k = b0 + (unsigned)j;
+      const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
+      const float2 r2 = *reinterpret_cast<const float2*>(&lds.recs[j * 3 + 2]);
       const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
       const bool act = k < last && ev.ok;
-      float v[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) v[i] = 0.f;
-      if (act) pixel_bwd_step(ps, ev, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, ddelx_dx, ddely_dy, v);
-      if (__ballot(act) != 0ull) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = wave_sum_to_lane63(v[i]);
-      }
-      if (lane == 63) {
-        gs[j * 3] = make_float4(v[0], v[1], v[2], v[3]);
-        gs[j * 3 + 1] = make_float4(v[4], v[5], v[6], v[7]);
-        gs[j * 3 + 2] = make_float4(v[8], v[9], v[10], v[11]);
-      }
+      float u = 0.f, w = 0.f;
+      if (act) pixel_bwd_scalars(ps, ev, r1.z, r1.w, r2.x, r2.y, u, w);
+      lds.U[j * ROW + lane] = u;
+      lds.Wm[j * ROW + lane] = w;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
+    float a_u = 0.f, a_x = 0.f, a_y = 0.f, a_ax = 0.f, a_ay = 0.f, a_xx = 0.f, a_xy = 0.f, a_yy = 0.f;
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
+    float op = 0.f, cA = 0.f, cB = 0.f, cC = 0.f;
+    if ((unsigned)ej < cnt) {
+      const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
+      const float mx = r0.x, my = r0.y;
+      cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x; op = r1.y;
+      const float* Urow = &lds.U[ej * ROW + grp * B];
+      const float* Wrow = &lds.Wm[ej * ROW + grp * B];
+      const float4* ptab = &lds.pix[(grp * B) * 2];
+#pragma unroll 4
+      for (int i = 0; i < B; ++i) {
+        const float u = Urow[i], w = Wrow[i];
+        const float4 p0 = ptab[i * 2];
+        const float2 p1 = *reinterpret_cast<const float2*>(&ptab[i * 2 + 1]);
+        const float dx = mx - p0.x, dy = my - p0.y;
+        const float udx = u * dx, udy = u * dy;
+        a_u += u; a_x += udx; a_y += udy;
+        a_ax += fabsf(u * fmaf(cA, dx, cB * dy));
+        a_ay += fabsf(u * fmaf(cC, dy, cB * dx));
+        a_xx = fmaf(udx, dx, a_xx); a_xy = fmaf(udx, dy, a_xy); a_yy = fmaf(udy, dy, a_yy);
+        a_r = fmaf(w, p0.z, a_r); a_g = fmaf(w, p0.w, a_g); a_b = fmaf(w, p1.x, a_b); a_d = fmaf(w, p1.y, a_d);
+      }
+    }
+    // combine the NGRP partial lanes of every entry (fixed order -> deterministic)
+    float acc[12] = {a_u, a_x, a_y, a_ax, a_ay, a_xx, a_xy, a_yy, a_r, a_g, a_b, a_d};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+      for (int d = B; d < 64; d <<= 1) acc[i] += __shfl_xor(acc[i], d);
+    }
     if ((unsigned)lane < cnt) {
+      const float sxm = -op * ddelx_dx, sym = -op * ddely_dy;
+      float4 o0, o1, o2;
+      o0.x = sxm * (cA * acc[1] + cB * acc[2]);   // dL/dmean2D x (NDC units)
+      o0.y = sym * (cC * acc[2] + cB * acc[1]);   // dL/dmean2D y
+      o0.z = op * ddelx_dx * acc[3];              // sum |.| x
+      o0.w = op * ddely_dy * acc[4];              // sum |.| y
+      o1.x = -0.5f * op * acc[5];                 // dL/dconic A
+      o1.y = -op * acc[6];                        // dL/dconic B
+      o1.z = -0.5f * op * acc[7];                 // dL/dconic C
+      o1.w = acc[0];                              // dL/d(op)
+      o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
       float4* dst = dupgrad + (size_t)my_dup * 4;
-      dst[0] = gs[lane * 3]; dst[1] = gs[lane * 3 + 1]; dst[2] = gs[lane * 3 + 2];
+      dst[0] = o0; dst[1] = o1; dst[2] = o2;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -197,6 +243,13 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
 
 using namespace sfgs;
 
+// entries per backward batch: 16 (11 KB LDS per wave, 3 workgroups per CU) or 32. Tuning knob for
+// experiments only (SFGS_BWD_BATCH=32); the default is what bench.py measures.
+static int bwd_batch() {
+  static const int v = [] { const char* e = getenv("SFGS_BWD_BATCH"); return (e && atoi(e) == 32) ? 32 : 16; }();
+  return v;
+}
+
 extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                                     const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
                                     const void* image, const float* dL_dcolor, const float* dL_ddepth,
@@ -225,8 +278,14 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
+  if (bwd_batch() == 32)
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+    hipLaunchKernelGGL(composite_bwd_kernel<32>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+                       bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
+                       dL_dalpha, (float4*)dupgrad); }
+  else
+  { ProfScope ps_(KID_COMPOSITE_BWD, stream);
+    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
                        dL_dalpha, (float4*)dupgrad); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);

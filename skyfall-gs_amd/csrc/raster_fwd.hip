@@ -156,8 +156,7 @@ __global__ void __launch_bounds__(PRE_BLOCK)
 scatter_kernel(KFrame kf, int N, const float4* __restrict__ rec_in, const uint2* __restrict__ brange,
                uint32_t* __restrict__ dupoff, const uint32_t* __restrict__ block_base,
                const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
-               unsigned long long* __restrict__ keys, uint32_t* __restrict__ dup_gauss,
-               unsigned long long dup_capacity, unsigned long long* __restrict__ hdr) {
+               uint4* __restrict__ items, unsigned long long dup_capacity, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const unsigned cnt = g < N ? dupoff[g] : 0u;
@@ -184,30 +183,30 @@ scatter_kernel(KFrame kf, int N, const float4* __restrict__ rec_in, const uint2*
   br.y0 = (int)(pk.y & 0xffffu); br.y1 = (int)(pk.y >> 16);
   const float thr = alpha_threshold_log2(r.op);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN;
-  const unsigned long long khi = (unsigned long long)__float_as_uint(r.depth) << 32;
+  const unsigned depth_bits = __float_as_uint(r.depth);
   unsigned j = 0;
   for (int ty = br.y0; ty < br.y1; ++ty)
     for (int tx = br.x0; tx < br.x1; ++tx)
       if (bin_test(r, thr, tx, ty, W, H, bound)) {
         const int t = ty * TX8 + tx;
         const unsigned pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-        const unsigned d = off + j;
-        keys[pos] = khi | d;
-        dup_gauss[d] = (unsigned)g;
+        items[pos] = make_uint4((unsigned)g, depth_bits, off + j, 0u);  // one 16-byte store per duplicate
         ++j;
       }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: per-tile sort of 64-bit keys (depth bits, duplicate index) == ascending (depth, Gaussian id),
+// K4: per-tile sort by 64-bit key (depth bits << 32 | Gaussian id) == ascending (depth, Gaussian id),
 // SURVEY A.3. Normalised bitonic network: every comparator sorts ascending, so +inf padding stays at
-// the tail. One wave per tile, list in LDS.
+// the tail. One wave per tile, keys + 16-bit local payload indices in LDS.
 template <int CAP>
 __global__ void __launch_bounds__(64)
 sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_start,
-                      const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ dup_gauss,
-                      uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
+                      const uint4* __restrict__ items, uint32_t* __restrict__ sorted_id,
+                      uint32_t* __restrict__ sorted_dup) {
   __shared__ unsigned long long k[CAP];
+  __shared__ uint32_t dups[CAP];
+  __shared__ unsigned short vi[CAP];
   const int t = blockIdx.x;
   if (t >= T8) return;
   const unsigned s = tile_start[t], e = tile_start[t + 1];
@@ -216,7 +215,16 @@ sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_
   const int lane = threadIdx.x;
   int n = 1;
   while (n < L) n <<= 1;
-  for (int i = lane; i < n; i += 64) k[i] = i < L ? keys[s + i] : ~0ull;
+  for (int i = lane; i < n; i += 64) {
+    if (i < L) {
+      const uint4 it = items[s + i];
+      k[i] = ((unsigned long long)it.y << 32) | it.x;
+      dups[i] = it.z;
+    } else {
+      k[i] = ~0ull;
+    }
+    vi[i] = (unsigned short)i;
+  }
   __syncthreads();
   for (int size = 2; size <= n; size <<= 1) {
     const int half = size >> 1;
@@ -224,70 +232,68 @@ sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_
       const int blk = c / half, o = c - blk * half;
       const int i = blk * size + o, j = blk * size + size - 1 - o;
       const unsigned long long a = k[i], b = k[j];
-      if (a > b) { k[i] = b; k[j] = a; }
+      if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
     }
     __syncthreads();
     for (int stride = half >> 1; stride >= 1; stride >>= 1) {
       for (int c = lane; c < (n >> 1); c += 64) {
         const int i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
         const unsigned long long a = k[i], b = k[j];
-        if (a > b) { k[i] = b; k[j] = a; }
+        if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
       }
       __syncthreads();
     }
   }
   for (int i = lane; i < L; i += 64) {
-    const unsigned d = (unsigned)(k[i] & 0xffffffffull);
-    sorted_dup[s + i] = d;
-    sorted_id[s + i] = dup_gauss[d];
+    sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull);
+    sorted_dup[s + i] = dups[vi[i]];
   }
 }
 
-// Long lists: same network on the tile's segment in global memory (virtual padding: comparators that
-// reach past the end are no-ops). Rare path; agent-scope relaxed accesses bypass the per-CU L1 so
-// that waves of the block see each other's exchanges after the barrier.
+// Long lists: same network on the tile's segment of 16-byte items in global memory (virtual padding:
+// comparators that reach past the end are no-ops). Rare path; agent-scope relaxed accesses bypass the
+// per-CU L1 so that waves of the block see each other's exchanges after the barrier.
 __global__ void __launch_bounds__(256)
-sort_tiles_global_kernel(int T8, int lo, const uint32_t* __restrict__ tile_start, unsigned long long* keys,
-                         const uint32_t* __restrict__ dup_gauss, uint32_t* __restrict__ sorted_id,
-                         uint32_t* __restrict__ sorted_dup) {
+sort_tiles_global_kernel(int T8, int lo, const uint32_t* __restrict__ tile_start, uint4* items,
+                         uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
   const int t = blockIdx.x;
   if (t >= T8) return;
   const unsigned s = tile_start[t], e = tile_start[t + 1];
   const long long L = (long long)e - s;
   if (L <= lo) return;
-  unsigned long long* k = keys + s;
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(items + s);  // item i = words 2i (key), 2i+1 (dup)
   long long n = 1;
   while (n < L) n <<= 1;
-  auto ld = [&](long long i) { return __hip_atomic_load(&k[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld = [&](long long i) { return __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto st = [&](long long i, unsigned long long v) {
-    __hip_atomic_store(&k[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&w[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto cmpx = [&](long long i, long long j) {
+    const unsigned long long a = ld(2 * i), b = ld(2 * j);
+    if (a > b) {
+      const unsigned long long pa = ld(2 * i + 1), pb = ld(2 * j + 1);
+      st(2 * i, b); st(2 * j, a); st(2 * i + 1, pb); st(2 * j + 1, pa);
+    }
   };
   for (long long size = 2; size <= n; size <<= 1) {
     const long long half = size >> 1;
     for (long long c = threadIdx.x; c < (n >> 1); c += 256) {
       const long long blk = c / half, o = c - blk * half;
       const long long i = blk * size + o, j = blk * size + size - 1 - o;
-      if (j < L) {
-        const unsigned long long a = ld(i), b = ld(j);
-        if (a > b) { st(i, b); st(j, a); }
-      }
+      if (j < L) cmpx(i, j);
     }
     __syncthreads();
     for (long long stride = half >> 1; stride >= 1; stride >>= 1) {
       for (long long c = threadIdx.x; c < (n >> 1); c += 256) {
         const long long i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
-        if (j < L) {
-          const unsigned long long a = ld(i), b = ld(j);
-          if (a > b) { st(i, b); st(j, a); }
-        }
+        if (j < L) cmpx(i, j);
       }
       __syncthreads();
     }
   }
   for (long long i = threadIdx.x; i < L; i += 256) {
-    const unsigned d = (unsigned)(ld(i) & 0xffffffffull);
-    sorted_dup[s + i] = d;
-    sorted_id[s + i] = dup_gauss[d];
+    sorted_id[s + i] = (unsigned)(ld(2 * i) & 0xffffffffull);
+    sorted_dup[s + i] = (unsigned)(ld(2 * i + 1) & 0xffffffffull);
   }
 }
 
@@ -475,20 +481,20 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, voi
   if (NB > 0) {
     { ProfScope ps_(KID_SCATTER, stream);
       hipLaunchKernelGGL(scatter_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, gv.rec, gv.brange, gv.dupoff,
-                         tv.block_base, tv.tile_start, tv.tile_cursor, bv.keys, bv.dup_gauss,
+                         tv.block_base, tv.tile_start, tv.tile_cursor, bv.items,
                          (unsigned long long)dup_capacity, tv.hdr); }
     SFGS_POST_LAUNCH("scatter", stream, frame->debug);
     { ProfScope ps_(KID_SORT_SMALL, stream);
       hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_SMALL>, dim3(T8), dim3(64), 0, stream, T8, 0, SORT_SMALL,
-                         tv.tile_start, bv.keys, bv.dup_gauss, bv.sorted_id, bv.sorted_dup); }
+                         tv.tile_start, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
     { ProfScope ps_(KID_SORT_MEDIUM, stream);
       hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(T8), dim3(64), 0, stream, T8, SORT_SMALL, SORT_CAP,
-                         tv.tile_start, bv.keys, bv.dup_gauss, bv.sorted_id, bv.sorted_dup); }
+                         tv.tile_start, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
     { ProfScope ps_(KID_SORT_GLOBAL, stream);
-      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_start, bv.keys,
-                         bv.dup_gauss, bv.sorted_id, bv.sorted_dup); }
+      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_start, bv.items,
+                         bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_global", stream, frame->debug);
   }
   ImageView iv = {nullptr, nullptr, nullptr};

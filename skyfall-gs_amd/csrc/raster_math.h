@@ -445,11 +445,14 @@ SFGS_HD void pixel_bwd_init(PixelBwd& s, unsigned last, float T_final, float dac
   s.bg_dot = bg[0] * s.gch[0] + bg[1] * s.gch[1] + bg[2] * s.gch[2];
 }
 
-// One contributing splat, back to front. v[12] (Grad2D order) receives this pixel's partial sums.
-SFGS_HD void pixel_bwd_step(PixelBwd& s, const SplatEval& e, float qa, float qb, float qc, float op, float depth,
-                            float r, float g, float b, float ddelx_dx, float ddely_dy, float v[12]) {
-  s.Tr = s.Tr * fast_rcp(1.0f - e.alpha);
-  const float w = e.alpha * s.Tr;
+// One contributing splat, back to front: advances the pixel's recurrences and returns the two scalars
+// every gradient of this (pixel, splat) pair is built from:
+//   u = G * dL/dalpha   and   w = alpha * T  (the blending weight).
+SFGS_HD void pixel_bwd_scalars(PixelBwd& s, const SplatEval& e, float depth, float r, float g, float b, float& u,
+                               float& w) {
+  const float inv = fast_rcp(1.0f - e.alpha);
+  s.Tr = s.Tr * inv;
+  w = e.alpha * s.Tr;
   const float val[5] = {r, g, b, depth, 1.0f};
   float dL_dalpha = 0.f;
   for (int ch = 0; ch < 5; ++ch) {
@@ -459,23 +462,32 @@ SFGS_HD void pixel_bwd_step(PixelBwd& s, const SplatEval& e, float qa, float qb,
   }
   dL_dalpha *= s.Tr;
   s.last_alpha = e.alpha;
-  dL_dalpha += (-s.T_final / (1.f - e.alpha)) * s.bg_dot;
-  // conic in natural-log units: A = -2 ln2 qa, B = -ln2 qb, C = -2 ln2 qc. The min(0.99, .) clamp is
-  // ignored in the derivative [UPSTREAM].
+  dL_dalpha -= (s.T_final * inv) * s.bg_dot;
+  u = e.G * dL_dalpha;
+}
+
+// Per-pixel partial sums v[12] (Grad2D order) of one pair from (u, w). The min(0.99, .) clamp is ignored
+// in the derivative [UPSTREAM]. Conic in natural-log units: A = -2 ln2 qa, B = -ln2 qb, C = -2 ln2 qc.
+SFGS_HD void pair_partials(const SplatEval& e, float u, float w, float qa, float qb, float qc, float op,
+                           const float gch[5], float ddelx_dx, float ddely_dy, float v[12]) {
   const float cA = -2.0f * LN2 * qa, cB = -LN2 * qb, cC = -2.0f * LN2 * qc;
-  const float dL_dG = op * dL_dalpha;
-  const float gdx = e.G * e.dx, gdy = e.G * e.dy;
-  const float dG_ddelx = -gdx * cA - gdy * cB;
-  const float dG_ddely = -gdy * cC - gdx * cB;
-  const float gx = dL_dG * dG_ddelx * ddelx_dx;
-  const float gy = dL_dG * dG_ddely * ddely_dy;
+  const float ou = op * u;  // = dL/dG * G
+  const float gx = -ou * (cA * e.dx + cB * e.dy) * ddelx_dx;
+  const float gy = -ou * (cC * e.dy + cB * e.dx) * ddely_dy;
   v[0] = gx; v[1] = gy; v[2] = fabsf(gx); v[3] = fabsf(gy);
-  v[4] = -0.5f * gdx * e.dx * dL_dG;
-  v[5] = -gdx * e.dy * dL_dG;
-  v[6] = -0.5f * gdy * e.dy * dL_dG;
-  v[7] = e.G * dL_dalpha;
-  v[8] = w * s.gch[0]; v[9] = w * s.gch[1]; v[10] = w * s.gch[2];
-  v[11] = w * s.gch[3];
+  v[4] = -0.5f * ou * e.dx * e.dx;
+  v[5] = -ou * e.dx * e.dy;
+  v[6] = -0.5f * ou * e.dy * e.dy;
+  v[7] = u;
+  v[8] = w * gch[0]; v[9] = w * gch[1]; v[10] = w * gch[2];
+  v[11] = w * gch[3];
+}
+
+SFGS_HD void pixel_bwd_step(PixelBwd& s, const SplatEval& e, float qa, float qb, float qc, float op, float depth,
+                            float r, float g, float b, float ddelx_dx, float ddely_dy, float v[12]) {
+  float u, w;
+  pixel_bwd_scalars(s, e, depth, r, g, b, u, w);
+  pair_partials(e, u, w, qa, qb, qc, op, s.gch, ddelx_dx, ddely_dy, v);
 }
 
 // ---- backward of the per-Gaussian chain (second half) -------------------

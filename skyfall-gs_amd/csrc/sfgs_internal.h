@@ -158,19 +158,17 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
 }
 
 struct BinsView {
-  unsigned long long* keys;  // [D] (depth bits << 32) | duplicate index, tile-major, unsorted
-  uint32_t* dup_gauss;       // [D] duplicate index -> Gaussian id
-  uint32_t* sorted_id;       // [D] per-tile lists of Gaussian ids, front to back
-  uint32_t* sorted_dup;      // [D] the matching duplicate indices
+  uint4* items;          // [D] unsorted per-tile segments: (Gaussian id, depth bits, duplicate index, 0)
+  uint32_t* sorted_id;   // [D] per-tile lists of Gaussian ids, front to back
+  uint32_t* sorted_dup;  // [D] the matching duplicate indices
 };
 static inline size_t bins_bytes(int64_t D) {
-  return align_up((size_t)D * 8, 256) + 3 * align_up((size_t)D * 4, 256);
+  return align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
 }
 static inline BinsView bins_view(void* base, int64_t D) {
   BinsView b;
   char* p = (char*)base;
-  b.keys = (unsigned long long*)p; p += align_up((size_t)D * 8, 256);
-  b.dup_gauss = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
+  b.items = (uint4*)p; p += align_up((size_t)D * 16, 256);
   b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
   b.sorted_dup = (uint32_t*)p;
   return b;
