@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 1
+#define SFGS_ABI_VERSION 2
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -103,17 +103,18 @@ typedef struct SfgsRasterSizes {
   uint32_t struct_size;
   size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile ranges, duplicate offsets      */
   size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials */
-  size_t bins_bytes;     /* f(D):   duplicate keys, sorted per-tile lists                        */
+  size_t bins_bytes;     /* f(D):   staged + per-tile duplicates, sorted per-tile lists           */
   size_t image_bytes;    /* f(W,H): per-pixel last contributor, final T, raw depth (for backward)*/
   size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
 } SfgsRasterSizes;
 
 /* Counters produced by the plan stage (host copy). */
 typedef struct SfgsRasterCounters {
-  int64_t num_duplicates;      /* D_eff: (Gaussian,tile) pairs actually binned (opacity-aware rect) */
-  int64_t num_duplicates_ref;  /* D:     sum of tiles_touched by the reference 3-sigma rule          */
-  int64_t num_visible;         /* N_vis: count(radii > 0)                                            */
-  int64_t max_tile_list;       /* longest per-tile list                                              */
+  int64_t num_duplicates;      /* D_eff: (Gaussian, 8x8 tile) pairs binned (opacity-aware test)             */
+  int64_t num_duplicates_ref;  /* D:     sum of tiles_touched by the reference's 3-sigma 16x16 rule         */
+  int64_t num_visible;         /* N_vis: count(radii > 0)                                                   */
+  int64_t max_tile_list;       /* longest per-tile list                                                     */
+  int64_t overflow;            /* != 0: dup_capacity was too small, redo the plan with a larger bins blob   */
 } SfgsRasterCounters;
 
 int sfgs_abi_version(void);
@@ -132,24 +133,27 @@ int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);
 int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, SfgsRasterSizes* out);
 
 /* Forward, stage 1 ("plan"): preprocess every Gaussian (cull, EWA projection, 2D mip filter,
- * radius, SH->RGB), write radii[N] (int32), count duplicates per tile and scan the counts.
- * Asynchronous on `stream`. */
+ * radius, SH->RGB), write radii[N] (int32), bin every Gaussian into the 8x8 tiles it can contribute
+ * to (duplicates staged in `bins`, at most dup_capacity of them) and scan the per-tile counts.
+ * The number of duplicates is only known afterwards: if the counters report overflow, call again with
+ * a bins blob sized for counters.num_duplicates. Asynchronous on `stream`. */
 int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii,
                              void* geom, size_t geom_bytes, void* tiles, size_t tiles_bytes,
-                             void* stream);
+                             void* bins, size_t bins_bytes, int64_t dup_capacity, void* stream);
 
 /* Copies the plan counters to the host. SYNCHRONISES `stream` (the one host sync of the forward,
  * as in the reference, where the duplicate total sizes the sort buffers). */
 int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream);
 
-/* Forward, stage 2 ("render"): scatter duplicates into per-tile segments, sort each segment by
- * (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
- * out_depth[1,H,W], out_alpha[1,H,W]. `bins` must hold `dup_capacity` >= D_eff duplicates.
- * `image` may be NULL when no backward will follow. Asynchronous on `stream`. */
-int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, void* geom, void* tiles,
+/* Forward, stage 2 ("render"): permute the staged duplicates into per-tile segments, sort each
+ * segment by (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
+ * out_depth[1,H,W], out_alpha[1,H,W]. num_duplicates = counters.num_duplicates of the plan that
+ * filled `bins` (same dup_capacity). `image` may be NULL when no backward will follow.
+ * Asynchronous on `stream`. */
+int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles,
                                void* bins, size_t bins_bytes, int64_t dup_capacity,
-                               float* out_color, float* out_depth, float* out_alpha,
-                               void* image, size_t image_bytes, void* stream);
+                               int64_t num_duplicates, float* out_color, float* out_depth,
+                               float* out_alpha, void* image, size_t image_bytes, void* stream);
 
 /* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
  * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same dup_capacity, image)

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rots, const float* __restrict__ opac,
                       const float* __restrict__ shs, const int* __restrict__ radii,
-                      const uint32_t* __restrict__ dupoff, const float4* __restrict__ dupgrad,
+                      const uint2* __restrict__ dup, const float4* __restrict__ dupgrad,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
                       float* __restrict__ g_rots, float* __restrict__ g_opac, float* __restrict__ g_colors,
                       float* __restrict__ g_shs) {
@@ -199,7 +199,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   const bool vis = radii[g] > 0;
   float* gsh = g_shs ? g_shs + 3 * (size_t)f.sh_coeffs * g : nullptr;
   if (vis) {
-    const unsigned d0 = dupoff[g], d1 = dupoff[g + 1];
+    const uint2 dr = dup[g];
+    const unsigned d0 = dr.x, d1 = dr.x + dr.y;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
     for (unsigned d = d0; d < d1; ++d) {
       const float4 x0 = dupgrad[(size_t)d * 4], x1 = dupgrad[(size_t)d * 4 + 1], x2 = dupgrad[(size_t)d * 4 + 2];
@@ -292,7 +293,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
-                       g->rotations, g->opacities, g->shs, radii, gv.dupoff, (const float4*)dupgrad, grads->means3D,
+                       g->rotations, g->opacities, g->shs, radii, gv.dup, (const float4*)dupgrad, grads->means3D,
                        grads->means2D, grads->scales, grads->rotations, grads->opacities, grads->colors_precomp,
                        grads->shs); }
   SFGS_POST_LAUNCH("preprocess_bwd", stream, frame->debug);

@@ -29,21 +29,47 @@ __global__ void __launch_bounds__(256) subpix_bound_kernel(const float* __restri
   if (lane_id() == 0) atomicMax((unsigned int*)&hdr[HDR_SUBPIX_BOUND], __float_as_uint(m));
 }
 
+// hit mask of tiles [c0, c0 + 64) of a walk range (row-major inside the range)
+__device__ __forceinline__ unsigned long long chunk_hits(const SplatRec& r, float thr, const BinRange& br, long long c0,
+                                                         long long ntiles, int W, int H, float bound) {
+  const int nx = br.x1 - br.x0;
+  const int cnt = (int)min(64ll, ntiles - c0);
+  unsigned long long m = 0ull;
+  int ty = br.y0 + (int)(c0 / nx), tx = br.x0 + (int)(c0 % nx);
+  for (int i = 0; i < cnt; ++i) {
+    if (bin_test(r, thr, tx, ty, W, H, bound)) m |= 1ull << i;
+    if (++tx == br.x1) { tx = br.x0; ++ty; }
+  }
+  return m;
+}
+
 // ------------------------------------------------------------------------------------------------
-// K1: one thread per Gaussian.
+// K1: one thread per Gaussian: project, write radii + the compositing record, and bin. Binning in one
+// pass: the thread walks the 8x8 tiles its splat can reach (opacity-aware test, raster_math.h),
+// remembers the hits in a bit mask, the block reserves a contiguous range of duplicate indices with ONE
+// returning atomic, and every hit then takes its rank inside the tile from the tile counter and is
+// staged as (id, depth, tile, rank). Nothing is recounted later: K3 is a pure permutation.
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
                   const float* __restrict__ colors, const float* __restrict__ shs, int* __restrict__ radii,
-                  float4* __restrict__ rec_out, uint32_t* __restrict__ dupcnt, uint2* __restrict__ brange,
-                  uint32_t* __restrict__ tile_count,
-                  uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_nvis,
-                  unsigned long long* __restrict__ block_dref, const unsigned long long* __restrict__ hdr) {
+                  float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ tile_count,
+                  uint4* __restrict__ staging, unsigned long long dup_capacity,
+                  uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
+                  unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
+  __shared__ unsigned long long s_base;
   const FrameParams f = load_frame(kf);
   const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  unsigned n_dup = 0, vis = 0, dref = 0;
+  const int TX8 = (f.W + TILE_BIN - 1) / TILE_BIN;
+  unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
+  unsigned long long mask = 0ull;  // hit mask of the last 64-tile chunk of the walk range
+  long long ntiles = 0;
+  SplatRec r;
+  BinRange br;
+  float thr = 0.f;
+  br.x0 = br.x1 = br.y0 = br.y1 = 0;
   if (g < N) {
     float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
     float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
@@ -58,30 +84,52 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       if (colors) {
         rgb[0] = colors[3 * (size_t)g]; rgb[1] = colors[3 * (size_t)g + 1]; rgb[2] = colors[3 * (size_t)g + 2];
       } else {
-        unsigned mask; float dir[3], len;
-        sh_to_rgb(f.sh_degree, shs + 3 * (size_t)f.sh_coeffs * g, p, f.campos, rgb, &mask, dir, &len);
+        unsigned cm; float dir[3], len;
+        sh_to_rgb(f.sh_degree, shs + 3 * (size_t)f.sh_coeffs * g, p, f.campos, rgb, &cm, dir, &len);
       }
-      const SplatRec r = make_record(pr, opac[g], rgb);
+      r = make_record(pr, opac[g], rgb);
       rec_out[3 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
       rec_out[3 * (size_t)g + 1] = make_float4(r.qc, r.op, r.depth, r.r);
       rec_out[3 * (size_t)g + 2] = make_float4(r.g, r.b, r.ex, r.ey);
-      const BinRange br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
-      brange[g] = make_uint2((unsigned)br.x0 | ((unsigned)br.x1 << 16), (unsigned)br.y0 | ((unsigned)br.y1 << 16));
-      const float thr = alpha_threshold_log2(r.op);
-      const int TX8 = (f.W + TILE_BIN - 1) / TILE_BIN;
-      for (int ty = br.y0; ty < br.y1; ++ty)
-        for (int tx = br.x0; tx < br.x1; ++tx)
-          if (bin_test(r, thr, tx, ty, f.W, f.H, bound)) {
-            atomicAdd(&tile_count[ty * TX8 + tx], 1u);
-            ++n_dup;
-          }
+      depth_bits = __float_as_uint(r.depth);
+      br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
+      thr = alpha_threshold_log2(r.op);
+      ntiles = (long long)(br.x1 - br.x0) * (br.y1 - br.y0);
+      for (long long c0 = 0; c0 < ntiles; c0 += 64) {
+        mask = chunk_hits(r, thr, br, c0, ntiles, f.W, f.H, bound);
+        n_dup += (unsigned)__popcll(mask);
+      }
     }
-    dupcnt[g] = n_dup;
   }
-  // per-block totals (no contended atomics: plan_scan sums them)
+  // reserve duplicate indices: block scan + one returning atomic per block
   unsigned total;
-  block_excl_scan_u32<PRE_BLOCK>(n_dup, &total, s_red);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  const unsigned ex = block_excl_scan_u32<PRE_BLOCK>(n_dup, &total, s_red);
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(&hdr[HDR_D_EFF], (unsigned long long)total) : 0ull;
+  __syncthreads();
+  const unsigned long long base = s_base;
+  const bool fits = base + total <= dup_capacity;
+  if (!fits && threadIdx.x == 0) hdr[HDR_OVERFLOW] = 1ull;
+  if (g < N) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
+  if (fits && n_dup) {
+    // emit: one 64-tile chunk of the walk range at a time (a single chunk -- whose hit mask is still in
+    // `mask` from the counting pass -- for all but very large splats)
+    const unsigned long long first = base + ex;
+    const int nx = br.x1 - br.x0;
+    unsigned j = 0;
+    for (long long c0 = 0; c0 < ntiles; c0 += 64) {
+      unsigned long long m = ntiles <= 64 ? mask : chunk_hits(r, thr, br, c0, ntiles, f.W, f.H, bound);
+      while (m) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1;
+        const long long idx = c0 + bit;
+        const int t = (br.y0 + (int)(idx / nx)) * TX8 + br.x0 + (int)(idx % nx);
+        const unsigned rank = atomicAdd(&tile_count[t], 1u);
+        staging[first + j] = make_uint4((unsigned)g, depth_bits, (unsigned)t, rank);
+        ++j;
+      }
+    }
+  }
+  // per-block statistics (summed by plan_scan; no contended atomics)
   block_excl_scan_u32<PRE_BLOCK>(vis, &total, s_red);
   if (threadIdx.x == 0) block_nvis[blockIdx.x] = total;
   block_excl_scan_u32<PRE_BLOCK>(dref, &total, s_red);
@@ -89,12 +137,10 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: single workgroup. Exclusive scans of tile_count -> tile_start and block_sums -> block_base,
-// plus the counters the host reads back.
+// K2: single workgroup. Exclusive scan of tile_count -> tile_start, plus the counters the host reads.
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
 plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
-                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_base,
                  const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
                  unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[SCAN_NT / 64 + 1];
@@ -109,8 +155,7 @@ plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32
     if (i < T8) tile_start[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) { tile_start[T8] = carry; hdr[HDR_D_EFF] = carry; }
-  // max list length
+  if (threadIdx.x == 0) tile_start[T8] = carry;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (unsigned)__shfl_xor((int)maxlen, d));
   if (lane_id() == 0) s_red[threadIdx.x >> 6] = maxlen;
@@ -121,19 +166,8 @@ plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32
     hdr[HDR_MAX_LIST] = m;
   }
   __syncthreads();
-  // per-block duplicate bases
-  carry = 0;
   unsigned long long nvis = 0, dref = 0;
-  for (int base = 0; base < NB; base += SCAN_NT) {
-    const int i = base + threadIdx.x;
-    const unsigned v = i < NB ? block_sums[i] : 0u;
-    if (i < NB) { nvis += block_nvis[i]; dref += block_dref[i]; }
-    unsigned total;
-    const unsigned ex = block_excl_scan_u32<SCAN_NT>(v, &total, s_red);
-    if (i < NB) block_base[i] = carry + ex;
-    carry += total;
-  }
-  // reduce nvis / dref
+  for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
   for (int pass = 0; pass < 2; ++pass) {
     unsigned long long v = pass == 0 ? nvis : dref;
 #pragma unroll
@@ -150,49 +184,15 @@ plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: scatter. Thread g re-walks its tile range (same deterministic test as K1) and emits one key per
-// binned tile. dupoff[g] (count) becomes the exclusive duplicate offset of Gaussian g.
-__global__ void __launch_bounds__(PRE_BLOCK)
-scatter_kernel(KFrame kf, int N, const float4* __restrict__ rec_in, const uint2* __restrict__ brange,
-               uint32_t* __restrict__ dupoff, const uint32_t* __restrict__ block_base,
-               const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
-               uint4* __restrict__ items, unsigned long long dup_capacity, unsigned long long* __restrict__ hdr) {
-  __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
-  const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  const unsigned cnt = g < N ? dupoff[g] : 0u;
-  unsigned total;
-  const unsigned off = block_base[blockIdx.x] + block_excl_scan_u32<PRE_BLOCK>(cnt, &total, s_red);
-  if (g >= N) return;
-  dupoff[g] = off;
-  if (g == N - 1) dupoff[N] = off + cnt;
-  if (cnt == 0) return;
-  if ((unsigned long long)off + cnt > dup_capacity) {
-    hdr[HDR_OVERFLOW] = 1ull;
-    return;
-  }
-  const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
-  const int W = kf.W, H = kf.H;
-  const float4 r0 = rec_in[3 * (size_t)g], r1 = rec_in[3 * (size_t)g + 1], r2 = rec_in[3 * (size_t)g + 2];
-  SplatRec r;
-  r.mx = r0.x; r.my = r0.y; r.qa = r0.z; r.qb = r0.w;
-  r.qc = r1.x; r.op = r1.y; r.depth = r1.z; r.r = r1.w;
-  r.g = r2.x; r.b = r2.y; r.ex = r2.z; r.ey = r2.w;
-  const uint2 pk = brange[g];
-  BinRange br;
-  br.x0 = (int)(pk.x & 0xffffu); br.x1 = (int)(pk.x >> 16);
-  br.y0 = (int)(pk.y & 0xffffu); br.y1 = (int)(pk.y >> 16);
-  const float thr = alpha_threshold_log2(r.op);
-  const int TX8 = (W + TILE_BIN - 1) / TILE_BIN;
-  const unsigned depth_bits = __float_as_uint(r.depth);
-  unsigned j = 0;
-  for (int ty = br.y0; ty < br.y1; ++ty)
-    for (int tx = br.x0; tx < br.x1; ++tx)
-      if (bin_test(r, thr, tx, ty, W, H, bound)) {
-        const int t = ty * TX8 + tx;
-        const unsigned pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-        items[pos] = make_uint4((unsigned)g, depth_bits, off + j, 0u);  // one 16-byte store per duplicate
-        ++j;
-      }
+// K3: permutation of the staged duplicates into per-tile segments (one thread per duplicate; coalesced
+// 16-byte reads, one 16-byte scattered store each; no atomics, no tests).
+__global__ void __launch_bounds__(256)
+permute_kernel(unsigned D, const uint4* __restrict__ staging, const uint32_t* __restrict__ tile_start,
+               uint4* __restrict__ items) {
+  const unsigned d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const uint4 it = staging[d];
+  items[tile_start[it.z] + it.w] = make_uint4(it.x, it.y, d, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,7 +407,8 @@ extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, Sfg
 }
 
 extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* geom,
-                                        size_t geom_sz, void* tiles, size_t tiles_sz, void* stream_) {
+                                        size_t geom_sz, void* tiles, size_t tiles_sz, void* bins, size_t bins_sz,
+                                        int64_t dup_capacity, void* stream_) {
   if (int rc = check_frame(frame)) return rc;
   if (int rc = check_gaussians(frame, g)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -418,7 +419,12 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   SFGS_REQUIRE(tiles_sz >= tb, SFGS_E_CAPACITY, "tiles blob: %zu bytes given, %zu needed", tiles_sz, tb);
   SFGS_REQUIRE(geom_sz >= geom_bytes(N), SFGS_E_CAPACITY, "geom blob: %zu bytes given, %zu needed", geom_sz, geom_bytes(N));
   SFGS_REQUIRE(N == 0 || (radii && geom), SFGS_E_ARG, "radii / geom is NULL");
+  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32), SFGS_E_ARG, "bad dup_capacity");
+  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity), SFGS_E_CAPACITY, "bins blob: %zu bytes given, %zu needed", bins_sz,
+               bins_bytes(dup_capacity));
+  SFGS_REQUIRE(dup_capacity == 0 || bins, SFGS_E_ARG, "bins blob is NULL");
   const GeomView gv = geom_view(geom, N);
+  const BinsView bv = bins_view(bins, dup_capacity);
   const KFrame kf = make_kframe(frame);
   const int T8 = (int)tiles8(W, H), NB = (int)pre_blocks(N);
   SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
@@ -432,14 +438,13 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
       hipLaunchKernelGGL(preprocess_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
-                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dupoff, gv.brange,
-                         tv.tile_count,
-                         tv.block_sums, tv.block_nvis, tv.block_dref, tv.hdr); }
+                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.tile_count,
+                         bv.staging, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref, tv.hdr); }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, T8, NB, tv.tile_count, tv.tile_start,
-                       tv.block_sums, tv.block_base, tv.block_nvis, tv.block_dref, tv.hdr); }
+                       tv.block_nvis, tv.block_dref, tv.hdr); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;
 }
@@ -454,13 +459,14 @@ extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* 
   out->num_duplicates_ref = (int64_t)h[HDR_D_REF];
   out->num_visible = (int64_t)h[HDR_N_VIS];
   out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
+  out->overflow = (int64_t)h[HDR_OVERFLOW];
   return SFGS_OK;
 }
 
 constexpr int SORT_SMALL = 512, SORT_CAP = 4096;
 
-extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, void* geom,
-                                          void* tiles, void* bins, size_t bins_sz, int64_t dup_capacity,
+extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles,
+                                          void* bins, size_t bins_sz, int64_t dup_capacity, int64_t num_duplicates,
                                           float* out_color, float* out_depth, float* out_alpha, void* image,
                                           size_t image_sz, void* stream_) {
   if (int rc = check_frame(frame)) return rc;
@@ -468,22 +474,24 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, voi
   const int W = frame->image_width, H = frame->image_height;
   SFGS_REQUIRE(N >= 0 && tiles && out_color && out_depth && out_alpha, SFGS_E_ARG, "NULL argument");
   SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32), SFGS_E_ARG, "bad dup_capacity");
+  SFGS_REQUIRE(num_duplicates >= 0 && num_duplicates <= dup_capacity, SFGS_E_CAPACITY,
+               "num_duplicates %lld exceeds dup_capacity %lld: redo the plan with a larger bins blob",
+               (long long)num_duplicates, (long long)dup_capacity);
   SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity), SFGS_E_CAPACITY, "bins blob: %zu bytes given, %zu needed", bins_sz,
                bins_bytes(dup_capacity));
   SFGS_REQUIRE(image == nullptr || image_sz >= image_bytes(W, H), SFGS_E_CAPACITY, "image blob too small");
   SFGS_REQUIRE(dup_capacity == 0 || bins, SFGS_E_ARG, "bins blob is NULL");
-  const TilesView tv = tiles_view(tiles, W, H, N, nullptr);
+  const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
   const BinsView bv = bins_view(bins, dup_capacity);
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN, T8 = TX8 * TY8;
-  const int NB = (int)pre_blocks(N);
-  if (NB > 0) {
-    { ProfScope ps_(KID_SCATTER, stream);
-      hipLaunchKernelGGL(scatter_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, gv.rec, gv.brange, gv.dupoff,
-                         tv.block_base, tv.tile_start, tv.tile_cursor, bv.items,
-                         (unsigned long long)dup_capacity, tv.hdr); }
-    SFGS_POST_LAUNCH("scatter", stream, frame->debug);
+  if (num_duplicates > 0) {
+    const unsigned D = (unsigned)num_duplicates;
+    { ProfScope ps_(KID_PERMUTE, stream);
+      hipLaunchKernelGGL(permute_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, D, bv.staging, tv.tile_start,
+                         bv.items); }
+    SFGS_POST_LAUNCH("permute", stream, frame->debug);
     { ProfScope ps_(KID_SORT_SMALL, stream);
       hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_SMALL>, dim3(T8), dim3(64), 0, stream, T8, 0, SORT_SMALL,
                          tv.tile_start, bv.items, bv.sorted_id, bv.sorted_dup); }
@@ -493,8 +501,8 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, voi
                          tv.tile_start, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
     { ProfScope ps_(KID_SORT_GLOBAL, stream);
-      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_start, bv.items,
-                         bv.sorted_id, bv.sorted_dup); }
+      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_start,
+                         bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_global", stream, frame->debug);
   }
   ImageView iv = {nullptr, nullptr, nullptr};

@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 
 // ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
 enum KernelId {
-  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_SCATTER, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
+  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_PERMUTE, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
   KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN,
   KID_COUNT
 };
@@ -99,38 +99,31 @@ constexpr int PRE_BLOCK = 256;      // threads per block of the per-Gaussian ker
 constexpr int HDR_WORDS = 64;       // uint64 words at the head of the tiles blob
 
 enum HeaderSlot {
-  HDR_D_EFF = 0,      // binned (Gaussian, 8x8 tile) pairs
+  HDR_D_EFF = 0,      // binned (Gaussian, 8x8 tile) pairs; doubles as the duplicate-index allocator of K1
   HDR_D_REF = 1,      // sum of the reference's tiles_touched (16x16 rule)
   HDR_N_VIS = 2,      // count(radii > 0)
   HDR_MAX_LIST = 3,   // longest per-tile list
-  HDR_OVERFLOW = 4,   // set by the scatter when dup_capacity is too small
+  HDR_OVERFLOW = 4,   // set by preprocess when dup_capacity is too small (the plan must be redone)
   HDR_SUBPIX_BOUND = 5  // float bits of max |subpixel_offset| (0 when none)
 };
 
 struct GeomView {
-  float4* rec;        // [N][3] float4 = SplatRec
-  uint32_t* dupoff;   // [N+1] per-Gaussian duplicate count (after plan) -> exclusive offsets (after render)
-  uint2* brange;      // [N] 8x8-tile range to walk, packed (x0 | x1 << 16, y0 | y1 << 16)
+  float4* rec;   // [N][3] float4 = SplatRec
+  uint2* dup;    // [N] (first duplicate index, duplicate count) of every Gaussian
 };
-static inline size_t geom_bytes(int64_t N) {
-  return align_up((size_t)N * 48, 256) + align_up((size_t)(N + 1) * 4, 256) + align_up((size_t)N * 8, 256);
-}
+static inline size_t geom_bytes(int64_t N) { return align_up((size_t)N * 48, 256) + align_up((size_t)N * 8, 256); }
 static inline GeomView geom_view(void* base, int64_t N) {
   GeomView g;
   char* p = (char*)base;
   g.rec = (float4*)p; p += align_up((size_t)N * 48, 256);
-  g.dupoff = (uint32_t*)p; p += align_up((size_t)(N + 1) * 4, 256);
-  g.brange = (uint2*)p;
+  g.dup = (uint2*)p;
   return g;
 }
 
 struct TilesView {
   unsigned long long* hdr;  // [HDR_WORDS]
   uint32_t* tile_count;     // [T8]   (zeroed by plan)
-  uint32_t* tile_cursor;    // [T8]   (zeroed by plan)
   uint32_t* tile_start;     // [T8+1]
-  uint32_t* block_sums;     // [NB] duplicates emitted per preprocess block
-  uint32_t* block_base;     // [NB] exclusive scan of block_sums
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
@@ -146,11 +139,8 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   size_t off = 0;
   t.hdr = (unsigned long long*)(p + off); off += HDR_WORDS * 8;
   t.tile_count = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
-  t.tile_cursor = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
   t.zero_bytes = off;
   t.tile_start = (uint32_t*)(p + off); off += align_up((size_t)(T8 + 1) * 4, 256);
-  t.block_sums = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
-  t.block_base = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
   if (total) *total = off;
@@ -158,16 +148,18 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
 }
 
 struct BinsView {
-  uint4* items;          // [D] unsorted per-tile segments: (Gaussian id, depth bits, duplicate index, 0)
+  uint4* staging;        // [D] duplicates in Gaussian order: (Gaussian id, depth bits, tile, rank in tile)
+  uint4* items;          // [D] the same permuted into per-tile segments: (Gaussian id, depth bits, dup index, 0)
   uint32_t* sorted_id;   // [D] per-tile lists of Gaussian ids, front to back
   uint32_t* sorted_dup;  // [D] the matching duplicate indices
 };
 static inline size_t bins_bytes(int64_t D) {
-  return align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
+  return 2 * align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
 }
 static inline BinsView bins_view(void* base, int64_t D) {
   BinsView b;
   char* p = (char*)base;
+  b.staging = (uint4*)p; p += align_up((size_t)D * 16, 256);
   b.items = (uint4*)p; p += align_up((size_t)D * 16, 256);
   b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
   b.sorted_dup = (uint32_t*)p;

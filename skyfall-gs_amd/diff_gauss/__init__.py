@@ -43,6 +43,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _last_counters = {}
+_cap_hint = {}   # device index -> duplicate capacity to plan with (grows geometrically)
 
 
 def last_counters():
@@ -112,33 +113,41 @@ class _Rasterize(torch.autograd.Function):
             gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                                  L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
             sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
-            L.check(lib.sfgs_raster_sizes(N, W, H, 0, L.C.byref(sizes)))
             u8 = dict(dtype=torch.uint8, device=dev)
-            geom = torch.empty(max(sizes.geom_bytes, 1), **u8)
-            tiles = torch.empty(sizes.tiles_bytes, **u8)
             radii = torch.empty(N, dtype=torch.int32, device=dev)
-            L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
-                                                 geom.numel(), L.ptr(tiles), tiles.numel(), stream))
-            cnt = L.SfgsRasterCounters()
-            L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))  # the one host sync
-            D = int(cnt.num_duplicates)
+            # The duplicate count D is only known after the plan: plan into a bins blob sized from the
+            # last frames' D (geometric growth), and redo the plan in the rare case it overflowed.
+            cap = max(_cap_hint.get(dev.index, 0), 4 * N, 1024)
+            while True:
+                L.check(lib.sfgs_raster_sizes(N, W, H, cap, L.C.byref(sizes)))
+                geom = torch.empty(max(sizes.geom_bytes, 1), **u8)
+                tiles = torch.empty(sizes.tiles_bytes, **u8)
+                bins = torch.empty(max(sizes.bins_bytes, 1), **u8)
+                L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
+                                                     geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
+                                                     bins.numel(), cap, stream))
+                cnt = L.SfgsRasterCounters()
+                L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))  # the one host sync
+                D = int(cnt.num_duplicates)
+                if not cnt.overflow and D <= cap:
+                    break
+                cap = int(D * 1.25) + 1024
+            _cap_hint[dev.index] = max(int(D * 1.25) + 1024, min(cap, 2 * D + 1024))
             _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
                                   num_visible=int(cnt.num_visible), max_tile_list=int(cnt.max_tile_list),
-                                  N=N, W=W, H=H)
-            L.check(lib.sfgs_raster_sizes(N, W, H, D, L.C.byref(sizes)))
-            bins = torch.empty(max(sizes.bins_bytes, 1), **u8)
+                                  N=N, W=W, H=H, dup_capacity=cap)
             need_bwd = any(ctx.needs_input_grad[:7])
             image = torch.empty(sizes.image_bytes, **u8) if need_bwd else None
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins),
-                                                   bins.numel(), D, L.ptr(color), L.ptr(depth), L.ptr(alpha),
+                                                   bins.numel(), cap, D, L.ptr(color), L.ptr(depth), L.ptr(alpha),
                                                    L.ptr(image), 0 if image is None else image.numel(), stream))
         norm = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(radii, norm)
         if need_bwd:
-            ctx.settings, ctx.D, ctx.sh_coeffs = settings, D, sh_coeffs
+            ctx.settings, ctx.D, ctx.sh_coeffs = settings, cap, sh_coeffs
             ctx.keep = keep
             ctx.has_colors, ctx.has_shs = colors_precomp is not None, shs is not None
             ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, geom, tiles, bins,
