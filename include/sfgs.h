@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 2
+#define SFGS_ABI_VERSION 3
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -63,6 +63,9 @@ typedef struct SfgsFrame {
   int32_t prefiltered;           /* accepted, ignored (reference always passes False)            */
   int32_t debug;                 /* !=0: synchronise + check after every launch                  */
   int32_t depth_mode;            /* SFGS_DEPTH_*                                                 */
+  int32_t tile_row_begin;        /* band rendering (multi-GPU joint render): only 8-pixel  */
+  int32_t tile_row_end;          /* tile rows [begin, end) are binned/composited; end <= 0 = all rows.
+                                    Pixels outside the band are left untouched in the outputs.      */
   const float* subpixel_offset;  /* device [H,W,2] or NULL (= zeros)                             */
   const float* bg;               /* device [3]                                                   */
   const float* viewmatrix;       /* device [16]                                                  */

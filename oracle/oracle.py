@@ -47,6 +47,10 @@ def lib():
         _lib.orc_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p]
         _lib.orc_knn_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _lib.orc_test_cov3d.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        _lib.orc_test_quat_to_R.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_test_sh.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_test_project.argtypes = [C.POINTER(OrcFrame), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -161,4 +165,51 @@ def knn_dist2(xyz):
     a = _f32(xyz)
     out = np.zeros(a.shape[0], np.float32)
     lib().orc_knn_dist2(_ptr(a), a.shape[0], _ptr(out))
+    return out
+
+
+# ---- helper hooks (checked against tests/golden, generated from the reference's own Python) -------------
+def make_frame_struct(frame, sh_coeffs=0, keep=None):
+    k = dict(subpix=_f32(frame.get("subpix")), bg=_f32(frame["bg"]), view=_f32(frame["view"]),
+             proj=_f32(frame["proj"]), campos=_f32(frame["campos"]))
+    if keep is not None:
+        keep.append(k)
+    return OrcFrame(int(frame["H"]), int(frame["W"]), float(frame["tanfovx"]), float(frame["tanfovy"]),
+                    float(frame["kernel_size"]), float(frame.get("scale_modifier", 1.0)),
+                    int(frame.get("sh_degree", 0)), sh_coeffs, int(frame.get("depth_mode", 0)), _ptr(k["subpix"]),
+                    _ptr(k["bg"]), _ptr(k["view"]), _ptr(k["proj"]), _ptr(k["campos"]))
+
+
+def cov3d(scales, modifier, quats):
+    s, q = _f32(scales), _f32(quats)
+    out = np.zeros((s.shape[0], 6), np.float32)
+    for i in range(s.shape[0]):
+        lib().orc_test_cov3d(_ptr(s[i]), float(modifier), _ptr(q[i]), _ptr(out[i]))
+    return out
+
+
+def quat_to_R(quats):
+    q = _f32(quats)
+    out = np.zeros((q.shape[0], 9), np.float32)
+    for i in range(q.shape[0]):
+        lib().orc_test_quat_to_R(_ptr(q[i]), _ptr(out[i]))
+    return out.reshape(-1, 3, 3)
+
+
+def sh_rgb(deg, sh_km3, dirs):
+    """sh_km3 [N,M,3] (coefficient-major, as the rasterizer receives it), dirs [N,3] unit."""
+    sh, d = _f32(sh_km3), _f32(dirs)
+    out = np.zeros((sh.shape[0], 3), np.float32)
+    for i in range(sh.shape[0]):
+        lib().orc_test_sh(int(deg), int(sh.shape[1]), _ptr(sh[i]), _ptr(d[i]), _ptr(out[i]))
+    return out
+
+
+def project(frame, means3D, scales, quats):
+    keep = []
+    fr = make_frame_struct(frame, keep=keep)
+    p, s, q = _f32(means3D), _f32(scales), _f32(quats)
+    out = np.zeros((p.shape[0], 4), np.float32)
+    for i in range(p.shape[0]):
+        lib().orc_test_project(C.byref(fr), _ptr(p[i]), _ptr(s[i]), _ptr(q[i]), _ptr(out[i]))
     return out

@@ -844,3 +844,21 @@ void orc_knn_dist2(const float* xyz, int32_t N, float* out) {
     out[i] = cntv ? sum / (float)cntv : 0.f;
   }
 }
+
+/* ---- test hooks: expose the helpers that the reference's own Python pins (tests/golden) ------------ */
+void orc_test_cov3d(const float* s, float mod, const float* q, float* cov6) { cov3d_from_scale_rot(s, mod, q, cov6); }
+void orc_test_quat_to_R(const float* q, float* R9) { quat_to_R(q, R9); }
+void orc_test_sh(int deg, int M, const float* sh /* [M,3] */, const float* dir /* unit */, float* rgb) {
+  /* sh_to_rgb normalises p - campos: pass campos = 0 and p = dir */
+  const float zero[3] = {0.f, 0.f, 0.f};
+  uint8_t cl[3];
+  sh_to_rgb(deg, M, sh, dir, zero, rgb, cl);
+}
+/* pixel-space mean, depth and radius of one Gaussian: out = {mx, my, depth, radius} */
+void orc_test_project(const OrcFrame* f, const float* p, const float* s, const float* q, float* out4) {
+  OrcGeom g;
+  const int TX = (f->W + TILE - 1) / TILE, TY = (f->H + TILE - 1) / TILE;
+  const float col[3] = {0.f, 0.f, 0.f};
+  preprocess_one(f, TX, TY, p, s, q, 1.0f, col, NULL, &g);
+  out4[0] = g.mx; out4[1] = g.my; out4[2] = g.depth; out4[3] = (float)g.radius;
+}

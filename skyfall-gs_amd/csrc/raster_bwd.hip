@@ -54,7 +54,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
-  if (tx >= TX8 || ty >= TY8) return;
+  if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[wave];
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;

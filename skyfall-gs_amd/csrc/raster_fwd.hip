@@ -93,6 +93,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       rec_out[3 * (size_t)g + 2] = make_float4(r.g, r.b, r.ex, r.ey);
       depth_bits = __float_as_uint(r.depth);
       br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
+      br.y0 = imax(br.y0, kf.band0); br.y1 = imax(br.y0, imin(br.y1, kf.band1));  // band rendering
       thr = alpha_threshold_log2(r.op);
       ntiles = (long long)(br.x1 - br.x0) * (br.y1 - br.y0);
       for (long long c0 = 0; c0 < ntiles; c0 += 64) {
@@ -311,7 +312,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
-  if (tx >= TX8 || ty >= TY8) return;
+  if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   const int W = kf.W, H = kf.H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
   const bool inside = px < W && py < H;

@@ -63,6 +63,7 @@ struct KFrame {
   int W, H;
   float tanfovx, tanfovy, kernel_size, scale_modifier;
   int sh_degree, sh_coeffs, depth_mode;
+  int band0, band1;  // 8-pixel tile rows [band0, band1) that are binned / composited
   const float* view;
   const float* proj;
   const float* campos;
@@ -76,6 +77,9 @@ static inline KFrame make_kframe(const SfgsFrame* f) {
   k.tanfovx = f->tanfovx; k.tanfovy = f->tanfovy;
   k.kernel_size = f->kernel_size; k.scale_modifier = f->scale_modifier;
   k.sh_degree = f->sh_degree; k.sh_coeffs = f->sh_coeffs; k.depth_mode = f->depth_mode;
+  const int ty8 = (f->image_height + TILE_BIN - 1) / TILE_BIN;
+  k.band0 = f->tile_row_end > 0 ? (f->tile_row_begin < 0 ? 0 : f->tile_row_begin) : 0;
+  k.band1 = f->tile_row_end > 0 ? (f->tile_row_end > ty8 ? ty8 : f->tile_row_end) : ty8;
   k.view = f->viewmatrix; k.proj = f->projmatrix; k.campos = f->campos; k.bg = f->bg;
   k.subpix = f->subpixel_offset;
   return k;

@@ -40,6 +40,7 @@ class GaussianRasterizationSettings(NamedTuple):
     prefiltered: bool
     debug: bool
     depth_mode: int = L.DEPTH_NORMALISED  # extension: L.DEPTH_RAW returns sum(T a z)
+    tile_rows: Optional[tuple] = None     # extension: (begin, end) 8-pixel tile rows to render (sfgs.shard)
 
 
 _last_counters = {}
@@ -82,10 +83,11 @@ def _frame(settings, dev, sh_coeffs, keep):
         if t is not None and t.device != dev:
             raise ValueError("all rasterizer inputs must be on the same device")
     keep.extend([sub, bg, view, proj, campos])
+    rows = getattr(settings, "tile_rows", None) or (0, 0)
     return L.SfgsFrame(C_sizeof(L.SfgsFrame), H, W, float(settings.tanfovx), float(settings.tanfovy),
                        float(settings.kernel_size), float(settings.scale_modifier), int(settings.sh_degree),
                        int(sh_coeffs), int(bool(settings.prefiltered)), int(bool(settings.debug)),
-                       int(getattr(settings, "depth_mode", 0)), L.ptr(sub), L.ptr(bg), L.ptr(view), L.ptr(proj),
+                       int(getattr(settings, "depth_mode", 0)), int(rows[0]), int(rows[1]), L.ptr(sub), L.ptr(bg), L.ptr(view), L.ptr(proj),
                        L.ptr(campos))
 
 

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsfgs.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -17,6 +17,7 @@ class SfgsFrame(C.Structure):
                 ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("kernel_size", C.c_float),
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32), ("depth_mode", C.c_int32),
+                ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
                 ("subpixel_offset", C.c_void_p), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 

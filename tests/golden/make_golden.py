@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""Generates tests/golden/reference_helpers.npz by IMPORTING the real reference (read-only, from
+/root/reference) and running its own Python on seeded inputs. The reference cannot travel to the GPU box,
+so the vectors are committed; nothing under tests/ reads /root/reference at run time.
+
+What the reference can pin (its rasterizer is an un-vendored CUDA submodule): every convention
+the rasterizer's inputs/outputs obey --
+  * camera tensors                 scene/cameras.py:56-79 (Camera.__init__), utils/graphics_utils.py:38-126
+  * quaternion -> R, Sigma packing utils/general_utils.py:64-110 (build_rotation, build_scaling_rotation,
+                                   strip_symmetric) as used by scene/gaussian_model.py:75-79
+  * SH -> RGB                      utils/sh_utils.py:57-112 (eval_sh) + the +0.5 / clamp of
+                                   gaussian_renderer/__init__.py:116-117
+  * pixel / focal convention       scene/gaussian_model.py:279-286 (projection used by compute_3D_filter)
+  * SSIM forward + autograd grad   utils/loss_utils.py:23-63
+The reference hard-codes device="cuda"; this script redirects those allocations to the CPU (monkey-patch
+below) -- the arithmetic executed is the reference's own.
+
+usage: python tests/golden/make_golden.py   (only in the authoring container)
+"""
+import importlib.util
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cpu_redirect():
+    for name in ("zeros", "ones", "empty", "tensor", "eye"):
+        orig = getattr(torch, name)
+
+        def wrapped(*a, __orig=orig, **k):
+            if str(k.get("device", "")).startswith("cuda"):
+                k["device"] = "cpu"
+            return __orig(*a, **k)
+        setattr(torch, name, wrapped)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    _cpu_redirect()
+    sys.path.insert(0, REF)
+    from utils import general_utils as gu
+    from utils import graphics_utils as gfx  # noqa: F401  (imported by scene/cameras.py)
+    from utils.loss_utils import ssim
+    from utils.sh_utils import eval_sh
+    cameras = _load(os.path.join(REF, "scene", "cameras.py"), "ref_cameras")  # avoids scene/__init__'s heavy imports
+
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+
+    # ---- cameras --------------------------------------------------------------------------------------
+    cams = []
+    for i in range(6):
+        q = torch.randn(4, generator=g, dtype=torch.float64)
+        q = q / q.norm()
+        w, x, y, z = q.tolist()
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        T = (torch.randn(3, generator=g, dtype=torch.float64) * 3).numpy()
+        W, H = [(800, 800), (1920, 1080), (1024, 1024), (130, 77), (960, 540), (2560, 1440)][i]
+        fovx = math.radians([60.0, 60.0, 20.0, 45.0, 20.0, 33.0][i])
+        fovy = 2 * math.atan(H / (2 * (W / (2 * math.tan(fovx / 2)))))
+        cx, cy = [(0.0, 0.0), (0.0, 0.0), (0.01, -0.02), (0.1, 0.05), (0.0, 0.0), (-0.03, 0.04)][i]
+        cam = cameras.Camera(colmap_id=i, R=R, T=T, FoVx=fovx, FoVy=fovy, cx=cx, cy=cy,
+                             image=torch.zeros(3, H, W), gt_alpha_mask=None, image_name=str(i), uid=i,
+                             data_device="cpu")
+        cams.append(dict(R=R, T=T, W=W, H=H, fovx=fovx, fovy=fovy, cx=cx, cy=cy,
+                         view=cam.world_view_transform.numpy(), proj=cam.projection_matrix.numpy(),
+                         full=cam.full_proj_transform.numpy(), center=cam.camera_center.numpy(),
+                         focal_x=cam.focal_x, focal_y=cam.focal_y))
+    for k in cams[0]:
+        out["cam_" + k] = np.stack([np.asarray(c[k]) for c in cams])
+
+    # ---- pixel convention: the reference's Python projection (gaussian_model.py:279-286) -------------------
+    c = cams[3]
+    pts = torch.randn(64, 3, generator=g, dtype=torch.float64) * 2 + torch.tensor([0.0, 0.0, 6.0], dtype=torch.float64)
+    Rt = torch.tensor(c["R"], dtype=torch.float64)
+    Tt = torch.tensor(c["T"], dtype=torch.float64)
+    world = (pts - Tt[None]) @ Rt.T          # so that world @ R + T == pts (camera space)
+    xyz_cam = world @ Rt + Tt[None]
+    x, y, z = xyz_cam[:, 0], xyz_cam[:, 1], xyz_cam[:, 2].clamp(min=0.001)
+    cx_ori = c["cx"] / 2 * c["W"] + c["W"] / 2
+    cy_ori = c["cy"] / 2 * c["H"] + c["H"] / 2
+    out["pix_world"] = world.numpy()
+    out["pix_x"] = (x / z * c["focal_x"] + cx_ori).numpy()
+    out["pix_y"] = (y / z * c["focal_y"] + cy_ori).numpy()
+    out["pix_z"] = xyz_cam[:, 2].numpy()
+
+    # ---- rotation / covariance ------------------------------------------------------------------------------
+    quats = torch.randn(256, 4, generator=g)
+    scales = torch.exp(torch.randn(256, 3, generator=g))
+    L = gu.build_scaling_rotation(1.7 * scales, quats)           # scene/gaussian_model.py:75-79 with modifier 1.7
+    cov = gu.strip_symmetric(L @ L.transpose(1, 2))
+    out["rot_quats"] = quats.numpy()
+    out["rot_R"] = gu.build_rotation(quats).numpy()
+    out["cov_scales"] = scales.numpy()
+    out["cov_modifier"] = np.float32(1.7)
+    out["cov_packed"] = cov.numpy()
+
+    # ---- spherical harmonics -----------------------------------------------------------------------------------
+    sh = torch.randn(200, 3, 16, generator=g)
+    dirs = torch.randn(200, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    out["sh_coeffs"] = sh.numpy()
+    out["sh_dirs"] = dirs.numpy()
+    for deg in range(4):
+        K = (deg + 1) ** 2
+        rgb = eval_sh(deg, sh[:, :, :K], dirs)
+        out[f"sh_rgb_deg{deg}"] = torch.clamp_min(rgb + 0.5, 0.0).numpy()
+
+    # ---- SSIM ----------------------------------------------------------------------------------------------------
+    for tag, (B, C, H, W) in {"a": (1, 3, 37, 53), "b": (2, 1, 16, 11), "c": (1, 3, 64, 96)}.items():
+        img1 = torch.rand(B, C, H, W, generator=g).requires_grad_(True)
+        img2 = (img1.detach() + 0.1 * torch.randn(B, C, H, W, generator=g)).clamp(0, 1)
+        val = ssim(img1, img2)
+        val.backward()
+        out[f"ssim_{tag}_img1"] = img1.detach().numpy()
+        out[f"ssim_{tag}_img2"] = img2.numpy()
+        out[f"ssim_{tag}_value"] = np.float64(val.item())
+        out[f"ssim_{tag}_grad"] = img1.grad.numpy()
+
+    path = os.path.join(HERE, "reference_helpers.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

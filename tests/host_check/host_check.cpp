@@ -158,3 +158,25 @@ int hc_render(const HcFrame* hf, int32_t N, const float* means, const float* sca
 }
 
 }  // extern "C"
+
+// ---- test hooks on the product header's helpers (same signatures as the oracle's orc_test_*) -------------
+extern "C" {
+void hc_cov3d(const float* s, float mod, const float* q, float* cov6) { cov3d_of(s, mod, q, cov6); }
+void hc_quat_to_R(const float* q, float* R9) { quat_to_rot(q, R9); }
+void hc_sh(int deg, int M, const float* sh, const float* dir, float* rgb) {
+  (void)M;
+  const float zero[3] = {0.f, 0.f, 0.f};
+  unsigned mask; float d[3], len;
+  sh_to_rgb(deg, sh, dir, zero, rgb, &mask, d, &len);
+}
+void hc_project(const HcFrame* hf, const float* p, const float* s, const float* q, float* out4) {
+  FrameParams f;
+  f.W = hf->W; f.H = hf->H; f.tanfovx = hf->tanfovx; f.tanfovy = hf->tanfovy;
+  f.kernel_size = hf->kernel_size; f.scale_modifier = hf->scale_modifier;
+  f.sh_degree = hf->sh_degree; f.sh_coeffs = hf->sh_coeffs; f.depth_mode = hf->depth_mode;
+  for (int i = 0; i < 16; ++i) { f.view[i] = hf->view[i]; f.proj[i] = hf->proj[i]; }
+  for (int i = 0; i < 3; ++i) { f.campos[i] = hf->campos[i]; f.bg[i] = hf->bg[i]; }
+  const Projected pr = project_gaussian(f, p, s, q);
+  out4[0] = pr.visible ? pr.mx : 0.f; out4[1] = pr.visible ? pr.my : 0.f; out4[2] = pr.tz; out4[3] = (float)pr.radius;
+}
+}

@@ -31,6 +31,10 @@ def lib():
         _lib = C.CDLL(_OUT)
         _lib.hc_render.restype = C.c_int
         _lib.hc_render.argtypes = [C.POINTER(HcFrame), C.c_int32] + [C.c_void_p] * 22
+        _lib.hc_cov3d.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        _lib.hc_quat_to_R.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.hc_sh.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.hc_project.argtypes = [C.POINTER(HcFrame), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -79,4 +83,48 @@ def render(frame, means3D, scales, rotations, opacities, colors_precomp=None, sh
                      _p(out["counters"]))
     assert rc == 0
     out["grads"] = g
+    return out
+
+
+def _frame_struct(frame, keep):
+    k = dict(subpix=_f32(frame.get("subpix")), bg=_f32(frame["bg"]), view=_f32(frame["view"]),
+             proj=_f32(frame["proj"]), campos=_f32(frame["campos"]))
+    keep.append(k)
+    return HcFrame(int(frame["W"]), int(frame["H"]), float(frame["tanfovx"]), float(frame["tanfovy"]),
+                   float(frame["kernel_size"]), float(frame.get("scale_modifier", 1.0)), int(frame.get("sh_degree", 0)),
+                   0, int(frame.get("depth_mode", 0)), _p(k["subpix"]), _p(k["bg"]), _p(k["view"]), _p(k["proj"]),
+                   _p(k["campos"]))
+
+
+def cov3d(scales, modifier, quats):
+    s, q = _f32(scales), _f32(quats)
+    out = np.zeros((s.shape[0], 6), np.float32)
+    for i in range(s.shape[0]):
+        lib().hc_cov3d(_p(s[i]), float(modifier), _p(q[i]), _p(out[i]))
+    return out
+
+
+def quat_to_R(quats):
+    q = _f32(quats)
+    out = np.zeros((q.shape[0], 9), np.float32)
+    for i in range(q.shape[0]):
+        lib().hc_quat_to_R(_p(q[i]), _p(out[i]))
+    return out.reshape(-1, 3, 3)
+
+
+def sh_rgb(deg, sh_km3, dirs):
+    sh, d = _f32(sh_km3), _f32(dirs)
+    out = np.zeros((sh.shape[0], 3), np.float32)
+    for i in range(sh.shape[0]):
+        lib().hc_sh(int(deg), int(sh.shape[1]), _p(sh[i]), _p(d[i]), _p(out[i]))
+    return out
+
+
+def project(frame, means3D, scales, quats):
+    keep = []
+    fr = _frame_struct(frame, keep)
+    p, s, q = _f32(means3D), _f32(scales), _f32(quats)
+    out = np.zeros((p.shape[0], 4), np.float32)
+    for i in range(p.shape[0]):
+        lib().hc_project(C.byref(fr), _p(p[i]), _p(s[i]), _p(q[i]), _p(out[i]))
     return out

@@ -1,0 +1,139 @@
+"""CPU tests of the product's host-side logic and of its math header (compiled by g++ into tests/host_check):
+projection / radii / opacity-aware binning / sort order / per-pixel compositing / chain rule against the
+oracle, plus the C-ABI contract (symbols, struct layouts, GPU-free entry points). No GPU needed."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import hostcheck
+import parity
+from oracle import oracle as orc
+from sfgs import _lib as L
+from sfgs.synth import scene, upstream_grads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "precomp": dict(n=3000, W=200, H=120, kw=dict(zrange=(4., 8.), scale_range=(0.01, 0.2))),
+    "sh3_jitter": dict(n=8000, W=256, H=160, kw=dict(zrange=(250., 350.), scale_range=(0.2, 3.0), mode="sh",
+                                                      sh_degree=3, jitter=True)),
+    "ragged_big": dict(n=1500, W=130, H=77, kw=dict(zrange=(2., 50.), scale_range=(0.01, 2.0), mode="sh", sh_degree=1)),
+    "low_elevation": dict(n=6000, W=240, H=136, kw=dict(zrange=(20., 400.), scale_range=(0.05, 2.0), pitch_deg=45.0)),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_product_math_matches_oracle(case):
+    c = CASES[case]
+    frame, g = scene(c["n"], c["W"], c["H"], seed=1, **c["kw"])
+    R = orc.OracleRender(frame, **g)
+    gc, gd = upstream_grads(c["W"], c["H"], 0)
+    gd = gd.clone()
+    gd[torch.from_numpy(np.isnan(R.depth))] = 0
+    G = R.backward(gc, gd)
+    o = hostcheck.render(frame, g["means3D"], g["scales"], g["rotations"], g["opacities"], g["colors_precomp"],
+                         g["shs"], gc, gd, None, backward=True)
+    np.testing.assert_array_equal(o["radii"], R.radii)                      # integers: bit-exact
+    assert int(o["counters"][1]) == R.num_duplicates                        # the reference's tiles_touched total
+    assert int(o["counters"][2]) == R.num_visible
+    # the opacity-aware 8x8 binning must never drop a contributor: images agree to float round-off
+    for name in ("color", "alpha", "depth"):
+        parity.assert_image_close(name, o[name], getattr(R, name))
+    for k in G:
+        parity.assert_grad_close(k, o["grads"][k], G[k])
+
+
+def test_raw_depth_mode_and_background():
+    frame, g = scene(2000, 160, 96, seed=4, zrange=(4., 8.), scale_range=(0.01, 0.2))
+    frame["depth_mode"] = 1
+    frame["bg"] = torch.tensor([0.2, 0.5, 0.9])
+    R = orc.OracleRender(frame, **g)
+    o = hostcheck.render(frame, g["means3D"], g["scales"], g["rotations"], g["opacities"], g["colors_precomp"], None)
+    for name in ("color", "alpha", "depth"):
+        parity.assert_image_close(name, o[name], getattr(R, name))
+    assert np.isfinite(o["depth"]).all()
+
+
+def test_binning_is_tighter_than_reference_rule_where_it_can_be():
+    """low-opacity splats reach alpha >= 1/255 on a smaller area than the 3-sigma square: D_eff counts
+    8x8 tiles, D_ref 16x16 tiles; per unit of covered area the binning must not exceed the reference's."""
+    frame, g = scene(20000, 320, 200, seed=2, zrange=(250., 350.), scale_range=(0.2, 3.0), opacity_range=(0.01, 0.05))
+    o = hostcheck.render(frame, g["means3D"], g["scales"], g["rotations"], g["opacities"], g["colors_precomp"], None)
+    d_eff, d_ref = int(o["counters"][0]), int(o["counters"][1])
+    assert d_eff * 64 < d_ref * 256  # pixel area binned < pixel area the reference would composite
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sfgs.h")).read()
+    declared = set(re.findall(r"\b(sfgs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    lib = L.load()  # binds every symbol, checks the ABI version
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.sfgs_abi_version() == L.ABI_VERSION
+
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    src = tmp_path / "layout.c"
+    names = ["SfgsFrame", "SfgsGaussians", "SfgsGaussianGrads", "SfgsRasterSizes", "SfgsRasterCounters"]
+    body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
+    offs = "\n".join(f'  printf("SfgsFrame.{f} %zu\\n", offsetof(SfgsFrame, {f}));' for f, _ in L.SfgsFrame._fields_)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "sfgs.h"\nint main(void) {{\n{body}\n{offs}\n  return 0;\n}}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for n in names:
+        assert int(out[n]) == C.sizeof(getattr(L, n)), n
+    for f, _ in L.SfgsFrame._fields_:
+        assert int(out[f"SfgsFrame.{f}"]) == getattr(L.SfgsFrame, f).offset, f
+
+
+def test_gpu_free_entry_points_and_error_convention():
+    lib = L.load()
+    sizes = L.SfgsRasterSizes(C.sizeof(L.SfgsRasterSizes))
+    assert lib.sfgs_raster_sizes(2_000_000, 1920, 1080, 7_000_000, C.byref(sizes)) == 0
+    assert sizes.geom_bytes >= 2_000_000 * 56 and sizes.bins_bytes >= 7_000_000 * 40
+    assert sizes.dupgrad_bytes == 7_000_000 * 64 and sizes.image_bytes >= 1920 * 1080 * 12
+    # errors: negative status + thread-local message, never an exception or exit
+    bad = L.SfgsRasterSizes(4)
+    assert lib.sfgs_raster_sizes(10, 64, 64, 0, C.byref(bad)) == -1
+    assert b"struct_size" in lib.sfgs_last_error()
+    assert lib.sfgs_raster_sizes(-1, 64, 64, 0, C.byref(sizes)) == -1
+    assert lib.sfgs_raster_sizes(10, 64, 64, 1 << 33, C.byref(sizes)) == -4  # > 2^32 duplicates unsupported
+    with pytest.raises(RuntimeError, match="libsfgs error"):
+        L.check(lib.sfgs_raster_sizes(-1, 64, 64, 0, C.byref(sizes)))
+    # a NULL frame is rejected before any HIP call
+    assert lib.sfgs_raster_forward_plan(None, None, None, None, 0, None, 0, None, 0, 0, None) == -1
+    assert lib.sfgs_ssim_scratch_bytes(1, 3, 1080, 1920, 1) > 3 * 3 * 1080 * 1920 * 4
+    assert lib.sfgs_knn_scratch_bytes(1000) == 0
+    assert lib.sfgs_profile_kernel_count() >= 10 and lib.sfgs_profile_kernel_name(1) == b"preprocess"
+
+
+def test_operator_argument_validation_without_gpu():
+    from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+    from fused_ssim import fused_ssim
+    from simple_knn._C import distCUDA2
+    frame, g = scene(8, 32, 32, seed=0)
+    s = GaussianRasterizationSettings(32, 32, frame["tanfovx"], frame["tanfovy"], 0.1, None, frame["bg"], 1.0,
+                                      frame["view"], frame["proj"], 0, frame["campos"], False, False)
+    assert s._fields[:14] == ("image_height", "image_width", "tanfovx", "tanfovy", "kernel_size", "subpixel_offset",
+                              "bg", "scale_modifier", "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered",
+                              "debug")  # field order of gaussian_renderer/__init__.py:40-55
+    r = GaussianRasterizer(raster_settings=s)
+    with pytest.raises(ValueError, match="exactly one"):
+        r(means3D=g["means3D"], means2D=None, opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"])
+    with pytest.raises(ValueError, match="cov3Ds_precomp"):
+        r(means3D=g["means3D"], means2D=None, opacities=g["opacities"], colors_precomp=g["colors_precomp"],
+          scales=g["scales"], rotations=g["rotations"], cov3Ds_precomp=torch.zeros(8, 6))
+    with pytest.raises(ValueError, match="GPU"):  # no CPU fallback, by design
+        r(means3D=g["means3D"], means2D=None, opacities=g["opacities"], colors_precomp=g["colors_precomp"],
+          scales=g["scales"], rotations=g["rotations"])
+    with pytest.raises(ValueError):
+        fused_ssim(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8))
+    with pytest.raises(ValueError):
+        distCUDA2(torch.zeros(10, 3))
