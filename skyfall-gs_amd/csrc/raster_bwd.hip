@@ -247,7 +247,7 @@ using namespace sfgs;
 // entries per backward batch: 16 (11 KB LDS per wave, 3 workgroups per CU) or 32. Tuning knob for
 // experiments only (SFGS_BWD_BATCH=32); the default is what bench.py measures.
 static int bwd_batch() {
-  static const int v = [] { const char* e = getenv("SFGS_BWD_BATCH"); return (e && atoi(e) == 32) ? 32 : 16; }();
+  static const int v = [] { const char* e = getenv("SFGS_BWD_BATCH"); const int b = e ? atoi(e) : 16; return (b == 32 || b == 8) ? b : 16; }();
   return v;
 }
 
@@ -279,7 +279,12 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
-  if (bwd_batch() == 32)
+  if (bwd_batch() == 8)
+  { ProfScope ps_(KID_COMPOSITE_BWD, stream);
+    hipLaunchKernelGGL(composite_bwd_kernel<8>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+                       bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
+                       dL_dalpha, (float4*)dupgrad); }
+  else if (bwd_batch() == 32)
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd_kernel<32>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
