@@ -37,11 +37,35 @@ struct BwdLds {
   float U[B * ROW];
   float Wm[B * ROW];
   float4 recs[B * 3];
-  float4 pix[64 * 2];  // per pixel: (sx, sy, g0, g1), (g2, g3, -, -)
 };
 
+// value of lane I of the caller's 16-lane row, broadcast to the whole row (DPP row_newbcast; folds into
+// the consuming VALU instruction). Phase 2 uses it to read per-PIXEL registers (sample position, upstream
+// gradients) from per-ENTRY lanes: lane (entry, quarter q) needs pixel 16 q + I = lane I of row q.
+template <int I>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xf, 0xf, false));
+}
+
+struct Phase2Acc {
+  float u, x, y, ax, ay, xx, xy, yy, r, g, b, d;
+};
+
+template <int I>
+__device__ __forceinline__ void phase2_step(Phase2Acc& a, float u, float w, float mx, float my, float cA, float cB,
+                                            float cC, float sx, float sy, float g0, float g1, float g2, float g3) {
+  const float dx = mx - row_bcast<I>(sx), dy = my - row_bcast<I>(sy);
+  const float udx = u * dx, udy = u * dy;
+  a.u += u; a.x += udx; a.y += udy;
+  a.ax += fabsf(u * fmaf(cA, dx, cB * dy));
+  a.ay += fabsf(u * fmaf(cC, dy, cB * dx));
+  a.xx = fmaf(udx, dx, a.xx); a.xy = fmaf(udx, dy, a.xy); a.yy = fmaf(udy, dy, a.yy);
+  a.r = fmaf(w, row_bcast<I>(g0), a.r); a.g = fmaf(w, row_bcast<I>(g1), a.g);
+  a.b = fmaf(w, row_bcast<I>(g2), a.b); a.d = fmaf(w, row_bcast<I>(g3), a.d);
+}
+
 template <int B>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)  // 4 waves/SIMD: <= 128 VGPRs, 4 workgroups (36 KB LDS each) per CU
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32_t* __restrict__ tile_start,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
@@ -49,7 +73,6 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, float4* __restrict__ dupgrad) {
   constexpr int ROW = BwdLds<B>::ROW;
-  constexpr int NGRP = 64 / B;  // lanes per entry in phase 2; each owns B pixels
   __shared__ BwdLds<B> lds_all[4];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -83,8 +106,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
     const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
     pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
   }
-  lds.pix[lane * 2] = make_float4(sx, sy, ps.gch[0], ps.gch[1]);
-  lds.pix[lane * 2 + 1] = make_float4(ps.gch[2], ps.gch[3], 0.f, 0.f);
+  static_assert(B == 16, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 rows");
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
   unsigned kmax = last;
@@ -128,32 +150,24 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
-    float a_u = 0.f, a_x = 0.f, a_y = 0.f, a_ax = 0.f, a_ay = 0.f, a_xx = 0.f, a_xy = 0.f, a_yy = 0.f;
-    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
-    float op = 0.f, cA = 0.f, cB = 0.f, cC = 0.f;
-    if ((unsigned)ej < cnt) {
+    // Every lane runs the 16 steps (a DPP source lane must be active); lanes of entries beyond cnt read
+    // stale U/Wm rows and their sums are discarded below.
+    Phase2Acc pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float op, cA, cB, cC;
+    {
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
       const float mx = r0.x, my = r0.y;
       cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x; op = r1.y;
       const float* Urow = &lds.U[ej * ROW + grp * B];
       const float* Wrow = &lds.Wm[ej * ROW + grp * B];
-      const float4* ptab = &lds.pix[(grp * B) * 2];
-#pragma unroll 4
-      for (int i = 0; i < B; ++i) {
-        const float u = Urow[i], w = Wrow[i];
-        const float4 p0 = ptab[i * 2];
-        const float2 p1 = *reinterpret_cast<const float2*>(&ptab[i * 2 + 1]);
-        const float dx = mx - p0.x, dy = my - p0.y;
-        const float udx = u * dx, udy = u * dy;
-        a_u += u; a_x += udx; a_y += udy;
-        a_ax += fabsf(u * fmaf(cA, dx, cB * dy));
-        a_ay += fabsf(u * fmaf(cC, dy, cB * dx));
-        a_xx = fmaf(udx, dx, a_xx); a_xy = fmaf(udx, dy, a_xy); a_yy = fmaf(udy, dy, a_yy);
-        a_r = fmaf(w, p0.z, a_r); a_g = fmaf(w, p0.w, a_g); a_b = fmaf(w, p1.x, a_b); a_d = fmaf(w, p1.y, a_d);
-      }
+      const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
+#define SFGS_P2(I) phase2_step<I>(pa, Urow[I], Wrow[I], mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
+      SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7);
+      SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15);
+#undef SFGS_P2
     }
     // combine the NGRP partial lanes of every entry (fixed order -> deterministic)
-    float acc[12] = {a_u, a_x, a_y, a_ax, a_ay, a_xx, a_xy, a_yy, a_r, a_g, a_b, a_d};
+    float acc[12] = {pa.u, pa.x, pa.y, pa.ax, pa.ay, pa.xx, pa.xy, pa.yy, pa.r, pa.g, pa.b, pa.d};
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
 #pragma unroll
@@ -244,13 +258,6 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
 
 using namespace sfgs;
 
-// entries per backward batch: 16 (11 KB LDS per wave, 3 workgroups per CU) or 32. Tuning knob for
-// experiments only (SFGS_BWD_BATCH=32); the default is what bench.py measures.
-static int bwd_batch() {
-  static const int v = [] { const char* e = getenv("SFGS_BWD_BATCH"); const int b = e ? atoi(e) : 16; return (b == 32 || b == 8) ? b : 16; }();
-  return v;
-}
-
 extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                                     const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
                                     const void* image, const float* dL_dcolor, const float* dL_ddepth,
@@ -279,17 +286,6 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
-  if (bwd_batch() == 8)
-  { ProfScope ps_(KID_COMPOSITE_BWD, stream);
-    hipLaunchKernelGGL(composite_bwd_kernel<8>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
-                       bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, (float4*)dupgrad); }
-  else if (bwd_batch() == 32)
-  { ProfScope ps_(KID_COMPOSITE_BWD, stream);
-    hipLaunchKernelGGL(composite_bwd_kernel<32>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
-                       bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, (float4*)dupgrad); }
-  else
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,

@@ -11,6 +11,8 @@
 //            -> composite (one wave per 8x8 tile, front to back, records staged through LDS)
 //
 // Compile with -ffp-contract=off: integer outputs depend on exact float32 sequences (raster_math.h).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "sfgs_internal.h"
@@ -53,7 +55,7 @@ __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
                   const float* __restrict__ colors, const float* __restrict__ shs, int* __restrict__ radii,
-                  float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ tile_count,
+                  float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ tile_count8, int T8,
                   uint4* __restrict__ staging, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
                   unsigned long long* __restrict__ hdr) {
@@ -116,6 +118,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     // `mask` from the counting pass -- for all but very large splats)
     const unsigned long long first = base + ex;
     const int nx = br.x1 - br.x0;
+    const unsigned xcd = xcc_id();
+    uint32_t* __restrict__ my_count = tile_count8 + (size_t)xcd * T8;  // this XCD's private counters
     unsigned j = 0;
     for (long long c0 = 0; c0 < ntiles; c0 += 64) {
       unsigned long long m = ntiles <= 64 ? mask : chunk_hits(r, thr, br, c0, ntiles, f.W, f.H, bound);
@@ -124,8 +128,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         m &= m - 1;
         const long long idx = c0 + bit;
         const int t = (br.y0 + (int)(idx / nx)) * TX8 + br.x0 + (int)(idx % nx);
-        const unsigned rank = atomicAdd(&tile_count[t], 1u);
-        staging[first + j] = make_uint4((unsigned)g, depth_bits, (unsigned)t, rank);
+        const unsigned rank = atomicAdd(&my_count[t], 1u);  // rank among THIS XCD's duplicates of tile t
+        staging[first + j] = make_uint4((unsigned)g, depth_bits, (unsigned)t | (xcd << 29), rank);
         ++j;
       }
     }
@@ -138,35 +142,46 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: single workgroup. Exclusive scan of tile_count -> tile_start, plus the counters the host reads.
+// K2: tile scan in three small launches (SCAN_BLOCK tiles per workgroup):
+//   tile_sums   : per tile, total over the 8 XCD-private counters; per-workgroup totals -> scan_part
+//   plan_scan   : one workgroup: exclusive scan of scan_part, counters for the host (also sums block stats)
+//   plan_finish : per tile, tile_start = base + in-workgroup exclusive scan; start8[x][t] = running offset
+//                 of XCD x's duplicates inside the tile's segment
+__global__ void __launch_bounds__(SCAN_BLOCK)
+tile_sums_kernel(int T8, const uint32_t* __restrict__ tile_count8, uint32_t* __restrict__ scan_part,
+                 unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_red[SCAN_BLOCK / 64 + 1];
+  const int t = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  unsigned v = 0;
+  if (t < T8) {
+#pragma unroll
+    for (int x = 0; x < NXCD; ++x) v += tile_count8[(size_t)x * T8 + t];
+  }
+  unsigned total;
+  block_excl_scan_u32<SCAN_BLOCK>(v, &total, s_red);
+  if (threadIdx.x == 0) scan_part[blockIdx.x] = total;
+  // longest list
+  unsigned m = v;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+  if (lane_id() == 0 && m) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], m);
+}
+
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
-plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
-                 const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
-                 unsigned long long* __restrict__ hdr) {
+plan_scan_kernel(int NS, int NB, uint32_t* __restrict__ scan_part, const uint32_t* __restrict__ block_nvis,
+                 const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[SCAN_NT / 64 + 1];
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
-  unsigned carry = 0, maxlen = 0;
-  for (int base = 0; base < T8; base += SCAN_NT) {
+  unsigned carry = 0;
+  for (int base = 0; base < NS; base += SCAN_NT) {
     const int i = base + threadIdx.x;
-    const unsigned v = i < T8 ? tile_count[i] : 0u;
-    maxlen = max(maxlen, v);
+    const unsigned v = i < NS ? scan_part[i] : 0u;
     unsigned total;
     const unsigned ex = block_excl_scan_u32<SCAN_NT>(v, &total, s_red);
-    if (i < T8) tile_start[i] = carry + ex;
+    if (i < NS) scan_part[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) tile_start[T8] = carry;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (unsigned)__shfl_xor((int)maxlen, d));
-  if (lane_id() == 0) s_red[threadIdx.x >> 6] = maxlen;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned m = 0;
-    for (int w = 0; w < SCAN_NT / 64; ++w) m = max(m, s_red[w]);
-    hdr[HDR_MAX_LIST] = m;
-  }
-  __syncthreads();
   unsigned long long nvis = 0, dref = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
   for (int pass = 0; pass < 2; ++pass) {
@@ -184,16 +199,36 @@ plan_scan_kernel(int T8, int NB, const uint32_t* __restrict__ tile_count, uint32
   }
 }
 
+__global__ void __launch_bounds__(SCAN_BLOCK)
+plan_finish_kernel(int T8, const uint32_t* __restrict__ tile_count8, const uint32_t* __restrict__ scan_part,
+                   uint32_t* __restrict__ tile_start, uint32_t* __restrict__ start8) {
+  __shared__ unsigned s_red[SCAN_BLOCK / 64 + 1];
+  const int t = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  unsigned c[NXCD], v = 0;
+#pragma unroll
+  for (int x = 0; x < NXCD; ++x) { c[x] = t < T8 ? tile_count8[(size_t)x * T8 + t] : 0u; v += c[x]; }
+  unsigned total;
+  const unsigned start = scan_part[blockIdx.x] + block_excl_scan_u32<SCAN_BLOCK>(v, &total, s_red);
+  if (t < T8) {
+    tile_start[t] = start;
+    unsigned run = start;
+#pragma unroll
+    for (int x = 0; x < NXCD; ++x) { start8[(size_t)x * T8 + t] = run; run += c[x]; }
+    if (t == T8 - 1) tile_start[T8] = start + v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: permutation of the staged duplicates into per-tile segments (one thread per duplicate; coalesced
 // 16-byte reads, one 16-byte scattered store each; no atomics, no tests).
 __global__ void __launch_bounds__(256)
-permute_kernel(unsigned D, const uint4* __restrict__ staging, const uint32_t* __restrict__ tile_start,
+permute_kernel(unsigned D, int T8, const uint4* __restrict__ staging, const uint32_t* __restrict__ start8,
                uint4* __restrict__ items) {
   const unsigned d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
   const uint4 it = staging[d];
-  items[tile_start[it.z] + it.w] = make_uint4(it.x, it.y, d, 0u);
+  const unsigned t = it.z & 0x1fffffffu, x = it.z >> 29;
+  items[start8[(size_t)x * T8 + t] + it.w] = make_uint4(it.x, it.y, d, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,13 +474,18 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
       hipLaunchKernelGGL(preprocess_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
-                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.tile_count,
+                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.tile_count8, T8,
                          bv.staging, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref, tv.hdr); }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }
+  const int NS = (T8 + SCAN_BLOCK - 1) / SCAN_BLOCK;
   { ProfScope ps_(KID_PLAN_SCAN, stream);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, T8, NB, tv.tile_count, tv.tile_start,
-                       tv.block_nvis, tv.block_dref, tv.hdr); }
+    hipLaunchKernelGGL(tile_sums_kernel, dim3(NS), dim3(SCAN_BLOCK), 0, stream, T8, tv.tile_count8, tv.scan_part,
+                       tv.hdr);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, NS, NB, tv.scan_part, tv.block_nvis,
+                       tv.block_dref, tv.hdr);
+    hipLaunchKernelGGL(plan_finish_kernel, dim3(NS), dim3(SCAN_BLOCK), 0, stream, T8, tv.tile_count8, tv.scan_part,
+                       tv.tile_start, tv.start8); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;
 }
@@ -490,7 +530,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   if (num_duplicates > 0) {
     const unsigned D = (unsigned)num_duplicates;
     { ProfScope ps_(KID_PERMUTE, stream);
-      hipLaunchKernelGGL(permute_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, D, bv.staging, tv.tile_start,
+      hipLaunchKernelGGL(permute_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, D, T8, bv.staging, tv.start8,
                          bv.items); }
     SFGS_POST_LAUNCH("permute", stream, frame->debug);
     { ProfScope ps_(KID_SORT_SMALL, stream);

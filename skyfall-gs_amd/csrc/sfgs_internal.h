@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 
 // ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
 enum KernelId {
-  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_PERMUTE, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
+  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_PLAN_FINISH, KID_PERMUTE, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
   KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN,
   KID_COUNT
 };
@@ -124,10 +124,16 @@ static inline GeomView geom_view(void* base, int64_t N) {
   return g;
 }
 
+constexpr int NXCD = 8;             // MI355X: 8 XCDs, each with a private L2
+constexpr int SCAN_BLOCK = 256;     // tiles per workgroup of the tile-scan kernels
+
 struct TilesView {
   unsigned long long* hdr;  // [HDR_WORDS]
-  uint32_t* tile_count;     // [T8]   (zeroed by plan)
+  uint32_t* tile_count8;    // [NXCD][T8] per-XCD tile counters (zeroed by plan): an XCD only ever touches its
+                            //            own copy, so the lines never bounce between the non-coherent L2s
   uint32_t* tile_start;     // [T8+1]
+  uint32_t* start8;         // [NXCD][T8] first slot of XCD x's duplicates inside tile t's segment
+  uint32_t* scan_part;      // [ceil(T8/SCAN_BLOCK)] per-workgroup totals -> exclusive bases
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
@@ -138,13 +144,15 @@ static inline int64_t tiles8(int W, int H) {
 static inline int64_t pre_blocks(int64_t N) { return (N + PRE_BLOCK - 1) / PRE_BLOCK; }
 static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* total) {
   TilesView t;
-  const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1;
+  const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1, NS = (T8 + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
   char* p = (char*)base;
   size_t off = 0;
   t.hdr = (unsigned long long*)(p + off); off += HDR_WORDS * 8;
-  t.tile_count = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
+  t.tile_count8 = (uint32_t*)(p + off); off += align_up((size_t)NXCD * T8 * 4, 256);
   t.zero_bytes = off;
   t.tile_start = (uint32_t*)(p + off); off += align_up((size_t)(T8 + 1) * 4, 256);
+  t.start8 = (uint32_t*)(p + off); off += align_up((size_t)NXCD * T8 * 4, 256);
+  t.scan_part = (uint32_t*)(p + off); off += align_up((size_t)NS * 4, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
   if (total) *total = off;
@@ -199,6 +207,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
 
 // ---- small wave / block primitives ---------------------------------------------------------------
 __device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
+
+// id (0..7) of the XCD this wave runs on: s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4). A hardware fact, not a
+// dispatch-order assumption: used to pick the XCD-private counter copy.
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (NXCD - 1); }
 
 __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
   const unsigned lane = lane_id();
