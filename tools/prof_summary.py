@@ -29,6 +29,9 @@ def kernel_stats(path):
     print()
 
 
+TRAFFIC = {}
+
+
 def pmc_stats(path):
     cur = sqlite3.connect(path).cursor()
     rows = cur.execute("select name, counter_name, count(*), avg(counter_value), avg(duration) from pmc_events "
@@ -40,11 +43,18 @@ def pmc_stats(path):
         b = v * 1024 if is_sz else float("nan")
         corr = 2 * b if cn == "FETCH_SIZE" else b
         print(f"{short(n):44s} {cn:12s} {c:6d} {v:14.1f} {b:14.0f} {corr:14.0f} {d/1e3:9.2f}")
+        if is_sz and "sfgs" in n:
+            TRAFFIC.setdefault(short(n), {})[cn] = corr
     print()
 
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    json_out = None
+    if "--json" in args:
+        i = args.index("--json")
+        json_out = args[i + 1]
+        args = args[:i] + args[i + 2:]
     if "--pmc" in args:
         i = args.index("--pmc")
         kts, pmcs = args[:i], args[i + 1:]
@@ -54,3 +64,7 @@ if __name__ == "__main__":
         kernel_stats(p)
     for p in pmcs:
         pmc_stats(p)
+    if json_out:
+        import json
+        with open(json_out, "w") as f:
+            json.dump({k: dict(v, hbm_bytes_per_launch=sum(v.values())) for k, v in TRAFFIC.items()}, f, indent=1)
