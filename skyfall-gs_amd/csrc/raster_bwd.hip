@@ -116,7 +116,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
   // list entries behind every pixel's last contributor receive zero gradient
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (unsigned k = kmax + lane; k < L; k += 64) {
-    float4* dst = dupgrad + (size_t)sorted_dup[s + k] * 4;
+    float4* dst = dupgrad + (size_t)sorted_dup[s + k] * 3;
     dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
   }
   if (kmax == 0) return;
@@ -185,7 +185,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
       o1.z = -0.5f * op * acc[7];                 // dL/dconic C
       o1.w = acc[0];                              // dL/d(op)
       o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
-      float4* dst = dupgrad + (size_t)my_dup * 4;
+      float4* dst = dupgrad + (size_t)my_dup * 3;
       dst[0] = o0; dst[1] = o1; dst[2] = o2;
     }
     __builtin_amdgcn_wave_barrier();
@@ -217,7 +217,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     const unsigned d0 = dr.x, d1 = dr.x + dr.y;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
     for (unsigned d = d0; d < d1; ++d) {
-      const float4 x0 = dupgrad[(size_t)d * 4], x1 = dupgrad[(size_t)d * 4 + 1], x2 = dupgrad[(size_t)d * 4 + 2];
+      const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
       a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
       a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
       a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;

@@ -192,7 +192,7 @@ static inline ImageView image_view(void* base, int W, int H) {
   return v;
 }
 
-constexpr int DUPGRAD_FLOATS = 16;  // one 64-byte line per duplicate, 12 floats used (Grad2D order)
+constexpr int DUPGRAD_FLOATS = 12;  // 48 bytes per duplicate (Grad2D order), three 16-byte stores
 static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
 
 // ---- XCD-aware block remap (bijective; guide T1) -------------------------------------------------

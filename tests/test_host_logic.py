@@ -98,7 +98,7 @@ def test_gpu_free_entry_points_and_error_convention():
     sizes = L.SfgsRasterSizes(C.sizeof(L.SfgsRasterSizes))
     assert lib.sfgs_raster_sizes(2_000_000, 1920, 1080, 7_000_000, C.byref(sizes)) == 0
     assert sizes.geom_bytes >= 2_000_000 * 56 and sizes.bins_bytes >= 7_000_000 * 40
-    assert sizes.dupgrad_bytes == 7_000_000 * 64 and sizes.image_bytes >= 1920 * 1080 * 12
+    assert sizes.dupgrad_bytes == 7_000_000 * 48 and sizes.image_bytes >= 1920 * 1080 * 12
     # errors: negative status + thread-local message, never an exception or exit
     bad = L.SfgsRasterSizes(4)
     assert lib.sfgs_raster_sizes(10, 64, 64, 0, C.byref(bad)) == -1
