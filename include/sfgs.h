@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 3
+#define SFGS_ABI_VERSION 4
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -106,9 +106,10 @@ typedef struct SfgsRasterSizes {
   uint32_t struct_size;
   size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile ranges, duplicate offsets      */
   size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials */
-  size_t bins_bytes;     /* f(D):   staged + per-tile duplicates, sorted per-tile lists           */
+  size_t bins_bytes;     /* f(D, coarse_capacity): coarse-bin slabs, per-tile duplicates, sorted lists */
   size_t image_bytes;    /* f(W,H): per-pixel last contributor, final T, raw depth (for backward)*/
   size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
+  int64_t coarse_bins;   /* number of 32x32-pixel coarse bins of this image (informational)      */
 } SfgsRasterSizes;
 
 /* Counters produced by the plan stage (host copy). */
@@ -116,8 +117,10 @@ typedef struct SfgsRasterCounters {
   int64_t num_duplicates;      /* D_eff: (Gaussian, 8x8 tile) pairs binned (opacity-aware test)             */
   int64_t num_duplicates_ref;  /* D:     sum of tiles_touched by the reference's 3-sigma 16x16 rule         */
   int64_t num_visible;         /* N_vis: count(radii > 0)                                                   */
-  int64_t max_tile_list;       /* longest per-tile list                                                     */
-  int64_t overflow;            /* != 0: dup_capacity was too small, redo the plan with a larger bins blob   */
+  int64_t max_tile_list;       /* longest per-tile list (valid when read after sfgs_raster_forward_render)  */
+  int64_t overflow;            /* != 0: dup_capacity or coarse_capacity was too small: redo the plan with
+                                  dup_capacity >= num_duplicates and coarse_capacity >= max_coarse_bin     */
+  int64_t max_coarse_bin;      /* items in the fullest 32x32-pixel coarse bin                               */
 } SfgsRasterCounters;
 
 int sfgs_abi_version(void);
@@ -132,41 +135,46 @@ int sfgs_profile_kernel_count(void);
 const char* sfgs_profile_kernel_name(int32_t id);
 int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);
 
-/* Blob sizes for N Gaussians, a W x H image and (for bins/dupgrad) a duplicate capacity D. */
-int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, SfgsRasterSizes* out);
+/* Blob sizes for N Gaussians, a W x H image, a duplicate capacity D (bins, dupgrad) and a per-coarse-bin
+ * item capacity (bins). */
+int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse_capacity,
+                      SfgsRasterSizes* out);
 
 /* Forward, stage 1 ("plan"): preprocess every Gaussian (cull, EWA projection, 2D mip filter,
- * radius, SH->RGB), write radii[N] (int32), bin every Gaussian into the 8x8 tiles it can contribute
- * to (duplicates staged in `bins`, at most dup_capacity of them) and scan the per-tile counts.
- * The number of duplicates is only known afterwards: if the counters report overflow, call again with
- * a bins blob sized for counters.num_duplicates. Asynchronous on `stream`. */
+ * radius, SH->RGB), write radii[N] (int32) and bin every Gaussian COARSELY: one 16-byte item per
+ * (Gaussian, 32x32-pixel coarse bin) holding the mask of the 8x8 tiles it can contribute to, appended
+ * to that bin's slab in `bins` (coarse_capacity items per bin; dup_capacity duplicate indices).
+ * Neither count is known beforehand: if the counters report overflow, call again with a bins blob
+ * sized for counters.num_duplicates / counters.max_coarse_bin. Asynchronous on `stream`. */
 int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii,
                              void* geom, size_t geom_bytes, void* tiles, size_t tiles_bytes,
-                             void* bins, size_t bins_bytes, int64_t dup_capacity, void* stream);
+                             void* bins, size_t bins_bytes, int64_t dup_capacity,
+                             int64_t coarse_capacity, void* stream);
 
 /* Copies the plan counters to the host. SYNCHRONISES `stream` (the one host sync of the forward,
  * as in the reference, where the duplicate total sizes the sort buffers). */
 int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream);
 
-/* Forward, stage 2 ("render"): permute the staged duplicates into per-tile segments, sort each
- * segment by (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
+/* Forward, stage 2 ("render"): expand the coarse items into per-tile lists (LDS-ranked), sort each
+ * list by (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
  * out_depth[1,H,W], out_alpha[1,H,W]. num_duplicates = counters.num_duplicates of the plan that
- * filled `bins` (same dup_capacity). `image` may be NULL when no backward will follow.
- * Asynchronous on `stream`. */
-int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles,
+ * filled `bins` (same capacities). `image` may be NULL when no backward will follow. One render per
+ * plan. Asynchronous on `stream`. */
+int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
                                void* bins, size_t bins_bytes, int64_t dup_capacity,
-                               int64_t num_duplicates, float* out_color, float* out_depth,
-                               float* out_alpha, void* image, size_t image_bytes, void* stream);
+                               int64_t coarse_capacity, int64_t num_duplicates, float* out_color,
+                               float* out_depth, float* out_alpha, void* image, size_t image_bytes,
+                               void* stream);
 
 /* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
- * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same dup_capacity, image)
+ * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same capacities, image)
  * and radii unchanged. `dupgrad` is scratch for dup_capacity duplicates (sfgs_raster_sizes). Every
  * gradient tensor in `grads` is fully overwritten. Deterministic (no float atomics). Asynchronous. */
 int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                          const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
-                         const void* image, const float* dL_dcolor, const float* dL_ddepth,
-                         const float* dL_dalpha, void* dupgrad, size_t dupgrad_bytes,
-                         const SfgsGaussianGrads* grads, void* stream);
+                         int64_t coarse_capacity, const void* image, const float* dL_dcolor,
+                         const float* dL_ddepth, const float* dL_dalpha, void* dupgrad,
+                         size_t dupgrad_bytes, const SfgsGaussianGrads* grads, void* stream);
 
 /* fused_ssim: mean SSIM (11x11 Gaussian window, sigma 1.5, zero "same" padding, C1=0.01^2,
  * C2=0.03^2 == utils/loss_utils.py:23-63) of img1,img2 [B,C,H,W] float32.

@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
 
 // ---- profiler: HIP events recorded on the launch stream around every kernel ---------------------
 static const char* const kKernelNames[KID_COUNT] = {
-    "subpix_bound", "preprocess", "plan_scan", "plan_finish", "permute", "sort_tiles_small", "sort_tiles_medium",
+    "subpix_bound", "preprocess", "plan_scan", "fine_bin", "sort_tiles_small", "sort_tiles_medium",
     "sort_tiles_global", "composite_fwd", "composite_bwd", "preprocess_bwd", "ssim_fwd", "ssim_mean", "ssim_bwd",
     "knn_dist2"};
 

@@ -66,7 +66,7 @@ __device__ __forceinline__ void phase2_step(Phase2Acc& a, float u, float w, floa
 
 template <int B>
 __global__ void __launch_bounds__(256, 4)  // 4 waves/SIMD: <= 128 VGPRs, 4 workgroups (36 KB LDS each) per CU
-composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32_t* __restrict__ tile_start,
+composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
@@ -85,7 +85,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
   const bool inside = px < W && py < H;
   const size_t pix = (size_t)py * W + px;
   const int t = ty * TX8 + tx;
-  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const uint2 tr = tile_range[t];
+  const unsigned s = tr.x, e = tr.x + tr.y;
   const unsigned L = e - s;
   if (L == 0) return;
 
@@ -260,7 +261,7 @@ using namespace sfgs;
 
 extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                                     const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
-                                    const void* image, const float* dL_dcolor, const float* dL_ddepth,
+                                    int64_t coarse_capacity, const void* image, const float* dL_dcolor, const float* dL_ddepth,
                                     const float* dL_dalpha, void* dupgrad, size_t dupgrad_sz,
                                     const SfgsGaussianGrads* grads, void* stream_) {
   SFGS_REQUIRE(frame && frame->struct_size == sizeof(SfgsFrame), SFGS_E_ARG, "SfgsFrame.struct_size mismatch");
@@ -281,13 +282,13 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_REQUIRE(dup_capacity == 0 || (bins && dupgrad), SFGS_E_ARG, "bins / dupgrad is NULL");
   const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
-  const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity);
+  const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity, coarse_bins(W, H), coarse_capacity);
   const ImageView iv = image_view(const_cast<void*>(image), W, H);
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
-    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
                        dL_dalpha, (float4*)dupgrad); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);

@@ -31,32 +31,32 @@ __global__ void __launch_bounds__(256) subpix_bound_kernel(const float* __restri
   if (lane_id() == 0) atomicMax((unsigned int*)&hdr[HDR_SUBPIX_BOUND], __float_as_uint(m));
 }
 
-// hit mask of tiles [c0, c0 + 64) of a walk range (row-major inside the range)
-__device__ __forceinline__ unsigned long long chunk_hits(const SplatRec& r, float thr, const BinRange& br, long long c0,
-                                                         long long ntiles, int W, int H, float bound) {
-  const int nx = br.x1 - br.x0;
-  const int cnt = (int)min(64ll, ntiles - c0);
-  unsigned long long m = 0ull;
-  int ty = br.y0 + (int)(c0 / nx), tx = br.x0 + (int)(c0 % nx);
-  for (int i = 0; i < cnt; ++i) {
-    if (bin_test(r, thr, tx, ty, W, H, bound)) m |= 1ull << i;
-    if (++tx == br.x1) { tx = br.x0; ++ty; }
-  }
+// 16-bit hit mask of the 4x4 tiles of coarse bin (cbx, cby) that lie inside the walk range `br`
+// (bit = 4 * local_y + local_x).
+__device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, const BinRange& br, int cbx, int cby,
+                                                int W, int H, float bound) {
+  unsigned m = 0;
+  const int tx0 = imax(br.x0, cbx * COARSE), tx1 = imin(br.x1, cbx * COARSE + COARSE);
+  const int ty0 = imax(br.y0, cby * COARSE), ty1 = imin(br.y1, cby * COARSE + COARSE);
+  for (int ty = ty0; ty < ty1; ++ty)
+    for (int tx = tx0; tx < tx1; ++tx)
+      if (bin_test(r, thr, tx, ty, W, H, bound)) m |= 1u << ((ty - cby * COARSE) * COARSE + (tx - cbx * COARSE));
   return m;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one thread per Gaussian: project, write radii + the compositing record, and bin. Binning in one
-// pass: the thread walks the 8x8 tiles its splat can reach (opacity-aware test, raster_math.h),
-// remembers the hits in a bit mask, the block reserves a contiguous range of duplicate indices with ONE
-// returning atomic, and every hit then takes its rank inside the tile from the tile counter and is
-// staged as (id, depth, tile, rank). Nothing is recounted later: K3 is a pure permutation.
+// K1: one thread per Gaussian: project, write radii + the compositing record, and bin COARSELY.
+// The thread walks the coarse bins (32x32 px) its splat can reach; for each it computes the 16-bit mask of
+// the 8x8 tiles the splat can contribute to (opacity-aware test, raster_math.h). A non-empty mask becomes
+// one 16-byte coarse item (id, depth, first duplicate index, mask) appended to the bin's slab with ONE
+// returning device atomic. The block reserves its duplicate indices (one per set mask bit, in walk order)
+// with one atomic per block.
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
                   const float* __restrict__ colors, const float* __restrict__ shs, int* __restrict__ radii,
-                  float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ tile_count8, int T8,
-                  uint4* __restrict__ staging, unsigned long long dup_capacity,
+                  float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
+                  uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
                   unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
@@ -64,13 +64,13 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const FrameParams f = load_frame(kf);
   const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  const int TX8 = (f.W + TILE_BIN - 1) / TILE_BIN;
+  const int CX = (((f.W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
   unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
-  unsigned long long mask = 0ull;  // hit mask of the last 64-tile chunk of the walk range
-  long long ntiles = 0;
+  unsigned long long cached = 0ull;  // masks of the first four coarse bins of the walk (16 bits each)
   SplatRec r;
   BinRange br;
   float thr = 0.f;
+  int cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;
   br.x0 = br.x1 = br.y0 = br.y1 = 0;
   if (g < N) {
     float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
@@ -97,10 +97,16 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
       br.y0 = imax(br.y0, kf.band0); br.y1 = imax(br.y0, imin(br.y1, kf.band1));  // band rendering
       thr = alpha_threshold_log2(r.op);
-      ntiles = (long long)(br.x1 - br.x0) * (br.y1 - br.y0);
-      for (long long c0 = 0; c0 < ntiles; c0 += 64) {
-        mask = chunk_hits(r, thr, br, c0, ntiles, f.W, f.H, bound);
-        n_dup += (unsigned)__popcll(mask);
+      if (br.x1 > br.x0 && br.y1 > br.y0) {
+        cx0 = br.x0 / COARSE; cx1 = (br.x1 - 1) / COARSE + 1;
+        cy0 = br.y0 / COARSE; cy1 = (br.y1 - 1) / COARSE + 1;
+        int k = 0;
+        for (int cy = cy0; cy < cy1; ++cy)
+          for (int cx = cx0; cx < cx1; ++cx, ++k) {
+            const unsigned m = coarse_hits(r, thr, br, cx, cy, f.W, f.H, bound);
+            if (k < 4) cached |= (unsigned long long)m << (16 * k);
+            n_dup += (unsigned)__popc(m);
+          }
       }
     }
   }
@@ -114,25 +120,19 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   if (!fits && threadIdx.x == 0) hdr[HDR_OVERFLOW] = 1ull;
   if (g < N) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
   if (fits && n_dup) {
-    // emit: one 64-tile chunk of the walk range at a time (a single chunk -- whose hit mask is still in
-    // `mask` from the counting pass -- for all but very large splats)
-    const unsigned long long first = base + ex;
-    const int nx = br.x1 - br.x0;
-    const unsigned xcd = xcc_id();
-    uint32_t* __restrict__ my_count = tile_count8 + (size_t)xcd * T8;  // this XCD's private counters
-    unsigned j = 0;
-    for (long long c0 = 0; c0 < ntiles; c0 += 64) {
-      unsigned long long m = ntiles <= 64 ? mask : chunk_hits(r, thr, br, c0, ntiles, f.W, f.H, bound);
-      while (m) {
-        const int bit = __builtin_ctzll(m);
-        m &= m - 1;
-        const long long idx = c0 + bit;
-        const int t = (br.y0 + (int)(idx / nx)) * TX8 + br.x0 + (int)(idx % nx);
-        const unsigned rank = atomicAdd(&my_count[t], 1u);  // rank among THIS XCD's duplicates of tile t
-        staging[first + j] = make_uint4((unsigned)g, depth_bits, (unsigned)t | (xcd << 29), rank);
-        ++j;
+    unsigned dup = (unsigned)(base + ex);
+    int k = 0;
+    for (int cy = cy0; cy < cy1; ++cy)
+      for (int cx = cx0; cx < cx1; ++cx, ++k) {
+        const unsigned m = k < 4 ? (unsigned)((cached >> (16 * k)) & 0xffffu) : coarse_hits(r, thr, br, cx, cy, f.W, f.H, bound);
+        if (m) {
+          const int cb = cy * CX + cx;
+          const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+          if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4((unsigned)g, depth_bits, dup, m);
+          else hdr[HDR_OVERFLOW] = 1ull;
+          dup += (unsigned)__popc(m);
+        }
       }
-    }
   }
   // per-block statistics (summed by plan_scan; no contended atomics)
   block_excl_scan_u32<PRE_BLOCK>(vis, &total, s_red);
@@ -142,93 +142,87 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: tile scan in three small launches (SCAN_BLOCK tiles per workgroup):
-//   tile_sums   : per tile, total over the 8 XCD-private counters; per-workgroup totals -> scan_part
-//   plan_scan   : one workgroup: exclusive scan of scan_part, counters for the host (also sums block stats)
-//   plan_finish : per tile, tile_start = base + in-workgroup exclusive scan; start8[x][t] = running offset
-//                 of XCD x's duplicates inside the tile's segment
-__global__ void __launch_bounds__(SCAN_BLOCK)
-tile_sums_kernel(int T8, const uint32_t* __restrict__ tile_count8, uint32_t* __restrict__ scan_part,
-                 unsigned long long* __restrict__ hdr) {
-  __shared__ unsigned s_red[SCAN_BLOCK / 64 + 1];
-  const int t = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  unsigned v = 0;
-  if (t < T8) {
-#pragma unroll
-    for (int x = 0; x < NXCD; ++x) v += tile_count8[(size_t)x * T8 + t];
-  }
-  unsigned total;
-  block_excl_scan_u32<SCAN_BLOCK>(v, &total, s_red);
-  if (threadIdx.x == 0) scan_part[blockIdx.x] = total;
-  // longest list
-  unsigned m = v;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
-  if (lane_id() == 0 && m) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], m);
-}
-
+// K2: single workgroup: counters for the host (visible count, reference duplicate total, fullest coarse bin).
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
-plan_scan_kernel(int NS, int NB, uint32_t* __restrict__ scan_part, const uint32_t* __restrict__ block_nvis,
+plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                  const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr) {
-  __shared__ unsigned s_red[SCAN_NT / 64 + 1];
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
-  unsigned carry = 0;
-  for (int base = 0; base < NS; base += SCAN_NT) {
-    const int i = base + threadIdx.x;
-    const unsigned v = i < NS ? scan_part[i] : 0u;
-    unsigned total;
-    const unsigned ex = block_excl_scan_u32<SCAN_NT>(v, &total, s_red);
-    if (i < NS) scan_part[i] = carry + ex;
-    carry += total;
-  }
-  unsigned long long nvis = 0, dref = 0;
+  unsigned long long nvis = 0, dref = 0, cmax = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
-  for (int pass = 0; pass < 2; ++pass) {
-    unsigned long long v = pass == 0 ? nvis : dref;
+  for (int i = threadIdx.x; i < NCB; i += SCAN_NT) cmax = max(cmax, (unsigned long long)coarse_count[(size_t)i * CC_STRIDE]);
+  for (int pass = 0; pass < 3; ++pass) {
+    unsigned long long v = pass == 0 ? nvis : pass == 1 ? dref : cmax;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long o = __shfl_xor(v, d);
+      v = pass == 2 ? max(v, o) : v + o;
+    }
     if (lane_id() == 0) s_acc[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
-      for (int w = 0; w < SCAN_NT / 64; ++w) t += s_acc[w];
-      hdr[pass == 0 ? HDR_N_VIS : HDR_D_REF] = t;
+      for (int w = 0; w < SCAN_NT / 64; ++w) t = pass == 2 ? max(t, s_acc[w]) : t + s_acc[w];
+      hdr[pass == 0 ? HDR_N_VIS : pass == 1 ? HDR_D_REF : HDR_MAX_COARSE] = t;
     }
     __syncthreads();
   }
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK)
-plan_finish_kernel(int T8, const uint32_t* __restrict__ tile_count8, const uint32_t* __restrict__ scan_part,
-                   uint32_t* __restrict__ tile_start, uint32_t* __restrict__ start8) {
-  __shared__ unsigned s_red[SCAN_BLOCK / 64 + 1];
-  const int t = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  unsigned c[NXCD], v = 0;
-#pragma unroll
-  for (int x = 0; x < NXCD; ++x) { c[x] = t < T8 ? tile_count8[(size_t)x * T8 + t] : 0u; v += c[x]; }
-  unsigned total;
-  const unsigned start = scan_part[blockIdx.x] + block_excl_scan_u32<SCAN_BLOCK>(v, &total, s_red);
-  if (t < T8) {
-    tile_start[t] = start;
-    unsigned run = start;
-#pragma unroll
-    for (int x = 0; x < NXCD; ++x) { start8[(size_t)x * T8 + t] = run; run += c[x]; }
-    if (t == T8 - 1) tile_start[T8] = start + v;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// K3: permutation of the staged duplicates into per-tile segments (one thread per duplicate; coalesced
-// 16-byte reads, one 16-byte scattered store each; no atomics, no tests).
+// K3: fine binning. One wave per coarse bin (4 per workgroup, no barriers): count the bin's 16 tiles with LDS
+// atomics, reserve the bin's list slots with ONE device atomic, publish (start, length) of its tiles, then
+// expand every coarse item into its per-tile duplicates: items[slot] = (id, depth, dup index, 0).
 __global__ void __launch_bounds__(256)
-permute_kernel(unsigned D, int T8, const uint4* __restrict__ staging, const uint32_t* __restrict__ start8,
-               uint4* __restrict__ items) {
-  const unsigned d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  const uint4 it = staging[d];
-  const unsigned t = it.z & 0x1fffffffu, x = it.z >> 29;
-  items[start8[(size_t)x * T8 + t] + it.w] = make_uint4(it.x, it.y, d, 0u);
+fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ coarse_count,
+                const uint4* __restrict__ slabs, unsigned coarse_capacity, uint2* __restrict__ tile_range,
+                uint4* __restrict__ items, unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_cnt[4][COARSE_TILES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cb = blockIdx.x * 4 + wave;
+  if (cb >= NCB) return;
+  unsigned* cnt = s_cnt[wave];
+  const unsigned n = min(coarse_count[(size_t)cb * CC_STRIDE], coarse_capacity);
+  const uint4* slab = slabs + (size_t)cb * coarse_capacity;
+  if (lane < COARSE_TILES) cnt[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (unsigned i = lane; i < n; i += 64) {
+    unsigned m = slab[i].w;
+    while (m) { const int b = __builtin_ctz(m); m &= m - 1; atomicAdd(&cnt[b], 1u); }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // exclusive scan of the 16 counts (lanes 0..15), one allocation for the whole bin
+  const unsigned c = lane < COARSE_TILES ? cnt[lane] : 0u;
+  unsigned incl = c;
+#pragma unroll
+  for (int d = 1; d < COARSE_TILES; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  const unsigned total = __shfl(incl, COARSE_TILES - 1);
+  unsigned long long base = 0;
+  if (lane == 0 && total) base = atomicAdd(&hdr[HDR_ITEM_ALLOC], (unsigned long long)total);
+  base = __shfl(base, 0);
+  const unsigned off = incl - c;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < COARSE_TILES) {
+    const int tx = (cb % CX) * COARSE + (lane & (COARSE - 1)), ty = (cb / CX) * COARSE + (lane / COARSE);
+    if (tx < TX8 && ty < TY8) tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
+    cnt[lane] = off;  // becomes the per-tile cursor
+    if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (unsigned i = lane; i < n; i += 64) {
+    const uint4 it = slab[i];
+    unsigned m = it.w, dup = it.z;
+    while (m) {
+      const int b = __builtin_ctz(m);
+      m &= m - 1;
+      const unsigned slot = atomicAdd(&cnt[b], 1u);
+      items[base + slot] = make_uint4(it.x, it.y, dup, 0u);
+      ++dup;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -237,7 +231,7 @@ permute_kernel(unsigned D, int T8, const uint4* __restrict__ staging, const uint
 // the tail. One wave per tile, keys + 16-bit local payload indices in LDS.
 template <int CAP>
 __global__ void __launch_bounds__(64)
-sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_start,
+sort_tiles_lds_kernel(int T8, int lo, int hi, const uint2* __restrict__ tile_range,
                       const uint4* __restrict__ items, uint32_t* __restrict__ sorted_id,
                       uint32_t* __restrict__ sorted_dup) {
   __shared__ unsigned long long k[CAP];
@@ -245,7 +239,8 @@ sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_
   __shared__ unsigned short vi[CAP];
   const int t = blockIdx.x;
   if (t >= T8) return;
-  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const uint2 tr = tile_range[t];
+  const unsigned s = tr.x, e = tr.x + tr.y;
   const int L = (int)(e - s);
   if (L <= lo || L > hi) return;
   const int lane = threadIdx.x;
@@ -290,11 +285,12 @@ sort_tiles_lds_kernel(int T8, int lo, int hi, const uint32_t* __restrict__ tile_
 // comparators that reach past the end are no-ops). Rare path; agent-scope relaxed accesses bypass the
 // per-CU L1 so that waves of the block see each other's exchanges after the barrier.
 __global__ void __launch_bounds__(256)
-sort_tiles_global_kernel(int T8, int lo, const uint32_t* __restrict__ tile_start, uint4* items,
+sort_tiles_global_kernel(int T8, int lo, const uint2* __restrict__ tile_range, uint4* items,
                          uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
   const int t = blockIdx.x;
   if (t >= T8) return;
-  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const uint2 tr = tile_range[t];
+  const unsigned s = tr.x, e = tr.x + tr.y;
   const long long L = (long long)e - s;
   if (L <= lo) return;
   unsigned long long* w = reinterpret_cast<unsigned long long*>(items + s);  // item i = words 2i (key), 2i+1 (dup)
@@ -339,7 +335,7 @@ sort_tiles_global_kernel(int T8, int lo, const uint32_t* __restrict__ tile_start
 // (48 B each) into a wave-private LDS stage and consumed with uniform-address (broadcast) reads.
 // No barriers: a wave only ever reads what it wrote itself.
 __global__ void __launch_bounds__(256)
-composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32_t* __restrict__ tile_start,
+composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const float4* __restrict__ rec,
                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
                      uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out) {
@@ -356,7 +352,8 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint32
   if (kf.subpix && inside) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
 
   const int t = ty * TX8 + tx;
-  const unsigned s = tile_start[t], e = tile_start[t + 1];
+  const uint2 tr = tile_range[t];
+  const unsigned s = tr.x, e = tr.x + tr.y;
   PixelFwd ps;
   ps.T = 1.f; ps.C0 = ps.C1 = ps.C2 = ps.D = 0.f; ps.last = 0; ps.done = !inside;
   float4* st = stage[wave];
@@ -428,23 +425,26 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
   return SFGS_OK;
 }
 
-extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, SfgsRasterSizes* out) {
+extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse_capacity,
+                                 SfgsRasterSizes* out) {
   SFGS_REQUIRE(out && out->struct_size == sizeof(SfgsRasterSizes), SFGS_E_ARG, "SfgsRasterSizes.struct_size mismatch");
-  SFGS_REQUIRE(N >= 0 && W > 0 && H > 0 && D >= 0, SFGS_E_ARG, "bad sizes N=%d W=%d H=%d D=%lld", N, W, H, (long long)D);
-  SFGS_REQUIRE(D < (1ll << 32), SFGS_E_UNSUPPORTED, "more than 2^32 duplicates");
+  SFGS_REQUIRE(N >= 0 && W > 0 && H > 0 && D >= 0 && coarse_capacity >= 0, SFGS_E_ARG,
+               "bad sizes N=%d W=%d H=%d D=%lld coarse_capacity=%lld", N, W, H, (long long)D, (long long)coarse_capacity);
+  SFGS_REQUIRE(D < (1ll << 32) && coarse_capacity < (1ll << 31), SFGS_E_UNSUPPORTED, "more than 2^32 duplicates");
   size_t tb = 0;
   tiles_view(nullptr, W, H, N, &tb);
   out->geom_bytes = geom_bytes(N);
   out->tiles_bytes = tb;
-  out->bins_bytes = bins_bytes(D);
+  out->bins_bytes = bins_bytes(D, coarse_bins(W, H), coarse_capacity);
   out->image_bytes = image_bytes(W, H);
   out->dupgrad_bytes = dupgrad_bytes(D);
+  out->coarse_bins = coarse_bins(W, H);
   return SFGS_OK;
 }
 
 extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* geom,
                                         size_t geom_sz, void* tiles, size_t tiles_sz, void* bins, size_t bins_sz,
-                                        int64_t dup_capacity, void* stream_) {
+                                        int64_t dup_capacity, int64_t coarse_capacity, void* stream_) {
   if (int rc = check_frame(frame)) return rc;
   if (int rc = check_gaussians(frame, g)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -452,17 +452,19 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   size_t tb = 0;
   SFGS_REQUIRE(tiles != nullptr, SFGS_E_ARG, "tiles blob is NULL");
   const TilesView tv = tiles_view(tiles, W, H, N, &tb);
+  const int64_t NCB = coarse_bins(W, H);
   SFGS_REQUIRE(tiles_sz >= tb, SFGS_E_CAPACITY, "tiles blob: %zu bytes given, %zu needed", tiles_sz, tb);
   SFGS_REQUIRE(geom_sz >= geom_bytes(N), SFGS_E_CAPACITY, "geom blob: %zu bytes given, %zu needed", geom_sz, geom_bytes(N));
   SFGS_REQUIRE(N == 0 || (radii && geom), SFGS_E_ARG, "radii / geom is NULL");
-  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32), SFGS_E_ARG, "bad dup_capacity");
-  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity), SFGS_E_CAPACITY, "bins blob: %zu bytes given, %zu needed", bins_sz,
-               bins_bytes(dup_capacity));
-  SFGS_REQUIRE(dup_capacity == 0 || bins, SFGS_E_ARG, "bins blob is NULL");
+  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0 && coarse_capacity < (1ll << 31),
+               SFGS_E_ARG, "bad dup_capacity / coarse_capacity");
+  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
+               "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
+  SFGS_REQUIRE(bins, SFGS_E_ARG, "bins blob is NULL");
   const GeomView gv = geom_view(geom, N);
-  const BinsView bv = bins_view(bins, dup_capacity);
+  const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
   const KFrame kf = make_kframe(frame);
-  const int T8 = (int)tiles8(W, H), NB = (int)pre_blocks(N);
+  const int NB = (int)pre_blocks(N);
   SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
   if (frame->subpixel_offset) {
     const int64_t n = (int64_t)W * H * 2;
@@ -474,18 +476,14 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
       hipLaunchKernelGGL(preprocess_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
-                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.tile_count8, T8,
-                         bv.staging, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref, tv.hdr); }
+                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,
+                         bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,
+                         tv.block_dref, tv.hdr); }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }
-  const int NS = (T8 + SCAN_BLOCK - 1) / SCAN_BLOCK;
   { ProfScope ps_(KID_PLAN_SCAN, stream);
-    hipLaunchKernelGGL(tile_sums_kernel, dim3(NS), dim3(SCAN_BLOCK), 0, stream, T8, tv.tile_count8, tv.scan_part,
-                       tv.hdr);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, NS, NB, tv.scan_part, tv.block_nvis,
-                       tv.block_dref, tv.hdr);
-    hipLaunchKernelGGL(plan_finish_kernel, dim3(NS), dim3(SCAN_BLOCK), 0, stream, T8, tv.tile_count8, tv.scan_part,
-                       tv.tile_start, tv.start8); }
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
+                       tv.block_dref, tv.hdr); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;
 }
@@ -501,48 +499,48 @@ extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* 
   out->num_visible = (int64_t)h[HDR_N_VIS];
   out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
   out->overflow = (int64_t)h[HDR_OVERFLOW];
+  out->max_coarse_bin = (int64_t)h[HDR_MAX_COARSE];
   return SFGS_OK;
 }
 
 constexpr int SORT_SMALL = 512, SORT_CAP = 4096;
 
-extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles,
-                                          void* bins, size_t bins_sz, int64_t dup_capacity, int64_t num_duplicates,
-                                          float* out_color, float* out_depth, float* out_alpha, void* image,
-                                          size_t image_sz, void* stream_) {
+extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
+                                          void* bins, size_t bins_sz, int64_t dup_capacity, int64_t coarse_capacity,
+                                          int64_t num_duplicates, float* out_color, float* out_depth, float* out_alpha,
+                                          void* image, size_t image_sz, void* stream_) {
   if (int rc = check_frame(frame)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   const int W = frame->image_width, H = frame->image_height;
-  SFGS_REQUIRE(N >= 0 && tiles && out_color && out_depth && out_alpha, SFGS_E_ARG, "NULL argument");
-  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32), SFGS_E_ARG, "bad dup_capacity");
+  const int64_t NCB = coarse_bins(W, H);
+  SFGS_REQUIRE(N >= 0 && tiles && out_color && out_depth && out_alpha && bins, SFGS_E_ARG, "NULL argument");
+  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0, SFGS_E_ARG, "bad capacity");
   SFGS_REQUIRE(num_duplicates >= 0 && num_duplicates <= dup_capacity, SFGS_E_CAPACITY,
                "num_duplicates %lld exceeds dup_capacity %lld: redo the plan with a larger bins blob",
                (long long)num_duplicates, (long long)dup_capacity);
-  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity), SFGS_E_CAPACITY, "bins blob: %zu bytes given, %zu needed", bins_sz,
-               bins_bytes(dup_capacity));
+  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
+               "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
   SFGS_REQUIRE(image == nullptr || image_sz >= image_bytes(W, H), SFGS_E_CAPACITY, "image blob too small");
-  SFGS_REQUIRE(dup_capacity == 0 || bins, SFGS_E_ARG, "bins blob is NULL");
-  const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
+  const TilesView tv = tiles_view(tiles, W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
-  const BinsView bv = bins_view(bins, dup_capacity);
+  const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
   const KFrame kf = make_kframe(frame);
-  const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN, T8 = TX8 * TY8;
+  const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
+  { ProfScope ps_(KID_FINE_BIN, stream);
+    hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)((NCB + 3) / 4)), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
+                       tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, tv.tile_range, bv.items, tv.hdr); }
+  SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
   if (num_duplicates > 0) {
-    const unsigned D = (unsigned)num_duplicates;
-    { ProfScope ps_(KID_PERMUTE, stream);
-      hipLaunchKernelGGL(permute_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, D, T8, bv.staging, tv.start8,
-                         bv.items); }
-    SFGS_POST_LAUNCH("permute", stream, frame->debug);
     { ProfScope ps_(KID_SORT_SMALL, stream);
       hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_SMALL>, dim3(T8), dim3(64), 0, stream, T8, 0, SORT_SMALL,
-                         tv.tile_start, bv.items, bv.sorted_id, bv.sorted_dup); }
+                         tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
     { ProfScope ps_(KID_SORT_MEDIUM, stream);
       hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(T8), dim3(64), 0, stream, T8, SORT_SMALL, SORT_CAP,
-                         tv.tile_start, bv.items, bv.sorted_id, bv.sorted_dup); }
+                         tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
     { ProfScope ps_(KID_SORT_GLOBAL, stream);
-      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_start,
+      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_range,
                          bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_global", stream, frame->debug);
   }
@@ -550,7 +548,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   if (image) iv = image_view(image, W, H);
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_FWD, stream);
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_start,
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T, iv.dacc); }
   SFGS_POST_LAUNCH("composite_fwd", stream, frame->debug);
   return SFGS_OK;

@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 
 // ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
 enum KernelId {
-  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_PLAN_FINISH, KID_PERMUTE, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
+  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_FINE_BIN, KID_SORT_SMALL, KID_SORT_MEDIUM, KID_SORT_GLOBAL,
   KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN,
   KID_COUNT
 };
@@ -107,8 +107,10 @@ enum HeaderSlot {
   HDR_D_REF = 1,      // sum of the reference's tiles_touched (16x16 rule)
   HDR_N_VIS = 2,      // count(radii > 0)
   HDR_MAX_LIST = 3,   // longest per-tile list
-  HDR_OVERFLOW = 4,   // set by preprocess when dup_capacity is too small (the plan must be redone)
-  HDR_SUBPIX_BOUND = 5  // float bits of max |subpixel_offset| (0 when none)
+  HDR_OVERFLOW = 4,   // set by preprocess when dup_capacity / coarse_capacity is too small (redo the plan)
+  HDR_SUBPIX_BOUND = 5,  // float bits of max |subpixel_offset| (0 when none)
+  HDR_ITEM_ALLOC = 6,    // list-slot allocator of the fine-binning kernel
+  HDR_MAX_COARSE = 7     // fullest coarse bin (sizes coarse_capacity for the next frame)
 };
 
 struct GeomView {
@@ -124,35 +126,39 @@ static inline GeomView geom_view(void* base, int64_t N) {
   return g;
 }
 
-constexpr int NXCD = 8;             // MI355X: 8 XCDs, each with a private L2
-constexpr int SCAN_BLOCK = 256;     // tiles per workgroup of the tile-scan kernels
+// Coarse bins: 4x4 tiles of 8x8 pixels = 32x32 pixels. Binning is two-level so that the slow device-wide
+// atomics (measured 26.7 G/s on MI355X, independent of scope / return / locality) are paid once per (Gaussian,
+// coarse bin) pair instead of once per (Gaussian, tile) pair; the per-tile ranks come from LDS atomics.
+constexpr int COARSE = 4;           // tiles per coarse-bin edge
+constexpr int COARSE_TILES = COARSE * COARSE;
+constexpr int CC_STRIDE = 32;       // coarse counters live 128 bytes apart: atomics on one cache line serialise
+                                    // (~12 ns each), and a dense array would put 16-32 hot counters on one line
 
 struct TilesView {
   unsigned long long* hdr;  // [HDR_WORDS]
-  uint32_t* tile_count8;    // [NXCD][T8] per-XCD tile counters (zeroed by plan): an XCD only ever touches its
-                            //            own copy, so the lines never bounce between the non-coherent L2s
-  uint32_t* tile_start;     // [T8+1]
-  uint32_t* start8;         // [NXCD][T8] first slot of XCD x's duplicates inside tile t's segment
-  uint32_t* scan_part;      // [ceil(T8/SCAN_BLOCK)] per-workgroup totals -> exclusive bases
+  uint32_t* coarse_count;   // [NCB * CC_STRIDE] items appended to every coarse bin, one counter per 128 bytes
+                            //                   (zeroed by plan; keeps counting past capacity)
+  uint2* tile_range;        // [T8] (first list slot, list length) of every 8x8 tile
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
 };
-static inline int64_t tiles8(int W, int H) {
-  return (int64_t)((W + TILE_BIN - 1) / TILE_BIN) * ((H + TILE_BIN - 1) / TILE_BIN);
-}
+static inline int tiles8_x(int W) { return (W + TILE_BIN - 1) / TILE_BIN; }
+static inline int tiles8_y(int H) { return (H + TILE_BIN - 1) / TILE_BIN; }
+static inline int64_t tiles8(int W, int H) { return (int64_t)tiles8_x(W) * tiles8_y(H); }
+static inline int coarse_x(int W) { return (tiles8_x(W) + COARSE - 1) / COARSE; }
+static inline int coarse_y(int H) { return (tiles8_y(H) + COARSE - 1) / COARSE; }
+static inline int64_t coarse_bins(int W, int H) { return (int64_t)coarse_x(W) * coarse_y(H); }
 static inline int64_t pre_blocks(int64_t N) { return (N + PRE_BLOCK - 1) / PRE_BLOCK; }
 static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* total) {
   TilesView t;
-  const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1, NS = (T8 + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+  const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1, NCB = coarse_bins(W, H);
   char* p = (char*)base;
   size_t off = 0;
   t.hdr = (unsigned long long*)(p + off); off += HDR_WORDS * 8;
-  t.tile_count8 = (uint32_t*)(p + off); off += align_up((size_t)NXCD * T8 * 4, 256);
+  t.coarse_count = (uint32_t*)(p + off); off += align_up((size_t)NCB * CC_STRIDE * 4, 256);
   t.zero_bytes = off;
-  t.tile_start = (uint32_t*)(p + off); off += align_up((size_t)(T8 + 1) * 4, 256);
-  t.start8 = (uint32_t*)(p + off); off += align_up((size_t)NXCD * T8 * 4, 256);
-  t.scan_part = (uint32_t*)(p + off); off += align_up((size_t)NS * 4, 256);
+  t.tile_range = (uint2*)(p + off); off += align_up((size_t)T8 * 8, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
   if (total) *total = off;
@@ -160,18 +166,18 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
 }
 
 struct BinsView {
-  uint4* staging;        // [D] duplicates in Gaussian order: (Gaussian id, depth bits, tile, rank in tile)
-  uint4* items;          // [D] the same permuted into per-tile segments: (Gaussian id, depth bits, dup index, 0)
+  uint4* slabs;          // [NCB][coarse_capacity] coarse items (Gaussian id, depth bits, first dup index, 16-bit tile mask)
+  uint4* items;          // [D] per-tile segments, unsorted: (Gaussian id, depth bits, dup index, 0)
   uint32_t* sorted_id;   // [D] per-tile lists of Gaussian ids, front to back
   uint32_t* sorted_dup;  // [D] the matching duplicate indices
 };
-static inline size_t bins_bytes(int64_t D) {
-  return 2 * align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
+static inline size_t bins_bytes(int64_t D, int64_t NCB, int64_t coarse_cap) {
+  return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
 }
-static inline BinsView bins_view(void* base, int64_t D) {
+static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coarse_cap) {
   BinsView b;
   char* p = (char*)base;
-  b.staging = (uint4*)p; p += align_up((size_t)D * 16, 256);
+  b.slabs = (uint4*)p; p += align_up((size_t)NCB * coarse_cap * 16, 256);
   b.items = (uint4*)p; p += align_up((size_t)D * 16, 256);
   b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
   b.sorted_dup = (uint32_t*)p;
@@ -207,10 +213,6 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
 
 // ---- small wave / block primitives ---------------------------------------------------------------
 __device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
-
-// id (0..7) of the XCD this wave runs on: s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4). A hardware fact, not a
-// dispatch-order assumption: used to pick the XCD-private counter copy.
-__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (NXCD - 1); }
 
 __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
   const unsigned lane = lane_id();

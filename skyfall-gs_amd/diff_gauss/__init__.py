@@ -44,12 +44,21 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _last_counters = {}
-_cap_hint = {}   # device index -> duplicate capacity to plan with (grows geometrically)
+_cap_hint = {}   # device index -> (duplicate capacity, per-coarse-bin capacity) to plan with (grow geometrically)
 
 
 def last_counters():
-    """Counters of the most recent forward on this process (D_eff, D_ref, N_vis, max list): bench/tests."""
-    return dict(_last_counters)
+    """Counters of the most recent forward on this process (D_eff, D_ref, N_vis, longest list, ...): bench/tests.
+    Synchronises the device (the longest list is only known once the render stage has run)."""
+    out = {k: v for k, v in _last_counters.items() if not k.startswith("_")}
+    tiles = _last_counters.get("_tiles")
+    if tiles is not None:
+        dev = _last_counters["_stream_dev"]
+        with torch.cuda.device(dev):
+            cnt = L.SfgsRasterCounters()
+            L.check(L.load().sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), _stream(dev)))
+        out["max_tile_list"] = int(cnt.max_tile_list)
+    return out
 
 
 def _f32c(t, name, shape_tail=None):
@@ -117,39 +126,47 @@ class _Rasterize(torch.autograd.Function):
             sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
             u8 = dict(dtype=torch.uint8, device=dev)
             radii = torch.empty(N, dtype=torch.int32, device=dev)
-            # The duplicate count D is only known after the plan: plan into a bins blob sized from the
-            # last frames' D (geometric growth), and redo the plan in the rare case it overflowed.
-            cap = max(_cap_hint.get(dev.index, 0), 4 * N, 1024)
+            # Neither the duplicate count D nor the fullest coarse bin is known before the plan: plan into a bins
+            # blob sized from the previous frames (geometric growth) and redo the plan in the rare case it
+            # overflowed.
+            L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
+            ncb = max(int(sizes.coarse_bins), 1)
+            hint = _cap_hint.get(dev.index, (0, 0))
+            cap = max(hint[0], 4 * N, 1024)
+            ccap = max(hint[1], 8 * N // ncb, 256)
             while True:
-                L.check(lib.sfgs_raster_sizes(N, W, H, cap, L.C.byref(sizes)))
+                L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
                 geom = torch.empty(max(sizes.geom_bytes, 1), **u8)
                 tiles = torch.empty(sizes.tiles_bytes, **u8)
                 bins = torch.empty(max(sizes.bins_bytes, 1), **u8)
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
-                                                     bins.numel(), cap, stream))
+                                                     bins.numel(), cap, ccap, stream))
                 cnt = L.SfgsRasterCounters()
                 L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))  # the one host sync
-                D = int(cnt.num_duplicates)
-                if not cnt.overflow and D <= cap:
+                D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
+                if not cnt.overflow and D <= cap and cmax <= ccap:
                     break
-                cap = int(D * 1.25) + 1024
-            _cap_hint[dev.index] = max(int(D * 1.25) + 1024, min(cap, 2 * D + 1024))
+                cap = max(cap, int(D * 1.25) + 1024)
+                ccap = max(ccap, int(cmax * 1.25) + 256)
+            _cap_hint[dev.index] = (max(int(D * 1.25) + 1024, min(cap, 2 * D + 1024)),
+                                    max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
+            _last_counters.clear()
             _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
-                                  num_visible=int(cnt.num_visible), max_tile_list=int(cnt.max_tile_list),
-                                  N=N, W=W, H=H, dup_capacity=cap)
+                                  num_visible=int(cnt.num_visible), max_coarse_bin=cmax, N=N, W=W, H=H,
+                                  dup_capacity=cap, coarse_capacity=ccap, _tiles=tiles, _stream_dev=dev)
             need_bwd = any(ctx.needs_input_grad[:7])
             image = torch.empty(sizes.image_bytes, **u8) if need_bwd else None
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins),
-                                                   bins.numel(), cap, D, L.ptr(color), L.ptr(depth), L.ptr(alpha),
+                                                   bins.numel(), cap, ccap, D, L.ptr(color), L.ptr(depth), L.ptr(alpha),
                                                    L.ptr(image), 0 if image is None else image.numel(), stream))
         norm = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(radii, norm)
         if need_bwd:
-            ctx.settings, ctx.D, ctx.sh_coeffs = settings, cap, sh_coeffs
+            ctx.settings, ctx.D, ctx.ccap, ctx.sh_coeffs = settings, cap, ccap, sh_coeffs
             ctx.keep = keep
             ctx.has_colors, ctx.has_shs = colors_precomp is not None, shs is not None
             ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, geom, tiles, bins,
@@ -180,14 +197,14 @@ class _Rasterize(torch.autograd.Function):
             grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
                                         L.ptr(g_scales), L.ptr(g_rot), L.ptr(g_opac), L.ptr(g_col), L.ptr(g_shs))
             sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
-            L.check(lib.sfgs_raster_sizes(N, int(settings.image_width), int(settings.image_height), D,
+            L.check(lib.sfgs_raster_sizes(N, int(settings.image_width), int(settings.image_height), D, ctx.ccap,
                                           L.C.byref(sizes)))
             dupgrad = torch.empty(max(sizes.dupgrad_bytes, 1), dtype=torch.uint8, device=dev)
             gc = None if g_color is None else g_color.contiguous().float()
             gd = None if g_depth is None else g_depth.contiguous().float()
             ga = None if g_alpha is None else g_alpha.contiguous().float()
             L.check(lib.sfgs_raster_backward(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom), L.ptr(tiles),
-                                             L.ptr(bins), D, L.ptr(image), L.ptr(gc), L.ptr(gd), L.ptr(ga),
+                                             L.ptr(bins), D, ctx.ccap, L.ptr(image), L.ptr(gc), L.ptr(gd), L.ptr(ga),
                                              L.ptr(dupgrad), dupgrad.numel(), L.C.byref(grads), stream))
         return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None
 

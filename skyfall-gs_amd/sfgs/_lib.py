@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsfgs.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -36,12 +36,13 @@ class SfgsGaussianGrads(C.Structure):
 
 class SfgsRasterSizes(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("geom_bytes", C.c_size_t), ("tiles_bytes", C.c_size_t),
-                ("bins_bytes", C.c_size_t), ("image_bytes", C.c_size_t), ("dupgrad_bytes", C.c_size_t)]
+                ("bins_bytes", C.c_size_t), ("image_bytes", C.c_size_t), ("dupgrad_bytes", C.c_size_t),
+                ("coarse_bins", C.c_int64)]
 
 
 class SfgsRasterCounters(C.Structure):
     _fields_ = [("num_duplicates", C.c_int64), ("num_duplicates_ref", C.c_int64), ("num_visible", C.c_int64),
-                ("max_tile_list", C.c_int64), ("overflow", C.c_int64)]
+                ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64)]
 
 
 # every symbol include/sfgs.h declares: name -> (restype, argtypes)
@@ -53,14 +54,14 @@ SYMBOLS = {
     "sfgs_profile_kernel_count": (C.c_int, []),
     "sfgs_profile_kernel_name": (C.c_char_p, [_I32]),
     "sfgs_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
-    "sfgs_raster_sizes": (C.c_int, [_I32, _I32, _I32, _I64, C.POINTER(SfgsRasterSizes)]),
+    "sfgs_raster_sizes": (C.c_int, [_I32, _I32, _I32, _I64, _I64, C.POINTER(SfgsRasterSizes)]),
     "sfgs_raster_forward_plan": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _V, _SZ, _V, _SZ,
-                                            _I64, _V]),
+                                            _I64, _I64, _V]),
     "sfgs_raster_read_counters": (C.c_int, [_V, C.POINTER(SfgsRasterCounters), _V]),
-    "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _I64, _V, _V, _V, _V,
-                                              _SZ, _V]),
-    "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _V, _V,
-                                        _V, _V, _V, _SZ, C.POINTER(SfgsGaussianGrads), _V]),
+    "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _I64, _I64, _V, _V, _V,
+                                              _V, _SZ, _V]),
+    "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _I64, _V,
+                                        _V, _V, _V, _V, _SZ, C.POINTER(SfgsGaussianGrads), _V]),
     "sfgs_ssim_scratch_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32]),
     "sfgs_ssim_forward": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _V, _V, _V, _SZ, _I32, _V]),
     "sfgs_ssim_backward": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _V, _V, _V, _V]),

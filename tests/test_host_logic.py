@@ -96,19 +96,20 @@ def test_struct_layouts_match_the_c_header(tmp_path):
 def test_gpu_free_entry_points_and_error_convention():
     lib = L.load()
     sizes = L.SfgsRasterSizes(C.sizeof(L.SfgsRasterSizes))
-    assert lib.sfgs_raster_sizes(2_000_000, 1920, 1080, 7_000_000, C.byref(sizes)) == 0
-    assert sizes.geom_bytes >= 2_000_000 * 56 and sizes.bins_bytes >= 7_000_000 * 40
+    assert lib.sfgs_raster_sizes(2_000_000, 1920, 1080, 7_000_000, 8192, C.byref(sizes)) == 0
+    assert sizes.geom_bytes >= 2_000_000 * 56 and sizes.bins_bytes >= 7_000_000 * 24 + sizes.coarse_bins * 8192 * 16
+    assert sizes.coarse_bins == 60 * 34
     assert sizes.dupgrad_bytes == 7_000_000 * 48 and sizes.image_bytes >= 1920 * 1080 * 12
     # errors: negative status + thread-local message, never an exception or exit
     bad = L.SfgsRasterSizes(4)
-    assert lib.sfgs_raster_sizes(10, 64, 64, 0, C.byref(bad)) == -1
+    assert lib.sfgs_raster_sizes(10, 64, 64, 0, 0, C.byref(bad)) == -1
     assert b"struct_size" in lib.sfgs_last_error()
-    assert lib.sfgs_raster_sizes(-1, 64, 64, 0, C.byref(sizes)) == -1
-    assert lib.sfgs_raster_sizes(10, 64, 64, 1 << 33, C.byref(sizes)) == -4  # > 2^32 duplicates unsupported
+    assert lib.sfgs_raster_sizes(-1, 64, 64, 0, 0, C.byref(sizes)) == -1
+    assert lib.sfgs_raster_sizes(10, 64, 64, 1 << 33, 0, C.byref(sizes)) == -4  # > 2^32 duplicates unsupported
     with pytest.raises(RuntimeError, match="libsfgs error"):
-        L.check(lib.sfgs_raster_sizes(-1, 64, 64, 0, C.byref(sizes)))
+        L.check(lib.sfgs_raster_sizes(-1, 64, 64, 0, 0, C.byref(sizes)))
     # a NULL frame is rejected before any HIP call
-    assert lib.sfgs_raster_forward_plan(None, None, None, None, 0, None, 0, None, 0, 0, None) == -1
+    assert lib.sfgs_raster_forward_plan(None, None, None, None, 0, None, 0, None, 0, 0, 0, None) == -1
     assert lib.sfgs_ssim_scratch_bytes(1, 3, 1080, 1920, 1) > 3 * 3 * 1080 * 1920 * 4
     assert lib.sfgs_knn_scratch_bytes(1000) == 0
     assert lib.sfgs_profile_kernel_count() >= 10 and lib.sfgs_profile_kernel_name(1) == b"preprocess"
