@@ -355,28 +355,48 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const uint2 tr = tile_range[t];
   const unsigned s = tr.x, e = tr.x + tr.y;
   PixelFwd ps;
-  ps.T = 1.f; ps.C0 = ps.C1 = ps.C2 = ps.D = 0.f; ps.last = 0; ps.done = !inside;
+  pixel_fwd_init(ps, inside);
   float4* st = stage[wave];
+  // Software pipeline over batches of 64 list entries: the (dependent) id -> record gathers of batch i+1
+  // are issued before batch i is composited, so their latency hides behind ~1600 VALU instructions.
+  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+  unsigned id_next = 0;
+  if (s + lane < e) {
+    const unsigned id = sorted_id[s + lane];
+    n0 = rec[3 * (size_t)id]; n1 = rec[3 * (size_t)id + 1]; n2 = rec[3 * (size_t)id + 2];
+  }
+  if (s + 64 + lane < e) id_next = sorted_id[s + 64 + lane];
   for (unsigned b = s; b < e; b += 64) {
-    if (__ballot(!ps.done) == 0ull) break;
+    if (__ballot(ps.T > 0.f) == 0ull) break;  // every pixel of the tile is saturated
     const unsigned cnt = min(64u, e - b);
-    if ((unsigned)lane < cnt) {
-      const unsigned id = sorted_id[b + lane];
-      const float4 a0 = rec[3 * (size_t)id], a1 = rec[3 * (size_t)id + 1], a2 = rec[3 * (size_t)id + 2];
-      st[lane * 3] = a0; st[lane * 3 + 1] = a1; st[lane * 3 + 2] = a2;
+    st[lane * 3] = n0; st[lane * 3 + 1] = n1; st[lane * 3 + 2] = n2;
+    if (b + 64 + lane < e) {  // prefetch: records of the next batch, ids of the one after
+      n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2];
     }
+    if (b + 128 + lane < e) id_next = sorted_id[b + 128 + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (unsigned j = 0; j < cnt; ++j) {
+    const unsigned k0 = b - s;
+    unsigned j = 0;
+    for (; j + 4 <= cnt; j += 4) {  // 4 entries per early-exit check
+#pragma unroll
+      for (unsigned u = 0; u < 4; ++u) {
+        const float4 r0 = st[(j + u) * 3], r1 = st[(j + u) * 3 + 1];
+        const float2 r2 = *reinterpret_cast<const float2*>(&st[(j + u) * 3 + 2]);
+        const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
+        pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, k0 + j + u);
+      }
+      if (__ballot(ps.T > 0.f) == 0ull) break;
+    }
+    for (; j < cnt; ++j) {
       const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
       const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
       const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-      pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, b - s + j);
-      if (__ballot(!ps.done) == 0ull) break;
+      pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, k0 + j);
     }
     __builtin_amdgcn_wave_barrier();
   }
-  const float T = ps.T, C0 = ps.C0, C1 = ps.C1, C2 = ps.C2, D = ps.D;
+  const float T = ps.T_out, C0 = ps.C0, C1 = ps.C1, C2 = ps.C2, D = ps.D;
   const unsigned last = ps.last;
   if (inside) {
     const size_t P = (size_t)W * H;

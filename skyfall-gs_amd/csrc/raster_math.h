@@ -400,24 +400,29 @@ SFGS_HD SplatEval eval_splat(float mx, float my, float qa, float qb, float qc, f
 }
 
 struct PixelFwd {
-  float T, C0, C1, C2, D;
-  unsigned last;
-  bool done;
+  float T;       // live transmittance; becomes 0 when the pixel saturates (then nothing can be accepted any more)
+  float T_out;   // transmittance after the last ACCEPTED splat = the reference's final T
+  float C0, C1, C2, D;
+  unsigned last; // 1-based list position of the last accepted splat
 };
 
-// k = 0-based list position. Returns nothing; updates the pixel state.
+SFGS_HD void pixel_fwd_init(PixelFwd& s, bool inside) {
+  s.T = inside ? 1.f : 0.f; s.T_out = 1.f;
+  s.C0 = s.C1 = s.C2 = s.D = 0.f; s.last = 0;
+}
+
+// k = 0-based list position. Branch-free restatement of SURVEY A.4:
+//   skip if power > 0 or alpha < 1/255;  stop (splat NOT applied) if T (1 - alpha) < 1e-4;  else blend.
+// A stopped pixel keeps T = 0, so every later splat "stops" again and nothing is accumulated.
 SFGS_HD void pixel_fwd_step(PixelFwd& s, const SplatEval& e, float depth, float r, float g, float b, unsigned k) {
   const float test_T = s.T * (1.0f - e.alpha);
-  const bool hit = !s.done && e.ok;
-  const bool stop = hit && test_T < 0.0001f;
-  s.done = s.done || stop;
-  if (hit && !stop) {
-    const float w = e.alpha * s.T;
-    s.C0 = fmaf(r, w, s.C0); s.C1 = fmaf(g, w, s.C1); s.C2 = fmaf(b, w, s.C2);
-    s.D = fmaf(depth, w, s.D);
-    s.T = test_T;
-    s.last = k + 1;
-  }
+  const bool acc = e.ok && !(test_T < 0.0001f);
+  const float w = acc ? e.alpha * s.T : 0.f;
+  s.C0 = fmaf(r, w, s.C0); s.C1 = fmaf(g, w, s.C1); s.C2 = fmaf(b, w, s.C2);
+  s.D = fmaf(depth, w, s.D);
+  s.T_out = acc ? test_T : s.T_out;
+  s.last = acc ? k + 1 : s.last;
+  s.T = acc ? test_T : (e.ok ? 0.f : s.T);
 }
 
 struct PixelBwd {

@@ -87,19 +87,20 @@ int hc_render(const HcFrame* hf, int32_t N, const float* means, const float* sca
       float sx = (float)px, sy = (float)py;
       if (hf->subpix) { sx += hf->subpix[pix * 2]; sy += hf->subpix[pix * 2 + 1]; }
       const auto& l = lists[(size_t)(py / 8) * TX8 + px / 8];
-      PixelFwd ps; ps.T = 1.f; ps.C0 = ps.C1 = ps.C2 = ps.D = 0.f; ps.last = 0; ps.done = false;
-      for (size_t k = 0; k < l.size() && !ps.done; ++k) {
+      PixelFwd ps;
+      pixel_fwd_init(ps, true);
+      for (size_t k = 0; k < l.size(); ++k) {
         const SplatRec& r = rec[dup_gauss[(uint32_t)(l[k] & 0xffffffffull)]];
         const SplatEval ev = eval_splat(r.mx, r.my, r.qa, r.qb, r.qc, r.op, sx, sy);
         pixel_fwd_step(ps, ev, r.depth, r.r, r.g, r.b, (unsigned)k);
       }
-      out_color[pix] = fmaf(ps.T, f.bg[0], ps.C0);
-      out_color[P + pix] = fmaf(ps.T, f.bg[1], ps.C1);
-      out_color[2 * P + pix] = fmaf(ps.T, f.bg[2], ps.C2);
-      const float a = 1.0f - ps.T;
+      out_color[pix] = fmaf(ps.T_out, f.bg[0], ps.C0);
+      out_color[P + pix] = fmaf(ps.T_out, f.bg[1], ps.C1);
+      out_color[2 * P + pix] = fmaf(ps.T_out, f.bg[2], ps.C2);
+      const float a = 1.0f - ps.T_out;
       out_alpha[pix] = a;
       out_depth[pix] = f.depth_mode == 0 ? ps.D / a : ps.D;
-      n_contrib[pix] = ps.last; final_T[pix] = ps.T; dacc[pix] = ps.D;
+      n_contrib[pix] = ps.last; final_T[pix] = ps.T_out; dacc[pix] = ps.D;
     }
   if (!g_means3D) return 0;
 
