@@ -176,7 +176,7 @@ plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, con
 __global__ void __launch_bounds__(256)
 fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ coarse_count,
                 const uint4* __restrict__ slabs, unsigned coarse_capacity, uint2* __restrict__ tile_range,
-                uint4* __restrict__ items, unsigned long long* __restrict__ hdr) {
+                uint4* __restrict__ items, uint32_t* __restrict__ long_tiles, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_cnt[4][COARSE_TILES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cb = blockIdx.x * 4 + wave;
@@ -206,7 +206,10 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
   __builtin_amdgcn_wave_barrier();
   if (lane < COARSE_TILES) {
     const int tx = (cb % CX) * COARSE + (lane & (COARSE - 1)), ty = (cb / CX) * COARSE + (lane / COARSE);
-    if (tx < TX8 && ty < TY8) tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
+    if (tx < TX8 && ty < TY8) {
+      tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
+      if (c > 512) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
+    }
     cnt[lane] = off;  // becomes the per-tile cursor
     if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
   }
@@ -226,24 +229,145 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4a: per-tile sort for lists of up to 512 entries, entirely in registers. One wave per tile; element
+// (lane, r) of the wave carries label e = lane * EPL + r. Normalised bitonic network: for every size the
+// first step pairs e with e ^ (size - 1), the following steps with e ^ stride; the lower label keeps the
+// smaller key. Label bits below log2(EPL) are register indices (compile-time), the bits above are lane
+// bits: those exchanges are cross-lane shuffles (3 per element: key hi/lo + payload). No LDS traffic, no
+// bank conflicts, no barriers. Keys: (depth bits << 32 | Gaussian id) == SURVEY A.3 order.
+// value of lane (l ^ K): DPP where the hardware has the permutation (no LDS latency), the LDS crossbar
+// (ds_swizzle / ds_bpermute) otherwise.
+template <int K>
+__device__ __forceinline__ unsigned xor_shuffle(unsigned v) {
+  if constexpr (K == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+  else if constexpr (K == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+  else if constexpr (K == 3) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xf, 0xf, false);  // quad_perm [3,2,1,0]
+  else if constexpr (K == 7) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror
+  else if constexpr (K == 15) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false); // row_mirror
+  else if constexpr (K < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (K << 10) | 0x1f);           // bit mode: xor K
+  else return (unsigned)__shfl_xor((int)v, K);
+}
+
+template <int EPL, int SIZE, int STEP>
+__device__ __forceinline__ void bitonic_stage(unsigned long long (&key)[EPL], unsigned (&pay)[EPL], int lane) {
+  constexpr int mask = STEP == 0 ? SIZE - 1 : (SIZE >> (STEP + 1));
+  constexpr int rmask = mask & (EPL - 1);   // register-index part of the label
+  constexpr int lmask = mask / EPL;         // lane part
+  if constexpr (lmask == 0) {
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const int q = r ^ rmask;
+      if (q > r) {
+        const bool sw = key[q] < key[r];
+        const unsigned long long kr = key[r], kq = key[q];
+        const unsigned pr = pay[r], pq = pay[q];
+        key[r] = sw ? kq : kr; key[q] = sw ? kr : kq;
+        pay[r] = sw ? pq : pr; pay[q] = sw ? pr : pq;
+      }
+    }
+  } else {
+    const bool upper = (lane & (lmask & ~(lmask >> 1))) != 0;  // highest bit of the mask decides who is lower
+    unsigned long long nk[EPL];
+    unsigned np[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const int q = r ^ rmask;  // partner's register index
+      const unsigned hi = xor_shuffle<lmask>((unsigned)(key[q] >> 32));
+      const unsigned lo = xor_shuffle<lmask>((unsigned)(key[q] & 0xffffffffull));
+      const unsigned pp = xor_shuffle<lmask>(pay[q]);
+      const unsigned long long theirs = ((unsigned long long)hi << 32) | lo;
+      const bool take = (theirs < key[r]) != upper;  // the lower label keeps the minimum, the upper the maximum
+      nk[r] = take ? theirs : key[r];
+      np[r] = take ? pp : pay[r];
+    }
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) { key[r] = nk[r]; pay[r] = np[r]; }
+  }
+}
+
+template <int EPL, int SIZE, int STEP>
+__device__ __forceinline__ void bitonic_steps(unsigned long long (&key)[EPL], unsigned (&pay)[EPL], int lane) {
+  if constexpr (STEP == 0 || (SIZE >> (STEP + 1)) >= 1) {
+    bitonic_stage<EPL, SIZE, STEP>(key, pay, lane);
+    bitonic_steps<EPL, SIZE, STEP + 1>(key, pay, lane);
+  }
+}
+
+template <int EPL, int SIZE>
+__device__ __forceinline__ void bitonic_sizes(unsigned long long (&key)[EPL], unsigned (&pay)[EPL], int lane) {
+  if constexpr (SIZE <= 64 * EPL) {
+    bitonic_steps<EPL, SIZE, 0>(key, pay, lane);
+    bitonic_sizes<EPL, SIZE * 2>(key, pay, lane);
+  }
+}
+
+template <int EPL>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&key)[EPL], unsigned (&pay)[EPL], int lane) {
+  bitonic_sizes<EPL, 2>(key, pay, lane);
+}
+
+template <int EPL>
+__device__ __forceinline__ void sort_tile_in_registers(unsigned s, int L, int lane, const uint4* __restrict__ items,
+                                                       uint32_t* __restrict__ sorted_id,
+                                                       uint32_t* __restrict__ sorted_dup) {
+  unsigned long long key[EPL];
+  unsigned pay[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) {  // coalesced (striped) load: the network sorts any initial arrangement
+    const int i = r * 64 + lane;
+    key[r] = ~0ull; pay[r] = 0u;
+    if (i < L) {
+      const uint4 it = items[s + i];
+      key[r] = ((unsigned long long)it.y << 32) | it.x;
+      pay[r] = it.z;
+    }
+  }
+  wave_bitonic_sort<EPL>(key, pay, lane);
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) {
+    const int e = lane * EPL + r;
+    if (e < L) {
+      sorted_id[s + e] = (unsigned)(key[r] & 0xffffffffull);
+      sorted_dup[s + e] = pay[r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4* __restrict__ items,
+                      uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= T8) return;
+  const uint2 tr = tile_range[t];
+  const int L = (int)tr.y;
+  if (L == 0 || L > 512) return;
+  if (L <= 64) sort_tile_in_registers<1>(tr.x, L, lane, items, sorted_id, sorted_dup);
+  else if (L <= 128) sort_tile_in_registers<2>(tr.x, L, lane, items, sorted_id, sorted_dup);
+  else if (L <= 256) sort_tile_in_registers<4>(tr.x, L, lane, items, sorted_id, sorted_dup);
+  else sort_tile_in_registers<8>(tr.x, L, lane, items, sorted_id, sorted_dup);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4: per-tile sort by 64-bit key (depth bits << 32 | Gaussian id) == ascending (depth, Gaussian id),
 // SURVEY A.3. Normalised bitonic network: every comparator sorts ascending, so +inf padding stays at
 // the tail. One wave per tile, keys + 16-bit local payload indices in LDS.
 template <int CAP>
 __global__ void __launch_bounds__(64)
-sort_tiles_lds_kernel(int T8, int lo, int hi, const uint2* __restrict__ tile_range,
+sort_tiles_lds_kernel(int lo, int hi, const uint32_t* __restrict__ long_tiles,
+                      const unsigned long long* __restrict__ hdr, const uint2* __restrict__ tile_range,
                       const uint4* __restrict__ items, uint32_t* __restrict__ sorted_id,
                       uint32_t* __restrict__ sorted_dup) {
   __shared__ unsigned long long k[CAP];
   __shared__ uint32_t dups[CAP];
   __shared__ unsigned short vi[CAP];
-  const int t = blockIdx.x;
-  if (t >= T8) return;
-  const uint2 tr = tile_range[t];
+  const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
+  for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
+  const uint2 tr = tile_range[long_tiles[li]];
   const unsigned s = tr.x, e = tr.x + tr.y;
   const int L = (int)(e - s);
-  if (L <= lo || L > hi) return;
+  if (L <= lo || L > hi) continue;
   const int lane = threadIdx.x;
+  __syncthreads();
   int n = 1;
   while (n < L) n <<= 1;
   for (int i = lane; i < n; i += 64) {
@@ -279,20 +403,23 @@ sort_tiles_lds_kernel(int T8, int lo, int hi, const uint2* __restrict__ tile_ran
     sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull);
     sorted_dup[s + i] = dups[vi[i]];
   }
+  }
 }
 
 // Long lists: same network on the tile's segment of 16-byte items in global memory (virtual padding:
 // comparators that reach past the end are no-ops). Rare path; agent-scope relaxed accesses bypass the
 // per-CU L1 so that waves of the block see each other's exchanges after the barrier.
 __global__ void __launch_bounds__(256)
-sort_tiles_global_kernel(int T8, int lo, const uint2* __restrict__ tile_range, uint4* items,
-                         uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
-  const int t = blockIdx.x;
-  if (t >= T8) return;
-  const uint2 tr = tile_range[t];
+sort_tiles_global_kernel(int lo, const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
+                         const uint2* __restrict__ tile_range, uint4* items, uint32_t* __restrict__ sorted_id,
+                         uint32_t* __restrict__ sorted_dup) {
+  const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
+  for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
+  const uint2 tr = tile_range[long_tiles[li]];
   const unsigned s = tr.x, e = tr.x + tr.y;
   const long long L = (long long)e - s;
-  if (L <= lo) return;
+  if (L <= lo) continue;
+  __syncthreads();
   unsigned long long* w = reinterpret_cast<unsigned long long*>(items + s);  // item i = words 2i (key), 2i+1 (dup)
   long long n = 1;
   while (n < L) n <<= 1;
@@ -326,6 +453,7 @@ sort_tiles_global_kernel(int T8, int lo, const uint2* __restrict__ tile_range, u
   for (long long i = threadIdx.x; i < L; i += 256) {
     sorted_id[s + i] = (unsigned)(ld(2 * i) & 0xffffffffull);
     sorted_dup[s + i] = (unsigned)(ld(2 * i + 1) & 0xffffffffull);
+  }
   }
 }
 
@@ -548,20 +676,20 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
   { ProfScope ps_(KID_FINE_BIN, stream);
     hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)((NCB + 3) / 4)), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
-                       tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, tv.tile_range, bv.items, tv.hdr); }
+                       tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr); }
   SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
   if (num_duplicates > 0) {
     { ProfScope ps_(KID_SORT_SMALL, stream);
-      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_SMALL>, dim3(T8), dim3(64), 0, stream, T8, 0, SORT_SMALL,
-                         tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
+      hipLaunchKernelGGL(sort_tiles_reg_kernel, dim3((T8 + 3) / 4), dim3(256), 0, stream, T8, tv.tile_range, bv.items,
+                         bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
     { ProfScope ps_(KID_SORT_MEDIUM, stream);
-      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(T8), dim3(64), 0, stream, T8, SORT_SMALL, SORT_CAP,
-                         tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
+      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(256), dim3(64), 0, stream, SORT_SMALL, SORT_CAP,
+                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
     { ProfScope ps_(KID_SORT_GLOBAL, stream);
-      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(T8), dim3(256), 0, stream, T8, SORT_CAP, tv.tile_range,
-                         bv.items, bv.sorted_id, bv.sorted_dup); }
+      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(64), dim3(256), 0, stream, SORT_CAP, tv.long_tiles, tv.hdr,
+                         tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_global", stream, frame->debug);
   }
   ImageView iv = {nullptr, nullptr, nullptr};

@@ -110,7 +110,8 @@ enum HeaderSlot {
   HDR_OVERFLOW = 4,   // set by preprocess when dup_capacity / coarse_capacity is too small (redo the plan)
   HDR_SUBPIX_BOUND = 5,  // float bits of max |subpixel_offset| (0 when none)
   HDR_ITEM_ALLOC = 6,    // list-slot allocator of the fine-binning kernel
-  HDR_MAX_COARSE = 7     // fullest coarse bin (sizes coarse_capacity for the next frame)
+  HDR_MAX_COARSE = 7,    // fullest coarse bin (sizes coarse_capacity for the next frame)
+  HDR_LONG_COUNT = 8     // tiles whose list is too long for the register sort (> 512 entries)
 };
 
 struct GeomView {
@@ -139,6 +140,7 @@ struct TilesView {
   uint32_t* coarse_count;   // [NCB * CC_STRIDE] items appended to every coarse bin, one counter per 128 bytes
                             //                   (zeroed by plan; keeps counting past capacity)
   uint2* tile_range;        // [T8] (first list slot, list length) of every 8x8 tile
+  uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
@@ -159,6 +161,7 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   t.coarse_count = (uint32_t*)(p + off); off += align_up((size_t)NCB * CC_STRIDE * 4, 256);
   t.zero_bytes = off;
   t.tile_range = (uint2*)(p + off); off += align_up((size_t)T8 * 8, 256);
+  t.long_tiles = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
   if (total) *total = off;
