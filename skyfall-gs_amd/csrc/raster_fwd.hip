@@ -170,52 +170,48 @@ plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: fine binning. One wave per coarse bin (4 per workgroup, no barriers): count the bin's 16 tiles with LDS
-// atomics, reserve the bin's list slots with ONE device atomic, publish (start, length) of its tiles, then
-// expand every coarse item into its per-tile duplicates: items[slot] = (id, depth, dup index, 0).
+// K3: fine binning. One 256-thread workgroup per coarse bin: count the bin's 16 tiles with LDS atomics,
+// reserve the bin's list slots with ONE device atomic, publish (start, length) of its tiles, then expand
+// every coarse item into its per-tile duplicates: items[slot] = (id, depth, dup index, 0).
 __global__ void __launch_bounds__(256)
 fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ coarse_count,
                 const uint4* __restrict__ slabs, unsigned coarse_capacity, uint2* __restrict__ tile_range,
                 uint4* __restrict__ items, uint32_t* __restrict__ long_tiles, unsigned long long* __restrict__ hdr) {
-  __shared__ unsigned s_cnt[4][COARSE_TILES];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cb = blockIdx.x * 4 + wave;
-  if (cb >= NCB) return;
-  unsigned* cnt = s_cnt[wave];
+  __shared__ unsigned cnt[COARSE_TILES];
+  __shared__ unsigned long long s_base;
+  const int cb = blockIdx.x, tid = threadIdx.x;
   const unsigned n = min(coarse_count[(size_t)cb * CC_STRIDE], coarse_capacity);
   const uint4* slab = slabs + (size_t)cb * coarse_capacity;
-  if (lane < COARSE_TILES) cnt[lane] = 0;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (unsigned i = lane; i < n; i += 64) {
+  if (tid < COARSE_TILES) cnt[tid] = 0;
+  __syncthreads();
+  for (unsigned i = tid; i < n; i += 256) {
     unsigned m = slab[i].w;
     while (m) { const int b = __builtin_ctz(m); m &= m - 1; atomicAdd(&cnt[b], 1u); }
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // exclusive scan of the 16 counts (lanes 0..15), one allocation for the whole bin
-  const unsigned c = lane < COARSE_TILES ? cnt[lane] : 0u;
-  unsigned incl = c;
+  __syncthreads();
+  if (tid < 64) {  // first wave: exclusive scan of the 16 counts, one allocation for the whole bin
+    const unsigned c = tid < COARSE_TILES ? cnt[tid] : 0u;
+    unsigned incl = c;
 #pragma unroll
-  for (int d = 1; d < COARSE_TILES; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-  const unsigned total = __shfl(incl, COARSE_TILES - 1);
-  unsigned long long base = 0;
-  if (lane == 0 && total) base = atomicAdd(&hdr[HDR_ITEM_ALLOC], (unsigned long long)total);
-  base = __shfl(base, 0);
-  const unsigned off = incl - c;
-  __builtin_amdgcn_wave_barrier();
-  if (lane < COARSE_TILES) {
-    const int tx = (cb % CX) * COARSE + (lane & (COARSE - 1)), ty = (cb / CX) * COARSE + (lane / COARSE);
-    if (tx < TX8 && ty < TY8) {
-      tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
-      if (c > 512) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
+    for (int d = 1; d < COARSE_TILES; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (tid >= d) incl += t; }
+    const unsigned total = __shfl(incl, COARSE_TILES - 1);
+    unsigned long long base = 0;
+    if (tid == 0) { if (total) base = atomicAdd(&hdr[HDR_ITEM_ALLOC], (unsigned long long)total); s_base = base; }
+    base = __shfl(base, 0);
+    const unsigned off = incl - c;
+    if (tid < COARSE_TILES) {
+      const int tx = (cb % CX) * COARSE + (tid & (COARSE - 1)), ty = (cb / CX) * COARSE + (tid / COARSE);
+      if (tx < TX8 && ty < TY8) {
+        tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
+        if (c > 512) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
+      }
+      cnt[tid] = off;  // becomes the per-tile cursor
+      if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
     }
-    cnt[lane] = off;  // becomes the per-tile cursor
-    if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (unsigned i = lane; i < n; i += 64) {
+  __syncthreads();
+  const unsigned long long base = s_base;
+  for (unsigned i = tid; i < n; i += 256) {
     const uint4 it = slab[i];
     unsigned m = it.w, dup = it.z;
     while (m) {
@@ -675,7 +671,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const KFrame kf = make_kframe(frame);
   const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
   { ProfScope ps_(KID_FINE_BIN, stream);
-    hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)((NCB + 3) / 4)), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
+    hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
                        tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr); }
   SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
   if (num_duplicates > 0) {
