@@ -44,6 +44,29 @@ __device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, co
   return m;
 }
 
+constexpr int BIG_WALK = 16;  // coarse bins above which a splat's walk is done by the whole wave
+
+struct WalkArgs { SplatRec r; BinRange br; float thr; int cx0, cx1, cy0, cy1; };
+
+// lane L's walk parameters, broadcast to the wave
+__device__ __forceinline__ WalkArgs broadcast_walk(const SplatRec& r, const BinRange& br, float thr, int cx0, int cx1,
+                                                  int cy0, int cy1, int L) {
+  WalkArgs a;
+  a.r.mx = __shfl(r.mx, L); a.r.my = __shfl(r.my, L); a.r.qa = __shfl(r.qa, L); a.r.qb = __shfl(r.qb, L);
+  a.r.qc = __shfl(r.qc, L); a.r.op = __shfl(r.op, L); a.r.depth = 0.f; a.r.r = a.r.g = a.r.b = 0.f;
+  a.r.ex = __shfl(r.ex, L); a.r.ey = __shfl(r.ey, L);
+  a.br.x0 = __shfl(br.x0, L); a.br.x1 = __shfl(br.x1, L); a.br.y0 = __shfl(br.y0, L); a.br.y1 = __shfl(br.y1, L);
+  a.thr = __shfl(thr, L);
+  a.cx0 = __shfl(cx0, L); a.cx1 = __shfl(cx1, L); a.cy0 = __shfl(cy0, L); a.cy1 = __shfl(cy1, L);
+  return a;
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += (unsigned)__shfl_xor((int)v, d);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: one thread per Gaussian: project, write radii + the compositing record, and bin COARSELY.
 // The thread walks the coarse bins (32x32 px) its splat can reach; for each it computes the 16-bit mask of
@@ -67,6 +90,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const int CX = (((f.W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
   unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
   unsigned long long cached = 0ull;  // masks of the first four coarse bins of the walk (16 bits each)
+  bool big = false;                  // walk handled cooperatively by the wave
+  const int lane = threadIdx.x & 63;
   SplatRec r;
   BinRange br;
   float thr = 0.f;
@@ -100,15 +125,34 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       if (br.x1 > br.x0 && br.y1 > br.y0) {
         cx0 = br.x0 / COARSE; cx1 = (br.x1 - 1) / COARSE + 1;
         cy0 = br.y0 / COARSE; cy1 = (br.y1 - 1) / COARSE + 1;
-        int k = 0;
-        for (int cy = cy0; cy < cy1; ++cy)
-          for (int cx = cx0; cx < cx1; ++cx, ++k) {
-            const unsigned m = coarse_hits(r, thr, br, cx, cy, f.W, f.H, bound);
-            if (k < 4) cached |= (unsigned long long)m << (16 * k);
-            n_dup += (unsigned)__popc(m);
-          }
+        big = (cx1 - cx0) * (cy1 - cy0) > BIG_WALK;
+        if (!big) {
+          int k = 0;
+          for (int cy = cy0; cy < cy1; ++cy)
+            for (int cx = cx0; cx < cx1; ++cx, ++k) {
+              const unsigned m = coarse_hits(r, thr, br, cx, cy, f.W, f.H, bound);
+              if (k < 4) cached |= (unsigned long long)m << (16 * k);
+              n_dup += (unsigned)__popc(m);
+            }
+        }
       }
     }
+  }
+  // Splats that reach many coarse bins (near or huge: up to the whole screen) are walked by the whole wave,
+  // one coarse bin per lane, instead of serially by their owner thread.
+  const unsigned long long big_lanes = __ballot(big);
+  for (unsigned long long bl = big_lanes; bl; bl &= bl - 1) {
+    const int L = __builtin_ctzll(bl);
+    const WalkArgs a = broadcast_walk(r, br, thr, cx0, cx1, cy0, cy1, L);
+    const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
+    unsigned total = 0;
+    for (int i0 = 0; i0 < ncb; i0 += 64) {
+      const int i = i0 + lane;
+      unsigned c = 0;
+      if (i < ncb) c = (unsigned)__popc(coarse_hits(a.r, a.thr, a.br, a.cx0 + i % nx, a.cy0 + i / nx, f.W, f.H, bound));
+      total += wave_sum_u32(c);
+    }
+    if (lane == L) n_dup = total;
   }
   // reserve duplicate indices: block scan + one returning atomic per block
   unsigned total;
@@ -119,7 +163,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const bool fits = base + total <= dup_capacity;
   if (!fits && threadIdx.x == 0) hdr[HDR_OVERFLOW] = 1ull;
   if (g < N) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
-  if (fits && n_dup) {
+  if (fits && n_dup && !big) {
     unsigned dup = (unsigned)(base + ex);
     int k = 0;
     for (int cy = cy0; cy < cy1; ++cy)
@@ -133,6 +177,31 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
           dup += (unsigned)__popc(m);
         }
       }
+  }
+  for (unsigned long long bl = fits ? big_lanes : 0ull; bl; bl &= bl - 1) {  // cooperative emission (fits is block-uniform)
+    const int L = __builtin_ctzll(bl);
+    const WalkArgs a = broadcast_walk(r, br, thr, cx0, cx1, cy0, cy1, L);
+    const unsigned g_L = (unsigned)__shfl((int)g, L), depth_L = __shfl(depth_bits, L);
+    unsigned dup = __shfl((unsigned)(base + ex), L);
+    const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
+    for (int i0 = 0; i0 < ncb; i0 += 64) {
+      const int i = i0 + lane;
+      unsigned m = 0;
+      int cb = 0;
+      if (i < ncb) {
+        const int cx = a.cx0 + i % nx, cy = a.cy0 + i / nx;
+        m = coarse_hits(a.r, a.thr, a.br, cx, cy, f.W, f.H, bound);
+        cb = cy * CX + cx;
+      }
+      const unsigned c = (unsigned)__popc(m);
+      const unsigned incl = wave_incl_scan_u32(c);
+      if (m) {
+        const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+        if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + incl - c, m);
+        else hdr[HDR_OVERFLOW] = 1ull;
+      }
+      dup += __shfl(incl, 63);
+    }
   }
   // per-block statistics (summed by plan_scan; no contended atomics)
   block_excl_scan_u32<PRE_BLOCK>(vis, &total, s_red);
