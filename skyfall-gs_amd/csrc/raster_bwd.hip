@@ -54,18 +54,25 @@ struct Phase2Acc {
 template <int I>
 __device__ __forceinline__ void phase2_step(Phase2Acc& a, float u, float w, float mx, float my, float cA, float cB,
                                             float cC, float sx, float sy, float g0, float g1, float g2, float g3) {
-  const float dx = mx - row_bcast<I>(sx), dy = my - row_bcast<I>(sy);
+  // d = m - (lane I of this row's s): the DPP row broadcast is folded into the subtract / multiply-add
+  // (hipcc keeps a separate v_mov_b32_dpp otherwise). sx, sy, g0..g3 are written once per kernel, far
+  // ahead of these reads, so the VALU-write -> DPP-read wait states are trivially satisfied.
+  float dx, dy;
+  asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(dx) : "v"(sx), "v"(mx), "n"(I));
+  asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(dy) : "v"(sy), "v"(my), "n"(I));
   const float udx = u * dx, udy = u * dy;
   a.u += u; a.x += udx; a.y += udy;
   a.ax += fabsf(u * fmaf(cA, dx, cB * dy));
   a.ay += fabsf(u * fmaf(cC, dy, cB * dx));
   a.xx = fmaf(udx, dx, a.xx); a.xy = fmaf(udx, dy, a.xy); a.yy = fmaf(udy, dy, a.yy);
-  a.r = fmaf(w, row_bcast<I>(g0), a.r); a.g = fmaf(w, row_bcast<I>(g1), a.g);
-  a.b = fmaf(w, row_bcast<I>(g2), a.b); a.d = fmaf(w, row_bcast<I>(g3), a.d);
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(I));
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(I));
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(I));
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
 }
 
 template <int B>
-__global__ void __launch_bounds__(256, 4)  // 4 waves/SIMD: <= 128 VGPRs, 4 workgroups (36 KB LDS each) per CU
+__global__ void __launch_bounds__(256, 4)
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
@@ -163,8 +170,17 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       const float* Wrow = &lds.Wm[ej * ROW + grp * B];
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
 #define SFGS_P2(I) phase2_step<I>(pa, Urow[I], Wrow[I], mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
-      SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7);
-      SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15);
+      // a rolled loop over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
+      // compiler from hoisting all 32 LDS loads above the arithmetic, which costs ~30 VGPRs
+#pragma nounroll
+      for (int c = 0; c < 4; ++c) {
+        switch (c) {
+          case 0: SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); break;
+          case 1: SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7); break;
+          case 2: SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); break;
+          default: SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15); break;
+        }
+      }
 #undef SFGS_P2
     }
     // combine the NGRP partial lanes of every entry (fixed order -> deterministic)
