@@ -158,8 +158,10 @@ int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* 
 /* Forward, stage 2 ("render"): expand the coarse items into per-tile lists (LDS-ranked), sort each
  * list by (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],
  * out_depth[1,H,W], out_alpha[1,H,W]. num_duplicates = counters.num_duplicates of the plan that
- * filled `bins` (same capacities). `image` may be NULL when no backward will follow. One render per
- * plan. Asynchronous on `stream`. */
+ * filled `bins` (same capacities), or -1 when the caller enqueues the render BEFORE reading the
+ * counters (no mid-frame host sync): an overflowing plan is memory-safe -- it drops the items that
+ * did not fit -- so the caller may read the counters after the render and redo both stages on
+ * overflow. `image` may be NULL when no backward will follow. One render per plan. Asynchronous. */
 int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
                                void* bins, size_t bins_bytes, int64_t dup_capacity,
                                int64_t coarse_capacity, int64_t num_duplicates, float* out_color,

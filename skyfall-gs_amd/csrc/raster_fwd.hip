@@ -728,7 +728,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const int64_t NCB = coarse_bins(W, H);
   SFGS_REQUIRE(N >= 0 && tiles && out_color && out_depth && out_alpha && bins, SFGS_E_ARG, "NULL argument");
   SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0, SFGS_E_ARG, "bad capacity");
-  SFGS_REQUIRE(num_duplicates >= 0 && num_duplicates <= dup_capacity, SFGS_E_CAPACITY,
+  SFGS_REQUIRE(num_duplicates <= dup_capacity, SFGS_E_CAPACITY,
                "num_duplicates %lld exceeds dup_capacity %lld: redo the plan with a larger bins blob",
                (long long)num_duplicates, (long long)dup_capacity);
   SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
@@ -743,7 +743,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
     hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
                        tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr); }
   SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
-  if (num_duplicates > 0) {
+  if (num_duplicates != 0) {  // < 0: unknown (render enqueued before the counters were read)
     { ProfScope ps_(KID_SORT_SMALL, stream);
       hipLaunchKernelGGL(sort_tiles_reg_kernel, dim3((T8 + 3) / 4), dim3(256), 0, stream, T8, tv.tile_range, bv.items,
                          bv.sorted_id, bv.sorted_dup); }

@@ -48,17 +48,8 @@ _cap_hint = {}   # device index -> (duplicate capacity, per-coarse-bin capacity)
 
 
 def last_counters():
-    """Counters of the most recent forward on this process (D_eff, D_ref, N_vis, longest list, ...): bench/tests.
-    Synchronises the device (the longest list is only known once the render stage has run)."""
-    out = {k: v for k, v in _last_counters.items() if not k.startswith("_")}
-    tiles = _last_counters.get("_tiles")
-    if tiles is not None:
-        dev = _last_counters["_stream_dev"]
-        with torch.cuda.device(dev):
-            cnt = L.SfgsRasterCounters()
-            L.check(L.load().sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), _stream(dev)))
-        out["max_tile_list"] = int(cnt.max_tile_list)
-    return out
+    """Counters of the most recent forward on this process (D_eff, D_ref, N_vis, longest list, ...): bench/tests."""
+    return dict(_last_counters)
 
 
 def _f32c(t, name, shape_tail=None):
@@ -134,16 +125,28 @@ class _Rasterize(torch.autograd.Function):
             hint = _cap_hint.get(dev.index, (0, 0))
             cap = max(hint[0], 4 * N, 1024)
             ccap = max(hint[1], 8 * N // ncb, 256)
+            need_bwd = any(ctx.needs_input_grad[:7])
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             while True:
                 L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
                 geom = torch.empty(max(sizes.geom_bytes, 1), **u8)
                 tiles = torch.empty(sizes.tiles_bytes, **u8)
                 bins = torch.empty(max(sizes.bins_bytes, 1), **u8)
+                image = torch.empty(sizes.image_bytes, **u8) if need_bwd else None
+                # plan and render are enqueued back to back (no mid-frame host sync: the GPU never idles inside
+                # the forward); the counters are read afterwards -- the one host sync -- and both stages are
+                # redone in the rare case a capacity was exceeded (an overflowing plan is memory-safe).
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
                                                      bins.numel(), cap, ccap, stream))
+                L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins),
+                                                       bins.numel(), cap, ccap, -1, L.ptr(color), L.ptr(depth),
+                                                       L.ptr(alpha), L.ptr(image), 0 if image is None else image.numel(),
+                                                       stream))
                 cnt = L.SfgsRasterCounters()
-                L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))  # the one host sync
+                L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))
                 D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
                 if not cnt.overflow and D <= cap and cmax <= ccap:
                     break
@@ -153,16 +156,9 @@ class _Rasterize(torch.autograd.Function):
                                     max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
             _last_counters.clear()
             _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
-                                  num_visible=int(cnt.num_visible), max_coarse_bin=cmax, N=N, W=W, H=H,
-                                  dup_capacity=cap, coarse_capacity=ccap, _tiles=tiles, _stream_dev=dev)
-            need_bwd = any(ctx.needs_input_grad[:7])
-            image = torch.empty(sizes.image_bytes, **u8) if need_bwd else None
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins),
-                                                   bins.numel(), cap, ccap, D, L.ptr(color), L.ptr(depth), L.ptr(alpha),
-                                                   L.ptr(image), 0 if image is None else image.numel(), stream))
+                                  num_visible=int(cnt.num_visible), max_coarse_bin=cmax,
+                                  max_tile_list=int(cnt.max_tile_list), N=N, W=W, H=H, dup_capacity=cap,
+                                  coarse_capacity=ccap)
         norm = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(radii, norm)
         if need_bwd:
