@@ -13,6 +13,7 @@
  *                      autograd backward of that call              train.py:279,845
  *   sfgs_ssim_*        fused_ssim.fused_ssim(img1, img2)           train.py:42,222,778
  *   sfgs_knn_dist2     simple_knn._C.distCUDA2(points)             scene/gaussian_model.py:25,324
+ *   sfgs_prepass_*     GaussianModel.get_*_with_3D_filter/get_rotation  scene/gaussian_model.py:207-249 (next row)
  *
  * Ownership: every buffer (inputs, outputs, gradients, scratch "blobs") is allocated by the
  * caller (PyTorch's caching allocator on the right device). The library never allocates or
@@ -199,6 +200,20 @@ int sfgs_ssim_backward(const float* img1, const float* img2, int32_t B, int32_t 
 size_t sfgs_knn_scratch_bytes(int32_t N);
 int sfgs_knn_dist2(const float* xyz, int32_t N, float* out, void* scratch, size_t scratch_bytes,
                    void* stream);
+
+/* Fused per-Gaussian pre-pass of render(): activations + Mip-Splatting 3D filter, i.e.
+ *   scales    = sqrt(exp(scaling_raw)^2 + filter3d^2)        GaussianModel.get_scaling_with_3D_filter  scene/gaussian_model.py:207-213
+ *   opacities = sigmoid(opacity_raw) * sqrt(prod s^2 / prod (s^2 + filter3d^2))  get_opacity_with_3D_filter  :237-249
+ *   rotations = normalize(rotation_raw)                       get_rotation                               :216-217
+ * filter3d is [N,1] float64 (training) or float32 (after load_ply): filter_is_f64 says which. Outputs float32.
+ * backward: gradients w.r.t. the three raw tensors given gradients of the three outputs (each may be NULL = 0). */
+int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const float* opacity_raw,
+                         const float* rotation_raw, const void* filter3d, int32_t filter_is_f64,
+                         float* scales, float* opacities, float* rotations, void* stream);
+int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const float* opacity_raw,
+                          const float* rotation_raw, const void* filter3d, int32_t filter_is_f64,
+                          const float* g_scales, const float* g_opacities, const float* g_rotations,
+                          float* g_scaling_raw, float* g_opacity_raw, float* g_rotation_raw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,30 @@ def main():
         out[f"ssim_{tag}_value"] = np.float64(val.item())
         out[f"ssim_{tag}_grad"] = img1.grad.numpy()
 
+    # ---- fused pre-pass: the REAL GaussianModel getters --------------------------------------
+    import types
+    for name in ("plyfile", "simple_knn", "simple_knn._C"):  # heavy / CUDA-only imports of scene/gaussian_model.py
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    gm = _load(os.path.join(REF, "scene", "gaussian_model.py"), "ref_gaussian_model")
+    for tag, fdtype in (("f64", torch.float64), ("f32", torch.float32)):
+        m = gm.GaussianModel.__new__(gm.GaussianModel)
+        m.setup_functions()
+        n = 512
+        m._scaling = (torch.randn(n, 3, generator=g) * 1.5 - 2.0).requires_grad_(True)
+        m._opacity = (torch.randn(n, 1, generator=g) * 2.0).requires_grad_(True)
+        m._rotation = torch.randn(n, 4, generator=g).requires_grad_(True)
+        m.filter_3D = torch.exp(torch.randn(n, 1, generator=g, dtype=torch.float64) - 3.0).to(fdtype)
+        sc, op, ro = m.get_scaling_with_3D_filter, m.get_opacity_with_3D_filter, m.get_rotation
+        w1, w2, w3 = torch.randn(n, 3, generator=g), torch.randn(n, 1, generator=g), torch.randn(n, 4, generator=g)
+        ((sc.float() * w1).sum() + (op.float() * w2).sum() + (ro * w3).sum()).backward()   # render()'s .float() casts
+        for k, v in dict(scaling=m._scaling.detach(), opacity=m._opacity.detach(), rotation=m._rotation.detach(),
+                         filter=m.filter_3D, out_scales=sc.detach().float(), out_opacity=op.detach().float(),
+                         out_rotation=ro.detach(), w_scales=w1, w_opacity=w2, w_rotation=w3,
+                         g_scaling=m._scaling.grad, g_opacity=m._opacity.grad, g_rotation=m._rotation.grad).items():
+            out[f"prepass_{tag}_{k}"] = v.numpy()
+
     path = os.path.join(HERE, "reference_helpers.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
