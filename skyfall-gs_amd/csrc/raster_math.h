@@ -287,6 +287,12 @@ SFGS_HD float alpha_threshold_log2(float op) {
 
 SFGS_HD void fill_extents(SplatRec& r, float cov_a, float cov_c) {
   const float thr = alpha_threshold_log2(r.op);  // <= 0 when the splat can be seen at all
+  if (r.op != r.op) {
+    // NaN opacity: min(0.99, NaN) = 0.99 in the compositing rule (fminf semantics, as in the CUDA original), i.e.
+    // such a splat blends with alpha 0.99 wherever power <= 0 -- keep every tile of the reference rectangle
+    r.ex = INFINITY; r.ey = INFINITY;
+    return;
+  }
   if (!(r.op > 0.f) || thr > 0.f) { r.ex = -1.f; r.ey = -1.f; return; }
   // power = ln2 * p2 >= ln2 * thr  <=>  d^T conic d <= tau2 = -2 ln2 thr ; bbox = sqrt(tau2 * cov_xx)
   const float tau2 = -2.0f * LN2 * thr;

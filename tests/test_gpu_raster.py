@@ -132,3 +132,33 @@ def test_argument_validation():
     with pytest.raises(ValueError):
         run_hip(dict(frame, subpix=torch.zeros(10, 10, 2)), g, backward=False)  # wrong subpixel shape
     assert GaussianRasterizer is not None
+
+
+def test_non_finite_and_degenerate_inputs_are_culled_not_crashing():
+    """NaN / Inf positions, scales, opacities and zero scales must neither crash nor poison other pixels."""
+    frame, g = scene(4000, 160, 96, seed=13, zrange=(4., 8.), scale_range=(0.01, 0.2))
+    bad = {k: (v.clone() if v is not None else None) for k, v in g.items()}
+    bad["means3D"][0] = float("nan")
+    bad["means3D"][1, 2] = float("inf")
+    bad["scales"][2] = float("nan")
+    bad["scales"][3] = 0.0
+    bad["opacities"][4] = float("nan")
+    bad["scales"][5] = 1e30
+    bad["rotations"][6] = 0.0
+    ok = torch.ones(4000, dtype=torch.bool)
+    ok[:7] = False
+    good = {k: (v[ok].contiguous() if v is not None else None) for k, v in g.items()}
+    gc, gd = upstream_grads(160, 96, 0)
+    a = run_hip(frame, bad, gc, gd * 0)
+    b = run_hip(frame, good, gc, gd * 0)
+    for k in ("color", "alpha"):
+        assert np.isfinite(a[k]).all()
+    # the seven broken splats contribute nothing visible except the valid-but-odd ones (zero scale, zero quaternion,
+    # huge scale), which the oracle treats the same way
+    R = orc.OracleRender(frame, **bad)
+    np.testing.assert_array_equal(a["radii"], R.radii)
+    parity.assert_image_close("color", a["color"], R.color)
+    assert a["radii"][0] == 0 and a["radii"][1] == 0 and a["radii"][2] == 0
+    for k, v in a["grads"].items():
+        assert np.isfinite(v[7:]).all(), k
+    assert b["color"].shape == a["color"].shape
