@@ -215,6 +215,14 @@ int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const float* opac
                           const float* g_scales, const float* g_opacities, const float* g_rotations,
                           float* g_scaling_raw, float* g_opacity_raw, float* g_rotation_raw, void* stream);
 
+/* GaussianModel.compute_3D_filter (scene/gaussian_model.py:255-308): filter_out[N] (float64) =
+ * (smallest camera-space depth at which any camera sees the point with a 15 % screen margin) / max_focal *
+ * sqrt(0.2); points no camera sees get the largest seen depth. cams: device [C][18] float64 =
+ * R[9] (row-major, used as xyz @ R like the reference), T[3], focal_x, focal_y, cx_ori, cy_ori, width, height. */
+size_t sfgs_filter3d_scratch_bytes(int32_t N);
+int sfgs_filter3d(const float* xyz, int32_t N, const double* cams, int32_t C, double max_focal,
+                  double* filter_out, void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,7 @@ def main():
     out = {}
 
     # ---- cameras --------------------------------------------------------------------------------------
-    cams = []
+    cams, cam_objs = [], []
     for i in range(6):
         q = torch.randn(4, generator=g, dtype=torch.float64)
         q = q / q.norm()
@@ -77,6 +77,7 @@ def main():
         cam = cameras.Camera(colmap_id=i, R=R, T=T, FoVx=fovx, FoVy=fovy, cx=cx, cy=cy,
                              image=torch.zeros(3, H, W), gt_alpha_mask=None, image_name=str(i), uid=i,
                              data_device="cpu")
+        cam_objs.append(cam)
         cams.append(dict(R=R, T=T, W=W, H=H, fovx=fovx, fovy=fovy, cx=cx, cy=cy,
                          view=cam.world_view_transform.numpy(), proj=cam.projection_matrix.numpy(),
                          full=cam.full_proj_transform.numpy(), center=cam.camera_center.numpy(),
@@ -155,6 +156,15 @@ def main():
                          out_rotation=ro.detach(), w_scales=w1, w_opacity=w2, w_rotation=w3,
                          g_scaling=m._scaling.grad, g_opacity=m._opacity.grad, g_rotation=m._rotation.grad).items():
             out[f"prepass_{tag}_{k}"] = v.numpy()
+
+    # ---- compute_3D_filter: the REAL GaussianModel method over the six cameras above ----------
+    m = gm.GaussianModel.__new__(gm.GaussianModel)
+    m._xyz = torch.randn(3000, 3, generator=g) * 6.0
+    m._xyz[:5] = 1e4  # a few points no camera sees
+    m.compute_3D_filter(cam_objs)
+    out["filter3d_xyz"] = m._xyz.numpy()
+    out["filter3d_out"] = m.filter_3D.numpy()
+    assert m.filter_3D.dtype == torch.float64 and m.filter_3D.shape == (3000, 1)
 
     path = os.path.join(HERE, "reference_helpers.npz")
     np.savez_compressed(path, **out)

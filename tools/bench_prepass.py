@@ -37,3 +37,47 @@ t_ref, t_fused = run(prepass_reference), run(fused_activations)
 # algorithmic bytes: fwd 36+8 read, 32 written; bwd 44 + 32 read, 32 written  (per Gaussian)
 print(json.dumps({"N": N, "torch_eager_ms": round(t_ref, 4), "fused_ms": round(t_fused, 4), "speedup": round(t_ref / t_fused, 2),
                   "fused_GBps": round(184 * N / (t_fused * 1e-3) / 1e9, 1)}))
+
+# ---- compute_3D_filter: fused pass vs the reference's per-camera torch loop on the same GPU ----------------
+import math
+from types import SimpleNamespace
+import numpy as np
+from sfgs.filter3d import compute_3D_filter
+rng = np.random.default_rng(0)
+cams = []
+for i in range(100):
+    q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    cams.append(SimpleNamespace(R=R, T=rng.normal(size=3) * 3, cx=0.0, cy=0.0, image_width=1024, image_height=1024,
+                                focal_x=1024 / (2 * math.tan(0.3)), focal_y=1024 / (2 * math.tan(0.3))))
+xyz = (torch.randn(N, 3, generator=g) * 8).to(dev)
+
+
+def reference_loop():  # scene/gaussian_model.py:255-308 as written, on the GPU
+    p = xyz.double()
+    distance = torch.ones(N, device=dev, dtype=torch.float64) * 1e8
+    valid_points = torch.zeros(N, device=dev, dtype=torch.bool)
+    focal = 0.0
+    for c in cams:
+        R = torch.tensor(c.R, device=dev, dtype=torch.float64); T = torch.tensor(c.T, device=dev, dtype=torch.float64)
+        pc = p @ R + T[None, :]
+        vd = pc[:, 2] > 0.2
+        x_, y_, z_ = pc[:, 0], pc[:, 1], torch.clamp(pc[:, 2], min=0.001)
+        x_ = x_ / z_ * c.focal_x + c.image_width / 2; y_ = y_ / z_ * c.focal_y + c.image_height / 2
+        ins = (x_ >= -0.15 * c.image_width) & (x_ <= c.image_width * 1.15) & (y_ >= -0.15 * c.image_height) & (y_ <= 1.15 * c.image_height)
+        v = vd & ins
+        distance[v] = torch.min(distance[v], z_[v]); valid_points |= v
+        focal = max(focal, c.focal_x)
+    distance[~valid_points] = distance[valid_points].max()
+    return (distance / focal * (0.2 ** 0.5))[..., None]
+
+
+def t(fn, it=3):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(it):
+        r = fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e3, r
+t_loop, r1 = t(reference_loop); t_f, r2 = t(lambda: compute_3D_filter(xyz, cams))
+print(json.dumps({"filter3d_N": N, "cameras": len(cams), "torch_loop_ms": round(t_loop, 2), "fused_ms": round(t_f, 3),
+                  "speedup": round(t_loop / t_f, 1), "max_rel_diff": float(((r1 - r2).abs() / r1.abs()).max())}))
