@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="Gaussians in the CPU-baseline sample (-1 = the whole workload, ~10-30 s; 0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="report render FPS instead of train-step Gaussians/s")
+    ap.add_argument("--sh-degree", type=int, default=-1, help=">= 0: colour path B (in-kernel SH of this degree) instead of colors_precomp")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,12 +75,13 @@ def main():
     L.load()
 
     W, H, N = args.width, args.height, args.n
-    frame, g = scene(N, W, H, seed=rank)
+    sh = args.sh_degree
+    frame, g = scene(N, W, H, seed=rank) if sh < 0 else scene(N, W, H, seed=rank, mode="sh", sh_degree=sh)
     gc, gd = upstream_grads(W, H, rank)
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"],
         kernel_size=frame["kernel_size"], subpixel_offset=None, bg=frame["bg"].to(dev),
-        scale_modifier=1.0, viewmatrix=frame["view"].to(dev), projmatrix=frame["proj"].to(dev), sh_degree=0,
+        scale_modifier=1.0, viewmatrix=frame["view"].to(dev), projmatrix=frame["proj"].to(dev), sh_degree=max(sh, 0),
         campos=frame["campos"].to(dev), prefiltered=False, debug=False)
     rast = GaussianRasterizer(settings)
     t = {k: (v.to(dev).requires_grad_(not args.forward_only) if v is not None else None) for k, v in g.items()}
@@ -90,13 +92,13 @@ def main():
     def step():
         if args.forward_only:
             with torch.no_grad():
-                rast(means3D=t["means3D"], means2D=means2D, shs=None, colors_precomp=t["colors_precomp"],
+                rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=t["colors_precomp"],
                      opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
             return
         for v in list(t.values()) + [means2D]:
             if v is not None:
                 v.grad = None
-        color, depth, _, _, _, _ = rast(means3D=t["means3D"], means2D=means2D, shs=None,
+        color, depth, _, _, _, _ = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"],
                                         colors_precomp=t["colors_precomp"], opacities=t["opacities"],
                                         scales=t["scales"], rotations=t["rotations"])
         torch.autograd.backward([color, depth], [gc, gd])
@@ -173,7 +175,8 @@ def main():
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic cfg-2 scene, N={N} Gaussians/GPU, {W}x{H}, colors_precomp, "
+            "config": {"workload": f"configs[1]: synthetic cfg-2 scene, N={N} Gaussians/GPU, {W}x{H}, "
+                                   f"{'colors_precomp' if sh < 0 else 'SH degree %d in-kernel' % sh}, "
                                    f"kernel_size=0.1, seed=rank, one scene per GPU",
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
                        "max_tile_list": cnt["max_tile_list"], "parallelism": f"scene-per-gpu x{world}"},

@@ -209,7 +209,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   }
 }
 
-// one thread per Gaussian
+// one thread per Gaussian. K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree:
+// compile-time so that the coefficient / gradient rows live in registers, not scratch.
+template <int K, int DEG>
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rots, const float* __restrict__ opac,
@@ -220,16 +222,19 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
                       float* __restrict__ g_shs) {
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   if (g >= N) return;
-  const FrameParams f = load_frame(kf);
+  FrameParams f = load_frame(kf);
+  f.sh_degree = DEG; f.sh_coeffs = K;
   GaussGrads out;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { out.means3D[i] = 0.f; out.means2D[i] = 0.f; out.scales[i] = 0.f; out.rgb[i] = 0.f; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) out.rot[i] = 0.f;
   out.opacity = 0.f;
-  const bool vis = radii[g] > 0;
-  float* gsh = g_shs ? g_shs + 3 * (size_t)f.sh_coeffs * g : nullptr;
-  if (vis) {
+  constexpr int ROW = K > 0 ? 3 * K : 1;
+  float gshl[ROW];
+#pragma unroll
+  for (int i = 0; i < ROW; ++i) gshl[i] = 0.f;
+  if (radii[g] > 0) {
     const uint2 dr = dup[g];
     const unsigned d0 = dr.x, d1 = dr.x + dr.y;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
@@ -247,15 +252,13 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     const float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
     const float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
     const float q[4] = {qv.x, qv.y, qv.z, qv.w};
-    float shl[48];
-    if (shs) {
-      for (int i = 0; i < 3 * f.sh_coeffs; ++i) shl[i] = shs[3 * (size_t)f.sh_coeffs * g + i];
+    if constexpr (K > 0) {
+      float shl[ROW];
+      load_row<ROW>(shs + (size_t)ROW * g, shl);
+      preprocess_backward_one(f, p, s, q, opac[g], shl, A, out, gshl);
+    } else {
+      preprocess_backward_one(f, p, s, q, opac[g], nullptr, A, out, gshl);
     }
-    float gshl[48];
-    preprocess_backward_one(f, p, s, q, opac[g], shs ? shl : nullptr, A, out, gshl);
-    if (gsh) for (int i = 0; i < 3 * f.sh_coeffs; ++i) gsh[i] = gshl[i];
-  } else if (gsh) {
-    for (int i = 0; i < 3 * f.sh_coeffs; ++i) gsh[i] = 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -265,7 +268,9 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   }
   *reinterpret_cast<float4*>(g_rots + 4 * (size_t)g) = make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]);
   g_opac[g] = out.opacity;
-  if (g_colors) {
+  if constexpr (K > 0) {
+    store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
+  } else {
 #pragma unroll
     for (int i = 0; i < 3; ++i) g_colors[3 * (size_t)g + i] = out.rgb[i];
   }
@@ -310,10 +315,14 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
-                       g->rotations, g->opacities, g->shs, radii, gv.dup, (const float4*)dupgrad, grads->means3D,
-                       grads->means2D, grads->scales, grads->rotations, grads->opacities, grads->colors_precomp,
-                       grads->shs); }
+#define SFGS_LAUNCH_PBWD(K, D)                                                                                          \
+  hipLaunchKernelGGL((preprocess_bwd_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales, \
+                     g->rotations, g->opacities, g->shs, radii, gv.dup, (const float4*)dupgrad, grads->means3D,        \
+                     grads->means2D, grads->scales, grads->rotations, grads->opacities, grads->colors_precomp,         \
+                     grads->shs)
+    SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PBWD);
+#undef SFGS_LAUNCH_PBWD
+  }
   SFGS_POST_LAUNCH("preprocess_bwd", stream, frame->debug);
   return SFGS_OK;
 }

@@ -74,6 +74,7 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 // one 16-byte coarse item (id, depth, first duplicate index, mask) appended to the bin's slab with ONE
 // returning device atomic. The block reserves its duplicate indices (one per set mask bit, in walk order)
 // with one atomic per block.
+template <int K, int DEG>  // K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
@@ -108,11 +109,13 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       vis = 1;
       dref = (unsigned)((pr.rmaxx - pr.rminx) * (pr.rmaxy - pr.rminy));
       float rgb[3];
-      if (colors) {
+      if constexpr (K == 0) {
         rgb[0] = colors[3 * (size_t)g]; rgb[1] = colors[3 * (size_t)g + 1]; rgb[2] = colors[3 * (size_t)g + 2];
       } else {
+        float shl[3 * K];
+        load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
         unsigned cm; float dir[3], len;
-        sh_to_rgb(f.sh_degree, shs + 3 * (size_t)f.sh_coeffs * g, p, f.campos, rgb, &cm, dir, &len);
+        sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len);
       }
       r = make_record(pr, opac[g], rgb);
       rec_out[3 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
@@ -632,8 +635,9 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
     SFGS_REQUIRE((g->colors_precomp != nullptr) != (g->shs != nullptr), SFGS_E_ARG,
                  "provide exactly one of colors_precomp / shs");
     if (g->shs)
-      SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) && f->sh_coeffs <= 16, SFGS_E_ARG,
-                   "sh_coeffs %d too small for degree %d (or > 16)", f->sh_coeffs, f->sh_degree);
+      SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) &&
+                       (f->sh_coeffs == 1 || f->sh_coeffs == 4 || f->sh_coeffs == 9 || f->sh_coeffs == 16),
+                   SFGS_E_ARG, "sh_coeffs %d: must be 1, 4, 9 or 16 and hold degree %d", f->sh_coeffs, f->sh_degree);
   }
   return SFGS_OK;
 }
@@ -688,10 +692,14 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   }
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
-      hipLaunchKernelGGL(preprocess_kernel, dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,
-                         g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,
-                         bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,
-                         tv.block_dref, tv.hdr); }
+#define SFGS_LAUNCH_PRE(K, D)                                                                                          \
+  hipLaunchKernelGGL((preprocess_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,    \
+                     g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,   \
+                     bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,            \
+                     tv.block_dref, tv.hdr)
+      SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
+#undef SFGS_LAUNCH_PRE
+    }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);

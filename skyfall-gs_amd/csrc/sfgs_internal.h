@@ -214,6 +214,43 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
   return base + idx;
 }
 
+// ---- per-Gaussian SH coefficient rows: 3K floats, 16-byte vector accesses when the row size allows -----------
+template <int CNT>
+__device__ __forceinline__ void load_row(const float* __restrict__ src, float (&dst)[CNT]) {
+  if constexpr (CNT % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < CNT / 4; ++i) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i];
+      dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) dst[i] = src[i];
+  }
+}
+template <int CNT>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float (&src)[CNT]) {
+  if constexpr (CNT % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < CNT / 4; ++i)
+      reinterpret_cast<float4*>(dst)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) dst[i] = src[i];
+  }
+}
+
+// Launch `KERNEL<K, DEG>` for the runtime (sh_coeffs, sh_degree) pair; K = 0 is the colors_precomp path.
+#define SFGS_DISPATCH_SH(K_RT, DEG_RT, LAUNCH)                                   \
+  do {                                                                           \
+    const int k_ = (K_RT), d_ = (DEG_RT);                                        \
+    if (k_ == 0) { LAUNCH(0, 0); }                                               \
+    else if (k_ == 1) { LAUNCH(1, 0); }                                          \
+    else if (k_ == 4) { if (d_ == 0) { LAUNCH(4, 0); } else { LAUNCH(4, 1); } }  \
+    else if (k_ == 9) { if (d_ == 0) { LAUNCH(9, 0); } else if (d_ == 1) { LAUNCH(9, 1); } else { LAUNCH(9, 2); } } \
+    else { if (d_ == 0) { LAUNCH(16, 0); } else if (d_ == 1) { LAUNCH(16, 1); } else if (d_ == 2) { LAUNCH(16, 2); } else { LAUNCH(16, 3); } } \
+  } while (0)
+
 // ---- small wave / block primitives ---------------------------------------------------------------
 __device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
 
