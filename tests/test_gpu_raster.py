@@ -162,3 +162,20 @@ def test_non_finite_and_degenerate_inputs_are_culled_not_crashing():
     for k, v in a["grads"].items():
         assert np.isfinite(v[7:]).all(), k
     assert b["color"].shape == a["color"].shape
+
+
+def test_runs_on_the_callers_current_stream():
+    """All launches go to torch's CURRENT stream (never a cached one): results on a side stream equal the default
+    stream's, and the forward on the side stream is ordered after work queued on that stream."""
+    frame, g = scene(20000, 320, 200, seed=21, zrange=(250., 350.), scale_range=(0.2, 3.0))
+    gc, gd = upstream_grads(320, 200, 2)
+    ref = run_hip(frame, g, gc, gd * 0, debug=False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = run_hip(frame, g, gc, gd * 0, debug=False)
+    side.synchronize()
+    np.testing.assert_array_equal(out["color"], ref["color"])
+    np.testing.assert_array_equal(out["radii"], ref["radii"])
+    for k in ref["grads"]:
+        np.testing.assert_array_equal(out["grads"][k], ref["grads"][k])
