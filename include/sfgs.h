@@ -155,6 +155,10 @@ int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int
 /* Copies the plan counters to the host. SYNCHRONISES `stream` (the one host sync of the forward,
  * as in the reference, where the duplicate total sizes the sort buffers). */
 int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream);
+/* Same, through a caller-owned PINNED host buffer of >= 64 bytes (no pageable staging copy: a few
+ * microseconds less per frame; the library itself owns no host or device memory). */
+int sfgs_raster_read_counters_pinned(const void* tiles, void* pinned_host_64, SfgsRasterCounters* out,
+                                     void* stream);
 
 /* Forward, stage 2 ("render"): expand the coarse items into per-tile lists (LDS-ranked), sort each
  * list by (depth, Gaussian index), alpha-composite front to back. Outputs: out_color[3,H,W],

@@ -709,18 +709,32 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   return SFGS_OK;
 }
 
-extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream_) {
-  SFGS_REQUIRE(tiles && out, SFGS_E_ARG, "NULL argument");
-  hipStream_t stream = (hipStream_t)stream_;
-  unsigned long long h[8];
-  SFGS_CHECK_HIP(hipMemcpyAsync(h, tiles, sizeof(h), hipMemcpyDeviceToHost, stream));
-  SFGS_CHECK_HIP(hipStreamSynchronize(stream));
+static void unpack_counters(const unsigned long long* h, SfgsRasterCounters* out) {
   out->num_duplicates = (int64_t)h[HDR_D_EFF];
   out->num_duplicates_ref = (int64_t)h[HDR_D_REF];
   out->num_visible = (int64_t)h[HDR_N_VIS];
   out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
   out->overflow = (int64_t)h[HDR_OVERFLOW];
   out->max_coarse_bin = (int64_t)h[HDR_MAX_COARSE];
+}
+
+extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream_) {
+  SFGS_REQUIRE(tiles && out, SFGS_E_ARG, "NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned long long h[8];
+  SFGS_CHECK_HIP(hipMemcpyAsync(h, tiles, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SFGS_CHECK_HIP(hipStreamSynchronize(stream));
+  unpack_counters(h, out);
+  return SFGS_OK;
+}
+
+extern "C" int sfgs_raster_read_counters_pinned(const void* tiles, void* pinned_host_64, SfgsRasterCounters* out,
+                                                void* stream_) {
+  SFGS_REQUIRE(tiles && out && pinned_host_64, SFGS_E_ARG, "NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  SFGS_CHECK_HIP(hipMemcpyAsync(pinned_host_64, tiles, 64, hipMemcpyDeviceToHost, stream));
+  SFGS_CHECK_HIP(hipStreamSynchronize(stream));
+  unpack_counters((const unsigned long long*)pinned_host_64, out);
   return SFGS_OK;
 }
 

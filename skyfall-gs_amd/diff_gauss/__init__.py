@@ -44,6 +44,16 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _last_counters = {}
+_pinned = {}     # device index -> pinned host buffer the counters are read through
+_ncb_cache = {}  # (W, H) -> number of coarse bins
+_zeros = {}      # device index -> 1-element zero tensor
+
+
+def _zero(dev):
+    z = _zeros.get(dev.index)
+    if z is None:
+        z = _zeros[dev.index] = torch.zeros(1, 1, 1, dtype=torch.float32, device=dev)
+    return z
 _cap_hint = {}   # device index -> (duplicate capacity, per-coarse-bin capacity) to plan with (grow geometrically)
 
 
@@ -115,26 +125,31 @@ class _Rasterize(torch.autograd.Function):
             gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                                  L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
             sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
-            u8 = dict(dtype=torch.uint8, device=dev)
-            radii = torch.empty(N, dtype=torch.int32, device=dev)
             # Neither the duplicate count D nor the fullest coarse bin is known before the plan: plan into a bins
             # blob sized from the previous frames (geometric growth) and redo the plan in the rare case it
             # overflowed.
-            L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
-            ncb = max(int(sizes.coarse_bins), 1)
+            ncb = _ncb_cache.get((W, H))
+            if ncb is None:
+                L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
+                ncb = _ncb_cache[(W, H)] = max(int(sizes.coarse_bins), 1)
             hint = _cap_hint.get(dev.index, (0, 0))
             cap = max(hint[0], 4 * N, 1024)
             ccap = max(hint[1], 8 * N // ncb, 256)
             need_bwd = any(ctx.needs_input_grad[:7])
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            # few, large allocations: the Python time before the first launch is GPU idle time
+            outs = torch.empty(5, H, W, dtype=torch.float32, device=dev)
+            color, depth, alpha = outs[0:3], outs[3:4], outs[4:5]
+            radii = torch.empty(N, dtype=torch.int32, device=dev)
+            al = lambda n: (n + 255) // 256 * 256
             while True:
                 L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
-                geom = torch.empty(max(sizes.geom_bytes, 1), **u8)
-                tiles = torch.empty(sizes.tiles_bytes, **u8)
-                bins = torch.empty(max(sizes.bins_bytes, 1), **u8)
-                image = torch.empty(sizes.image_bytes, **u8) if need_bwd else None
+                o_tiles = al(max(sizes.geom_bytes, 1))
+                o_bins = o_tiles + al(sizes.tiles_bytes)
+                o_image = o_bins + al(max(sizes.bins_bytes, 1))
+                total = o_image + (al(sizes.image_bytes) if need_bwd else 0)
+                scratch = torch.empty(total, dtype=torch.uint8, device=dev)
+                geom, tiles, bins = scratch[:o_tiles], scratch[o_tiles:o_bins], scratch[o_bins:o_image]
+                image = scratch[o_image:] if need_bwd else None
                 # plan and render are enqueued back to back (no mid-frame host sync: the GPU never idles inside
                 # the forward); the counters are read afterwards -- the one host sync -- and both stages are
                 # redone in the rare case a capacity was exceeded (an overflowing plan is memory-safe).
@@ -146,7 +161,11 @@ class _Rasterize(torch.autograd.Function):
                                                        L.ptr(alpha), L.ptr(image), 0 if image is None else image.numel(),
                                                        stream))
                 cnt = L.SfgsRasterCounters()
-                L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))
+                pinned = _pinned.get(dev.index)
+                if pinned is None:
+                    pinned = _pinned[dev.index] = torch.empty(8, dtype=torch.int64).pin_memory()
+                L.check(lib.sfgs_raster_read_counters_pinned(L.ptr(tiles), L.C.c_void_p(pinned.data_ptr()),
+                                                             L.C.byref(cnt), stream))
                 D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
                 if not cnt.overflow and D <= cap and cmax <= ccap:
                     break
@@ -159,7 +178,9 @@ class _Rasterize(torch.autograd.Function):
                                   num_visible=int(cnt.num_visible), max_coarse_bin=cmax,
                                   max_tile_list=int(cnt.max_tile_list), N=N, W=W, H=H, dup_capacity=cap,
                                   coarse_capacity=ccap)
-        norm = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        # normals are not produced by this rasterizer (no consumer in the reference): a zero-stride view of one
+        # zero, i.e. a read-only all-zeros [3,H,W] tensor that costs no memory and no kernel
+        norm = _zero(dev).expand(3, H, W)
         ctx.mark_non_differentiable(radii, norm)
         if need_bwd:
             ctx.settings, ctx.D, ctx.ccap, ctx.sh_coeffs = settings, cap, ccap, sh_coeffs
@@ -182,20 +203,26 @@ class _Rasterize(torch.autograd.Function):
             stream = _stream(dev)
             gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                                  L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
-            f32 = dict(dtype=torch.float32, device=dev)
-            g_means3D = torch.empty(N, 3, **f32)
-            g_means2D = torch.empty(N, 3, **f32)
-            g_scales = torch.empty(N, 3, **f32)
-            g_rot = torch.empty(N, 4, **f32)
-            g_opac = torch.empty(N, 1, **f32)
-            g_col = torch.empty(N, 3, **f32) if ctx.has_colors else None
-            g_shs = torch.empty(N, ctx.sh_coeffs, 3, **f32) if ctx.has_shs else None
+            # one allocation for all gradient tensors (views), one for the per-duplicate scratch
+            K = ctx.sh_coeffs
+            ncol = 3 * K if ctx.has_shs else 3
+            flat = torch.empty(N * (14 + ncol) + 32, dtype=torch.float32, device=dev)
+            o = 0
+
+            def take(cols, shape):
+                nonlocal o
+                o = (o + 3) // 4 * 4         # 16-byte aligned regions (the kernels use float4 stores)
+                v = flat[o:o + N * cols].view(shape)
+                o += N * cols
+                return v
+            g_rot = take(4, (N, 4))
+            g_means3D, g_means2D, g_scales = take(3, (N, 3)), take(3, (N, 3)), take(3, (N, 3))
+            g_opac = take(1, (N, 1))
+            g_col = take(3, (N, 3)) if ctx.has_colors else None
+            g_shs = take(3 * K, (N, K, 3)) if ctx.has_shs else None
             grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
                                         L.ptr(g_scales), L.ptr(g_rot), L.ptr(g_opac), L.ptr(g_col), L.ptr(g_shs))
-            sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
-            L.check(lib.sfgs_raster_sizes(N, int(settings.image_width), int(settings.image_height), D, ctx.ccap,
-                                          L.C.byref(sizes)))
-            dupgrad = torch.empty(max(sizes.dupgrad_bytes, 1), dtype=torch.uint8, device=dev)
+            dupgrad = torch.empty(max((D * 48 + 255) // 256 * 256, 1), dtype=torch.uint8, device=dev)
             gc = None if g_color is None else g_color.contiguous().float()
             gd = None if g_depth is None else g_depth.contiguous().float()
             ga = None if g_alpha is None else g_alpha.contiguous().float()

@@ -58,6 +58,7 @@ SYMBOLS = {
     "sfgs_raster_forward_plan": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _V, _SZ, _V, _SZ,
                                             _I64, _I64, _V]),
     "sfgs_raster_read_counters": (C.c_int, [_V, C.POINTER(SfgsRasterCounters), _V]),
+    "sfgs_raster_read_counters_pinned": (C.c_int, [_V, _V, C.POINTER(SfgsRasterCounters), _V]),
     "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _I64, _I64, _V, _V, _V,
                                               _V, _SZ, _V]),
     "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _I64, _V,
