@@ -227,6 +227,14 @@ size_t sfgs_filter3d_scratch_bytes(int32_t N);
 int sfgs_filter3d(const float* xyz, int32_t N, const double* cams, int32_t C, double max_focal,
                   double* filter_out, void* scratch, size_t scratch_bytes, void* stream);
 
+/* GaussianModel.add_densification_stats (scene/gaussian_model.py:744-749), in place, no host
+ * sync: for every i with update_filter[i] != 0 (bool/uint8 [N]):
+ *   accum[i] += hypot(grad[i,0], grad[i,1]); accum_abs[i] += |grad[i,2]|; accum_abs_max[i] = max(., |grad[i,2]|);
+ *   denom[i] += 1.   viewspace_grad is means2D.grad [N,3]; accum_abs_max may be NULL. */
+int sfgs_densify_stats(int32_t N, const float* viewspace_grad, const unsigned char* update_filter,
+                       float* xyz_gradient_accum, float* xyz_gradient_accum_abs,
+                       float* xyz_gradient_accum_abs_max_or_null, float* denom, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,7 @@ SYMBOLS = {
     "sfgs_knn_dist2": (C.c_int, [_V, _I32, _V, _V, _SZ, _V]),
     "sfgs_filter3d_scratch_bytes": (_SZ, [_I32]),
     "sfgs_filter3d": (C.c_int, [_V, _I32, _V, _I32, C.c_double, _V, _V, _SZ, _V]),
+    "sfgs_densify_stats": (C.c_int, [_I32, _V, _V, _V, _V, _V, _V, _V]),
     "sfgs_prepass_forward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V]),
     "sfgs_prepass_backward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V, _V, _V, _V]),
 }

@@ -166,6 +166,22 @@ def main():
     out["filter3d_out"] = m.filter_3D.numpy()
     assert m.filter_3D.dtype == torch.float64 and m.filter_3D.shape == (3000, 1)
 
+    # ---- add_densification_stats: the REAL GaussianModel method, two consecutive steps ---------
+    m = gm.GaussianModel.__new__(gm.GaussianModel)
+    n = 1000
+    for name in ("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom"):
+        setattr(m, name, torch.zeros(n, 1))
+    for step in range(2):
+        vs = torch.zeros(n, 3, requires_grad=True)
+        vs.grad = torch.randn(n, 3, generator=g) * torch.tensor([1.0, 1.0, 1.0])
+        vs.grad[:, 2].abs_()
+        filt = torch.rand(n, generator=g) > 0.3
+        m.add_densification_stats(vs, filt)
+        out[f"dstats_grad{step}"] = vs.grad.numpy().copy()
+        out[f"dstats_filter{step}"] = filt.numpy().copy()
+    for name in ("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom"):
+        out["dstats_" + name] = getattr(m, name).numpy().copy()
+
     path = os.path.join(HERE, "reference_helpers.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -81,3 +81,18 @@ def t(fn, it=3):
 t_loop, r1 = t(reference_loop); t_f, r2 = t(lambda: compute_3D_filter(xyz, cams))
 print(json.dumps({"filter3d_N": N, "cameras": len(cams), "torch_loop_ms": round(t_loop, 2), "fused_ms": round(t_f, 3),
                   "speedup": round(t_loop / t_f, 1), "max_rel_diff": float(((r1 - r2).abs() / r1.abs()).max())}))
+
+# ---- add_densification_stats: fused kernel vs the reference's boolean-mask torch ops on the same GPU ---------
+from sfgs import densify_stats
+m = SimpleNamespace(**{k: torch.zeros(N, 1, device=dev) for k in ("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom")})
+vs = SimpleNamespace(grad=torch.randn(N, 3, device=dev))
+filt = torch.rand(N, device=dev) > 0.1
+
+
+def ref_stats():  # scene/gaussian_model.py:744-749 as written
+    m.xyz_gradient_accum[filt] += torch.norm(vs.grad[filt, :2], dim=-1, keepdim=True)
+    m.xyz_gradient_accum_abs[filt] += torch.norm(vs.grad[filt, 2:], dim=-1, keepdim=True)
+    m.xyz_gradient_accum_abs_max[filt] = torch.max(m.xyz_gradient_accum_abs_max[filt], torch.norm(vs.grad[filt, 2:], dim=-1, keepdim=True))
+    m.denom[filt] += 1
+t_ref, _ = t(ref_stats, 10); t_f, _ = t(lambda: densify_stats.add_densification_stats(m, vs, filt), 10)
+print(json.dumps({"densify_stats_N": N, "torch_masked_ms": round(t_ref, 3), "fused_ms": round(t_f, 4), "speedup": round(t_ref / t_f, 1)}))
