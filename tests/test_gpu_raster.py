@@ -19,6 +19,9 @@ CASES = {
                                                      sh_degree=1)),
     "cfg2_like": dict(n=60000, W=480, H=270, kw=dict(zrange=(250., 350.), scale_range=(0.2, 2.4))),
     "big_splats": dict(n=400, W=256, H=192, kw=dict(zrange=(3., 6.), scale_range=(0.3, 2.0))),
+    # the headline scene generator at its full viewport, 1/10 of the Gaussians (the oracle needs ~1 s for it)
+    "cfg2_200k_1080p": dict(n=200000, W=1920, H=1080, kw=dict()),
+    "cfg4_like_1440p": dict(n=150000, W=2560, H=1440, kw=dict(zrange=(500., 700.))),
     # per-tile lists of ~2000 (LDS sort path) and ~6000 entries (global-memory sort path); low opacity so that
     # pixels do not saturate after a few dozen splats and the long lists are really composited
     "lists_2k": dict(n=2000, W=72, H=56, kw=dict(zrange=(3., 6.), scale_range=(0.5, 1.5), opacity_range=(0.004, 0.02))),
