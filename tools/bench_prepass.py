@@ -2,10 +2,21 @@
 """Fused pre-pass vs the reference's torch-eager getters on the same GPU (N = 2 M, float64 filter as in training)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "skyfall-gs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "skyfall-gs_amd"))
 import torch
 from sfgs.prepass import fused_activations
-from oracle.prepass_torch import prepass_reference   # here: the thing being compared against, run on the GPU
+
+
+def prepass_reference(scaling_raw, opacity_raw, rotation_raw, filter_3D):
+    """The reference's three getters as torch eager ops (scene/gaussian_model.py:207-213,216-217,237-249) + render()'s
+    .float() casts: the baseline this tool times on the GPU. (Restated here: tools do not import oracle/.)"""
+    scales = torch.exp(scaling_raw)
+    s_filt = torch.sqrt(torch.square(scales) + torch.square(filter_3D))
+    scales_square = torch.square(scales)
+    coef = torch.sqrt(scales_square.prod(dim=1) / (scales_square + torch.square(filter_3D)).prod(dim=1))
+    o_filt = torch.sigmoid(opacity_raw) * coef[..., None]
+    return s_filt.float(), o_filt.float(), torch.nn.functional.normalize(rotation_raw)
+
 
 dev = torch.device("cuda:0")
 N = 2_000_000
