@@ -49,6 +49,16 @@ _ncb_cache = {}  # (W, H) -> number of coarse bins
 _zeros = {}      # device index -> 1-element zero tensor
 
 
+def _scratch_budget(dev):
+    b = _budget.get(dev.index)
+    if b is None:
+        b = _budget[dev.index] = torch.cuda.get_device_properties(dev).total_memory // 2
+    return b
+
+
+_budget = {}
+
+
 def _zero(dev):
     z = _zeros.get(dev.index)
     if z is None:
@@ -147,6 +157,11 @@ class _Rasterize(torch.autograd.Function):
                 o_bins = o_tiles + al(sizes.tiles_bytes)
                 o_image = o_bins + al(max(sizes.bins_bytes, 1))
                 total = o_image + (al(sizes.image_bytes) if need_bwd else 0)
+                if total > _scratch_budget(dev):
+                    # uniform per-coarse-bin slabs (ncb x fullest bin x 16 B): only a pathologically skewed frame
+                    # (most Gaussians inside one 32x32-pixel bin) can get here on a 288 GB device
+                    raise RuntimeError(f"rasterizer scratch of {total / 2**30:.1f} GiB exceeds half of the device memory "
+                                       f"(duplicates {cap}, fullest coarse bin {ccap}, {ncb} bins)")
                 scratch = torch.empty(total, dtype=torch.uint8, device=dev)
                 geom, tiles, bins = scratch[:o_tiles], scratch[o_tiles:o_bins], scratch[o_bins:o_image]
                 image = scratch[o_image:] if need_bwd else None
