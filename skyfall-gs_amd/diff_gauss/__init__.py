@@ -64,7 +64,7 @@ def _zero(dev):
     if z is None:
         z = _zeros[dev.index] = torch.zeros(1, 1, 1, dtype=torch.float32, device=dev)
     return z
-_cap_hint = {}   # device index -> (duplicate capacity, per-coarse-bin capacity) to plan with (grow geometrically)
+_cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin capacity) to plan with
 
 
 def last_counters():
@@ -142,7 +142,7 @@ class _Rasterize(torch.autograd.Function):
             if ncb is None:
                 L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
                 ncb = _ncb_cache[(W, H)] = max(int(sizes.coarse_bins), 1)
-            hint = _cap_hint.get(dev.index, (0, 0))
+            hint = _cap_hint.get((dev.index, W, H), (0, 0))
             cap = max(hint[0], 4 * N, 1024)
             ccap = max(hint[1], 8 * N // ncb, 256)
             need_bwd = any(ctx.needs_input_grad[:7])
@@ -186,7 +186,7 @@ class _Rasterize(torch.autograd.Function):
                     break
                 cap = max(cap, int(D * 1.25) + 1024)
                 ccap = max(ccap, int(cmax * 1.25) + 256)
-            _cap_hint[dev.index] = (max(int(D * 1.25) + 1024, min(cap, 2 * D + 1024)),
+            _cap_hint[(dev.index, W, H)] = (max(int(D * 1.25) + 1024, min(cap, 2 * D + 1024)),
                                     max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
             _last_counters.clear()
             _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
