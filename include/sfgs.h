@@ -132,6 +132,7 @@ const char* sfgs_last_error(void);
  * the recorded events, returns per-kernel summed milliseconds and launch counts (arrays of
  * sfgs_profile_kernel_count() entries) and clears the record. Off by default; costs nothing then. */
 int sfgs_profile_enable(int32_t on);
+int sfgs_profile_select(uint64_t kernel_mask); /* bit i = time kernel id i (default: all); events cost ~4 us each */
 int sfgs_profile_kernel_count(void);
 const char* sfgs_profile_kernel_name(int32_t id);
 int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);

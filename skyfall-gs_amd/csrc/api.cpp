@@ -28,10 +28,12 @@ static const char* const kKernelNames[KID_COUNT] = {
 struct ProfRec { int id; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static unsigned long long g_prof_mask = ~0ull;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 
 bool prof_enabled() { return g_prof_on; }
+bool prof_selected(int id) { return g_prof_on && ((g_prof_mask >> id) & 1ull); }
 
 static hipEvent_t prof_get_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -73,6 +75,12 @@ extern "C" int sfgs_profile_enable(int32_t on) {
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
   g_prof_recs.clear();
   g_prof_on = on != 0;
+  return SFGS_OK;
+}
+
+extern "C" int sfgs_profile_select(uint64_t kernel_mask) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_mask = kernel_mask;
   return SFGS_OK;
 }
 

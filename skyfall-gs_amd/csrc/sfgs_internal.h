@@ -37,11 +37,12 @@ enum KernelId {
   KID_COUNT
 };
 bool prof_enabled();
+bool prof_selected(int id);
 void* prof_begin(int id, hipStream_t stream);
 void prof_end(void* token, hipStream_t stream);
 struct ProfScope {
   void* tok; hipStream_t st;
-  ProfScope(int id, hipStream_t s) : tok(prof_enabled() ? prof_begin(id, s) : nullptr), st(s) {}
+  ProfScope(int id, hipStream_t s) : tok(prof_selected(id) ? prof_begin(id, s) : nullptr), st(s) {}
   ~ProfScope() { if (tok) prof_end(tok, st); }
 };
 

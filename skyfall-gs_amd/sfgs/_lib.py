@@ -51,6 +51,7 @@ SYMBOLS = {
     "sfgs_abi_version": (C.c_int, []),
     "sfgs_last_error": (C.c_char_p, []),
     "sfgs_profile_enable": (C.c_int, [_I32]),
+    "sfgs_profile_select": (C.c_int, [C.c_uint64]),
     "sfgs_profile_kernel_count": (C.c_int, []),
     "sfgs_profile_kernel_name": (C.c_char_p, [_I32]),
     "sfgs_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
@@ -109,6 +110,16 @@ def ptr(t):
 
 def profile_enable(on=True):
     check(load().sfgs_profile_enable(int(bool(on))))
+
+
+def profile_select(names=None):
+    """Time only the kernels whose names are given (None = all)."""
+    lib = load()
+    mask = 0
+    for i in range(lib.sfgs_profile_kernel_count()):
+        if names is None or lib.sfgs_profile_kernel_name(i).decode() in names:
+            mask |= 1 << i
+    check(lib.sfgs_profile_select(mask))
 
 
 def profile_collect():
