@@ -182,3 +182,20 @@ def test_runs_on_the_callers_current_stream():
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     for k in ref["grads"]:
         np.testing.assert_array_equal(out["grads"][k], ref["grads"][k])
+
+
+@pytest.mark.parametrize("W,H,n", [(5, 3, 7), (1, 1, 3), (9, 17, 1), (33, 8, 50)])
+def test_tiny_images_and_single_gaussians(W, H, n):
+    frame, g = scene(n, W, H, seed=W * 100 + H, zrange=(2., 4.), scale_range=(0.05, 0.5))
+    R = orc.OracleRender(frame, **g)
+    gc, gd = upstream_grads(W, H, 0)
+    gd = gd.clone()
+    gd[torch.from_numpy(np.isnan(R.depth))] = 0
+    G = R.backward(gc, gd)
+    out = run_hip(frame, g, gc, gd)
+    np.testing.assert_array_equal(out["radii"], R.radii)
+    for name in ("color", "alpha", "depth"):
+        parity.assert_image_close(name, out[name], getattr(R, name))
+    for k in G:
+        if np.abs(G[k]).max() > 0:
+            parity.assert_grad_close(k, out["grads"][k], G[k])
