@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 4
+#define SFGS_ABI_VERSION 5
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -235,6 +235,31 @@ int sfgs_filter3d(const float* xyz, int32_t N, const double* cams, int32_t C, do
 int sfgs_densify_stats(int32_t N, const float* viewspace_grad, const unsigned char* update_filter,
                        float* xyz_gradient_accum, float* xyz_gradient_accum_abs,
                        float* xyz_gradient_accum_abs_max_or_null, float* denom, void* stream);
+
+/* One Adam step over a list of float32 tensors in one launch. Replaces the per-iteration
+ * `gaussians.optimizer.step()` (train.py:339,906) of `torch.optim.Adam(l, lr=0.0, eps=1e-15)`
+ * (scene/gaussian_model.py:382); arithmetic = torch's default ("foreach") CUDA path, operation by operation:
+ *   g' = grad + weight_decay*param (if weight_decay != 0);  m += (1-b1)*(g'-m);  v = v*b2 + (1-b2)*g'*g';
+ *   param += neg_step_size * (m / (sqrt(v)/bias_correction2_sqrt + eps))
+ * The host computes, in double like torch does, neg_step_size = -lr/(1-b1^t) and bias_correction2_sqrt =
+ * sqrt(1-b2^t) for the tensor's own step count t (already incremented), then rounds to float. `tensors` is a HOST
+ * array; all pointers are device pointers to contiguous float32 storage of `count` elements, updated in place. */
+typedef struct SfgsAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t count;
+  float neg_step_size;
+  float one_minus_beta1;
+  float beta2;
+  float one_minus_beta2;
+  float bias_correction2_sqrt;
+  float eps;
+  float weight_decay;
+  float reserved;
+} SfgsAdamTensor;
+int sfgs_adam_step(const SfgsAdamTensor* tensors, int32_t count, void* stream);
 
 #ifdef __cplusplus
 }

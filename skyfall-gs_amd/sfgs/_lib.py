@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsfgs.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -38,6 +38,13 @@ class SfgsRasterSizes(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("geom_bytes", C.c_size_t), ("tiles_bytes", C.c_size_t),
                 ("bins_bytes", C.c_size_t), ("image_bytes", C.c_size_t), ("dupgrad_bytes", C.c_size_t),
                 ("coarse_bins", C.c_int64)]
+
+
+class SfgsAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("count", C.c_int64), ("neg_step_size", C.c_float), ("one_minus_beta1", C.c_float),
+                ("beta2", C.c_float), ("one_minus_beta2", C.c_float), ("bias_correction2_sqrt", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("reserved", C.c_float)]
 
 
 class SfgsRasterCounters(C.Structure):
@@ -72,6 +79,7 @@ SYMBOLS = {
     "sfgs_filter3d_scratch_bytes": (_SZ, [_I32]),
     "sfgs_filter3d": (C.c_int, [_V, _I32, _V, _I32, C.c_double, _V, _V, _SZ, _V]),
     "sfgs_densify_stats": (C.c_int, [_I32, _V, _V, _V, _V, _V, _V, _V]),
+    "sfgs_adam_step": (C.c_int, [C.POINTER(SfgsAdamTensor), _I32, _V]),
     "sfgs_prepass_forward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V]),
     "sfgs_prepass_backward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V, _V, _V, _V]),
 }

@@ -48,6 +48,103 @@ def _load(path, name):
     return mod
 
 
+OPT_GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "appearance_embeddings", "embeddings",
+              "appearance_mlp")
+
+
+def make_optimizer_golden(gm):
+    """the REAL GaussianModel drives the REAL torch.optim.Adam through training_setup ->
+    optimizer.step x3 -> densification_postfix -> prune_points -> step x2 (one with missing grads) ->
+    replace_tensor_to_optimizer -> step. Records every input and the final parameters / moments / step counts
+    (scene/gaussian_model.py:350-392,549-645; train.py:339)."""
+    import types
+    from torch import nn
+    g = torch.Generator().manual_seed(4321)
+    torch.manual_seed(99)  # EmbeddingModel init + appearance_embeddings.normal_ use the global generator
+    orig_to = nn.Module.to
+    nn.Module.to = lambda self, *a, **k: self if (a and str(a[0]).startswith("cuda")) else orig_to(self, *a, **k)
+    try:
+        m = gm.GaussianModel(1, appearance_enabled=True, appearance_n_fourier_freqs=4, appearance_embedding_dim=32)
+    finally:
+        nn.Module.to = orig_to
+    n = 301  # odd on purpose: ragged tails, unaligned views after surgery
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    m._xyz = nn.Parameter(rnd(n, 3) * 5)
+    m._features_dc = nn.Parameter(rnd(n, 1, 3))
+    m._features_rest = nn.Parameter(rnd(n, 3, 3) * 0.1)
+    m._opacity = nn.Parameter(rnd(n, 1))
+    m._scaling = nn.Parameter(rnd(n, 3) - 2)
+    m._rotation = nn.Parameter(rnd(n, 4))
+    m._embeddings = nn.Parameter(rnd(n, 24))
+    m.max_radii2D = torch.zeros(n)
+    m.spatial_lr_scale = 3.5
+    args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                                 position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025,
+                                 opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, embedding_lr=0.005,
+                                 appearance_embedding_lr=0.001, appearance_embedding_regularization=0.01,
+                                 appearance_mlp_lr=0.0005, idu_position_lr_max_steps=10000)
+    m.training_setup(args, num_train_cameras=5, from_scratch=True)
+    assert type(m.optimizer) is torch.optim.Adam
+    out = {}
+
+    def params_of(name):
+        return [grp for grp in m.optimizer.param_groups if grp["name"] == name][0]["params"]
+
+    for name in OPT_GROUPS:
+        grp = [q for q in m.optimizer.param_groups if q["name"] == name][0]
+        out[f"opt_lr_{name}"] = np.float64(grp["lr"])
+        out[f"opt_wd_{name}"] = np.float64(grp["weight_decay"])
+        for i, prm in enumerate(grp["params"]):
+            out[f"opt_init_{name}_{i}"] = prm.detach().numpy().copy()
+    out["opt_eps"] = np.float64(m.optimizer.defaults["eps"])
+    out["opt_betas"] = np.array(m.optimizer.defaults["betas"], np.float64)
+
+    def do_step(k, iteration, skip=()):
+        out[f"opt_s{k}_xyzlr"] = np.float64(m.update_learning_rate(iteration))
+        for name in OPT_GROUPS:
+            for i, prm in enumerate(params_of(name)):
+                if name in skip:
+                    prm.grad = None
+                    continue
+                scale = 10.0 ** float(torch.randint(-6, 1, (1,), generator=g))  # gradients span many magnitudes
+                prm.grad = rnd(*prm.shape) * scale
+                if name == "opacity":
+                    prm.grad[::7] = 0.0  # exact zeros: invisible Gaussians
+                out[f"opt_s{k}_g_{name}_{i}"] = prm.grad.numpy().copy()
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+
+    for k in range(3):
+        do_step(k, 1 + k)
+    # densification_postfix: 40 new points
+    n_new = 40
+    new = dict(xyz=rnd(n_new, 3), f_dc=rnd(n_new, 1, 3), f_rest=rnd(n_new, 3, 3), opacity=rnd(n_new, 1),
+               scaling=rnd(n_new, 3), rotation=rnd(n_new, 4), embeddings=rnd(n_new, 24))
+    for name, t in new.items():
+        out[f"opt_cat_{name}"] = t.numpy().copy()
+    m.densification_postfix(new["xyz"], new["f_dc"], new["f_rest"], new["opacity"], new["scaling"], new["rotation"],
+                            new["embeddings"])
+    mask = torch.rand(n + n_new, generator=g) < 0.3
+    out["opt_prune_mask"] = mask.numpy().copy()
+    m.prune_points(mask)
+    do_step(3, 200, skip=("embeddings", "appearance_mlp"))
+    do_step(4, 201)
+    new_op = rnd(*m._opacity.shape)
+    out["opt_replace_opacity"] = new_op.numpy().copy()
+    m._opacity = m.replace_tensor_to_optimizer(new_op, "opacity")["opacity"]
+    do_step(5, 202)
+    for name in OPT_GROUPS:
+        for i, prm in enumerate(params_of(name)):
+            st = m.optimizer.state[prm]
+            out[f"opt_final_{name}_{i}"] = prm.detach().numpy().copy()
+            out[f"opt_final_m_{name}_{i}"] = st["exp_avg"].numpy().copy()
+            out[f"opt_final_v_{name}_{i}"] = st["exp_avg_sq"].numpy().copy()
+            out[f"opt_final_step_{name}_{i}"] = np.float64(float(st["step"]))
+    path = os.path.join(HERE, "reference_optimizer.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     _cpu_redirect()
     sys.path.insert(0, REF)
@@ -185,6 +282,7 @@ def main():
     path = os.path.join(HERE, "reference_helpers.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+    make_optimizer_golden(gm)
 
 
 if __name__ == "__main__":
