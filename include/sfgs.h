@@ -261,6 +261,32 @@ typedef struct SfgsAdamTensor {
 } SfgsAdamTensor;
 int sfgs_adam_step(const SfgsAdamTensor* tensors, int32_t count, void* stream);
 
+/* utils/sh_utils.py:57-112 eval_sh: out[n,c] = sum_{k < (deg+1)^2} basis_k(dirs[n]) * sh[n,c,k], the reference's
+ * channel-major layout sh[N,3,K] with K >= (deg+1)^2 stored coefficients (used by render() at
+ * gaussian_renderer/__init__.py:115,124). No normalisation of dirs, no +0.5, no clamp -- like the reference function.
+ * backward: g_sh[N,3,K] fully written (zeros beyond the active degree), g_dirs[N,3] optional. */
+int sfgs_sh_eval_forward(int32_t N, int32_t deg, int32_t K, const float* sh, const float* dirs, float* out,
+                         void* stream);
+int sfgs_sh_eval_backward(int32_t N, int32_t deg, int32_t K, const float* sh, const float* dirs, const float* g_out,
+                          float* g_sh, float* g_dirs_or_null, void* stream);
+
+/* Row compaction of many tensors by ONE keep-mask (replaces the 26 `tensor[mask]` operations of
+ * GaussianModel.prune_points/_prune_optimizer, scene/gaussian_model.py:563-603). keep[N]: bool/uint8, nonzero = the
+ * row survives. sfgs_compact_plan scans the mask into caller-owned scratch and, if kept_out != NULL, synchronises the
+ * stream once to report the number of surviving rows (the caller allocates dst tensors of that many rows).
+ * sfgs_compact_rows then copies row i of every src to row rank(i) of its dst in one launch; src/dst are device
+ * pointers to contiguous [N, row_bytes] / [kept, row_bytes] storage, `tensors` is a HOST array. */
+typedef struct SfgsCompactTensor {
+  const void* src;
+  void* dst;
+  int64_t row_bytes;
+} SfgsCompactTensor;
+size_t sfgs_compact_scratch_bytes(int64_t N);
+int sfgs_compact_plan(const unsigned char* keep, int64_t N, void* scratch, size_t scratch_bytes, int64_t* kept_out,
+                      void* stream);
+int sfgs_compact_rows(const unsigned char* keep, int64_t N, const void* scratch, const SfgsCompactTensor* tensors,
+                      int32_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

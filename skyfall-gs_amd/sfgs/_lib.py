@@ -47,6 +47,10 @@ class SfgsAdamTensor(C.Structure):
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("reserved", C.c_float)]
 
 
+class SfgsCompactTensor(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]
+
+
 class SfgsRasterCounters(C.Structure):
     _fields_ = [("num_duplicates", C.c_int64), ("num_duplicates_ref", C.c_int64), ("num_visible", C.c_int64),
                 ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64)]
@@ -80,6 +84,11 @@ SYMBOLS = {
     "sfgs_filter3d": (C.c_int, [_V, _I32, _V, _I32, C.c_double, _V, _V, _SZ, _V]),
     "sfgs_densify_stats": (C.c_int, [_I32, _V, _V, _V, _V, _V, _V, _V]),
     "sfgs_adam_step": (C.c_int, [C.POINTER(SfgsAdamTensor), _I32, _V]),
+    "sfgs_sh_eval_forward": (C.c_int, [_I32, _I32, _I32, _V, _V, _V, _V]),
+    "sfgs_sh_eval_backward": (C.c_int, [_I32, _I32, _I32, _V, _V, _V, _V, _V, _V]),
+    "sfgs_compact_scratch_bytes": (_SZ, [_I64]),
+    "sfgs_compact_plan": (C.c_int, [_V, _I64, _V, _SZ, C.POINTER(C.c_int64), _V]),
+    "sfgs_compact_rows": (C.c_int, [_V, _I64, _V, C.POINTER(SfgsCompactTensor), _I32, _V]),
     "sfgs_prepass_forward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V]),
     "sfgs_prepass_backward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V, _V, _V, _V]),
 }

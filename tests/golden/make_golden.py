@@ -145,6 +145,27 @@ def make_optimizer_golden(gm):
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def make_sh_grad_golden(eval_sh):
+    """the REAL eval_sh (utils/sh_utils.py:57-112) forward + autograd gradients w.r.t. the coefficients
+    and the directions, degrees 0-3, with more stored coefficients than the active degree uses (as in render())."""
+    g = torch.Generator().manual_seed(777)
+    out = {}
+    n, K = 96, 16
+    for deg in range(4):
+        sh = torch.randn(n, 3, K, generator=g).requires_grad_(True)
+        d = torch.randn(n, 3, generator=g)
+        dirs = (d / d.norm(dim=1, keepdim=True)).detach().requires_grad_(True)
+        w = torch.randn(n, 3, generator=g)
+        val = eval_sh(deg, sh, dirs)
+        (val * w).sum().backward()
+        for k, v in dict(sh=sh.detach(), dirs=dirs.detach(), w=w, out=val.detach(), g_sh=sh.grad,
+                         g_dirs=dirs.grad if dirs.grad is not None else torch.zeros_like(dirs)).items():
+            out[f"shg{deg}_{k}"] = v.numpy().copy()
+    path = os.path.join(HERE, "reference_sh_grad.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     _cpu_redirect()
     sys.path.insert(0, REF)
@@ -283,6 +304,7 @@ def main():
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
     make_optimizer_golden(gm)
+    make_sh_grad_golden(eval_sh)
 
 
 if __name__ == "__main__":
