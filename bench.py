@@ -71,7 +71,7 @@ def main():
 
     from sfgs import _lib as L
     from sfgs.synth import scene, upstream_grads
-    from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, last_counters
+    from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, collect_full_counters, last_counters
     L.load()
 
     W, H, N = args.width, args.height, args.n
@@ -114,6 +114,12 @@ def main():
     # Warm-up with every kernel timed (HIP events on the launch stream): gives the per-kernel split and names the
     # dominant kernel. The timed region then brackets ONLY that kernel (each event pair costs the GPU ~4 us of
     # bubble; 9 kernels x 2 events per step would inflate the step by ~5 %).
+    # one untimed frame with the diagnostic counter read (full stream sync) for max_tile_list; the timed steps use
+    # the default mid-frame read
+    collect_full_counters(True)
+    step()
+    max_tile_list = last_counters()["max_tile_list"]
+    collect_full_counters(False)
     L.profile_select(None)
     n_prof = max(args.warmup - 1, 1) if args.warmup else 0   # the first step sizes the scratch (may re-plan): not timed
     for i in range(args.warmup):
@@ -200,7 +206,7 @@ def main():
                                    f"{'colors_precomp' if sh < 0 else 'SH degree %d in-kernel' % sh}, "
                                    f"kernel_size=0.1, seed=rank, one scene per GPU",
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
-                       "max_tile_list": cnt["max_tile_list"], "parallelism": f"scene-per-gpu x{world}"},
+                       "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}"},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 5
+#define SFGS_ABI_VERSION 6
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -147,11 +147,17 @@ int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse
  * (Gaussian, 32x32-pixel coarse bin) holding the mask of the 8x8 tiles it can contribute to, appended
  * to that bin's slab in `bins` (coarse_capacity items per bin; dup_capacity duplicate indices).
  * Neither count is known beforehand: if the counters report overflow, call again with a bins blob
- * sized for counters.num_duplicates / counters.max_coarse_bin. Asynchronous on `stream`. */
+ * sized for counters.num_duplicates / counters.max_coarse_bin. Asynchronous on `stream`.
+ * counters_pinned_host (optional): 64 bytes of PINNED host memory (hipHostMalloc / torch pin_memory) that the
+ * plan's last kernel fills with the frame's counters. Record an event right after this call, enqueue
+ * sfgs_raster_forward_render, THEN wait for the event and sfgs_raster_counters_decode the buffer: the capacity
+ * check overlaps with the render stage instead of draining the stream (max_tile_list is produced by the render
+ * stage and reads 0 there; sfgs_raster_read_counters after the render returns it). */
 int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii,
                              void* geom, size_t geom_bytes, void* tiles, size_t tiles_bytes,
                              void* bins, size_t bins_bytes, int64_t dup_capacity,
-                             int64_t coarse_capacity, void* stream);
+                             int64_t coarse_capacity, void* counters_pinned_host, void* stream);
+int sfgs_raster_counters_decode(const void* host_64, SfgsRasterCounters* out); /* host only, no GPU work */
 
 /* Copies the plan counters to the host. SYNCHRONISES `stream` (the one host sync of the forward,
  * as in the reference, where the duplicate total sizes the sort buffers). */

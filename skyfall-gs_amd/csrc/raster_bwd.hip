@@ -71,6 +71,54 @@ __device__ __forceinline__ void phase2_step(Phase2Acc& a, float u, float w, floa
   asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
 }
 
+// Phase 2 when the sample points sit on the pixel grid (no ray jitter: subpixel_offset absent or all zero, the
+// default of train.py and of every render script). In tile-centred coordinates pixel I of a lane's 2x8 group has the
+// COMPILE-TIME column cx = (I & 7) - 3.5 and row r = I >> 3, so the six polynomial sums are carried as raw per-row
+// moments  S_r = sum u,  X_r = sum u cx,  XX_r = sum u cx^2  (3 instructions per pixel instead of 10) and recentred
+// on the splat's mean once per batch (phase2_grid_finish); the two |.| sums need the linear forms
+//   lx = cA dx + cB dy = kx_r - cA cx,   ly = cC dy + cB dx = ky_r - cB cx     (dx = m_x - s_x, dy = m_y - s_y)
+// which are one multiply-add each. |cx| <= 3.5, so recentring loses at most ~12 / dx^2 ulps -- far inside the
+// gradient tolerance -- and nothing when the mean is far from the tile.
+struct Phase2Grid {
+  float S0, S1, X0, X1, XX0, XX1, ax, ay, r, g, b, d;
+};
+
+template <int I>
+__device__ __forceinline__ void phase2_grid_step(Phase2Grid& a, float u, float w, float ncA, float ncB, float kx0,
+                                                 float kx1, float ky0, float ky1, float g0, float g1, float g2,
+                                                 float g3) {
+  constexpr float cx = (float)(I & 7) - 3.5f;
+  float lx, ly;
+  if constexpr (I < 8) {
+    a.S0 += u; a.X0 = fmaf(u, cx, a.X0); a.XX0 = fmaf(u, cx * cx, a.XX0);
+    lx = fmaf(ncA, cx, kx0); ly = fmaf(ncB, cx, ky0);
+  } else {
+    a.S1 += u; a.X1 = fmaf(u, cx, a.X1); a.XX1 = fmaf(u, cx * cx, a.XX1);
+    lx = fmaf(ncA, cx, kx1); ly = fmaf(ncB, cx, ky1);
+  }
+  a.ax = fmaf(fabsf(u), fabsf(lx), a.ax);
+  a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(I));
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(I));
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(I));
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
+}
+
+// raw moments -> the sums about the mean that Phase2Acc carries (mxl = m_x - tile centre x, dy_r = m_y - y of row r)
+__device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, float mxl, float dy0, float dy1) {
+  Phase2Acc o;
+  const float Su = a.S0 + a.S1, X = a.X0 + a.X1, XX = a.XX0 + a.XX1;
+  const float t0 = mxl * a.S0 - a.X0, t1 = mxl * a.S1 - a.X1;  // sum u dx of each row
+  o.u = Su;
+  o.x = t0 + t1;
+  o.y = dy0 * a.S0 + dy1 * a.S1;
+  o.xx = mxl * (o.x - X) + XX;
+  o.xy = dy0 * t0 + dy1 * t1;
+  o.yy = (dy0 * dy0) * a.S0 + (dy1 * dy1) * a.S1;
+  o.ax = a.ax; o.ay = a.ay; o.r = a.r; o.g = a.g; o.b = a.b; o.d = a.d;
+  return o;
+}
+
 template <int B>
 __global__ void __launch_bounds__(256, 4)
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
@@ -78,7 +126,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                     const float* __restrict__ dL_dalpha, float4* __restrict__ dupgrad) {
+                     const float* __restrict__ dL_dalpha, float4* __restrict__ dupgrad,
+                     const unsigned long long* __restrict__ hdr) {
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[4];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
@@ -130,6 +179,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   if (kmax == 0) return;
 
   const int ej = lane & (B - 1), grp = lane / B;  // phase-2 role of this lane
+  // wave-uniform: sample points on the pixel grid (max |subpixel_offset| of the plan == 0)?
+  const bool on_grid = !(kf.subpix && (unsigned)hdr[HDR_SUBPIX_BOUND] != 0u);
+  const float ocx = (float)(tx * 8) + 3.5f, ocy = (float)(ty * 8) + 3.5f;  // tile centre
   const int nbatch = (int)((kmax + B - 1) / B);
   for (int bi = nbatch - 1; bi >= 0; --bi) {
     const unsigned b0 = (unsigned)bi * B;
@@ -144,6 +196,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 1: lane = pixel -------------------------------------------------------------------
+#pragma unroll 4
     for (int j = (int)cnt - 1; j >= 0; --j) {
       const unsigned k = b0 + (unsigned)j;
       const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
@@ -160,7 +213,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
     // Every lane runs the 16 steps (a DPP source lane must be active); lanes of entries beyond cnt read
     // stale U/Wm rows and their sums are discarded below.
-    Phase2Acc pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Phase2Acc pa;
     float op, cA, cB, cC;
     {
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
@@ -169,19 +222,41 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       const float* Urow = &lds.U[ej * ROW + grp * B];
       const float* Wrow = &lds.Wm[ej * ROW + grp * B];
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
-#define SFGS_P2(I) phase2_step<I>(pa, Urow[I], Wrow[I], mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
-      // a rolled loop over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
+      // rolled loops over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
       // compiler from hoisting all 32 LDS loads above the arithmetic, which costs ~30 VGPRs
+      if (on_grid) {
+        const float mxl = mx - ocx;
+        const float dy0 = (my - ocy) - ((float)(grp * 2) - 3.5f), dy1 = dy0 - 1.0f;
+        const float kx0 = fmaf(cA, mxl, cB * dy0), kx1 = fmaf(cA, mxl, cB * dy1);
+        const float ky0 = fmaf(cC, dy0, cB * mxl), ky1 = fmaf(cC, dy1, cB * mxl);
+        const float ncA = -cA, ncB = -cB;
+        Phase2Grid pg = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define SFGS_P2(I) phase2_grid_step<I>(pg, Urow[I], Wrow[I], ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
 #pragma nounroll
-      for (int c = 0; c < 4; ++c) {
-        switch (c) {
-          case 0: SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); break;
-          case 1: SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7); break;
-          case 2: SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); break;
-          default: SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15); break;
+        for (int c = 0; c < 4; ++c) {
+          switch (c) {
+            case 0: SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); break;
+            case 1: SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7); break;
+            case 2: SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); break;
+            default: SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15); break;
+          }
         }
-      }
 #undef SFGS_P2
+        pa = phase2_grid_finish(pg, mxl, dy0, dy1);
+      } else {
+        pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define SFGS_P2(I) phase2_step<I>(pa, Urow[I], Wrow[I], mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
+#pragma nounroll
+        for (int c = 0; c < 4; ++c) {
+          switch (c) {
+            case 0: SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); break;
+            case 1: SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7); break;
+            case 2: SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); break;
+            default: SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15); break;
+          }
+        }
+#undef SFGS_P2
+      }
     }
     // combine the NGRP partial lanes of every entry (fixed order -> deterministic)
     float acc[12] = {pa.u, pa.x, pa.y, pa.ax, pa.ay, pa.xx, pa.xy, pa.yy, pa.r, pa.g, pa.b, pa.d};
@@ -311,7 +386,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, (float4*)dupgrad); }
+                       dL_dalpha, (float4*)dupgrad, tv.hdr); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);

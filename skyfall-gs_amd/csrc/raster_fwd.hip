@@ -218,7 +218,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
 plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
-                 const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr) {
+                 const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
+                 unsigned long long* __restrict__ host_out) {
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
   unsigned long long nvis = 0, dref = 0, cmax = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
@@ -238,6 +239,13 @@ plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, con
       hdr[pass == 0 ? HDR_N_VIS : pass == 1 ? HDR_D_REF : HDR_MAX_COARSE] = t;
     }
     __syncthreads();
+  }
+  // publish the first 8 header words straight into the caller's pinned host buffer (fine-grained memory: visible
+  // to the host once this kernel has completed) -- the host can then decide about a capacity retry while the render
+  // stage is already running, without a copy engine round trip in the middle of the stream
+  if (threadIdx.x == 0 && host_out) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) host_out[i] = hdr[i];
   }
 }
 
@@ -661,7 +669,8 @@ extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int
 
 extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* geom,
                                         size_t geom_sz, void* tiles, size_t tiles_sz, void* bins, size_t bins_sz,
-                                        int64_t dup_capacity, int64_t coarse_capacity, void* stream_) {
+                                        int64_t dup_capacity, int64_t coarse_capacity, void* counters_pinned_host,
+                                        void* stream_) {
   if (int rc = check_frame(frame)) return rc;
   if (int rc = check_gaussians(frame, g)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -704,7 +713,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
-                       tv.block_dref, tv.hdr); }
+                       tv.block_dref, tv.hdr, (unsigned long long*)counters_pinned_host); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;
 }
@@ -716,6 +725,12 @@ static void unpack_counters(const unsigned long long* h, SfgsRasterCounters* out
   out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
   out->overflow = (int64_t)h[HDR_OVERFLOW];
   out->max_coarse_bin = (int64_t)h[HDR_MAX_COARSE];
+}
+
+extern "C" int sfgs_raster_counters_decode(const void* host_64, SfgsRasterCounters* out) {
+  SFGS_REQUIRE(host_64 && out, SFGS_E_ARG, "NULL argument");
+  unpack_counters((const unsigned long long*)host_64, out);
+  return SFGS_OK;
 }
 
 extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream_) {

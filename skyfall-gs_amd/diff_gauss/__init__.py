@@ -21,7 +21,8 @@ import torch.nn as nn
 
 from sfgs import _lib as L
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_counters"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_counters",
+           "collect_full_counters"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -44,6 +45,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _last_counters = {}
+_stats = {"full": False}
 _pinned = {}     # device index -> pinned host buffer the counters are read through
 _ncb_cache = {}  # (W, H) -> number of coarse bins
 _zeros = {}      # device index -> 1-element zero tensor
@@ -67,8 +69,15 @@ def _zero(dev):
 _cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin capacity) to plan with
 
 
+def collect_full_counters(on=True):
+    """Diagnostics switch: read the counters after the render stage (a full stream sync per frame) so that
+    `last_counters()["max_tile_list"]` is filled in; off by default (the counters are then read mid-frame and
+    max_tile_list reads 0)."""
+    _stats["full"] = bool(on)
+
+
 def last_counters():
-    """Counters of the most recent forward on this process (D_eff, D_ref, N_vis, longest list, ...): bench/tests."""
+    """Counters of the most recent forward on this process (duplicates, visible Gaussians, capacities ...)."""
     return dict(_last_counters)
 
 
@@ -165,22 +174,32 @@ class _Rasterize(torch.autograd.Function):
                 scratch = torch.empty(total, dtype=torch.uint8, device=dev)
                 geom, tiles, bins = scratch[:o_tiles], scratch[o_tiles:o_bins], scratch[o_bins:o_image]
                 image = scratch[o_image:] if need_bwd else None
-                # plan and render are enqueued back to back (no mid-frame host sync: the GPU never idles inside
-                # the forward); the counters are read afterwards -- the one host sync -- and both stages are
-                # redone in the rare case a capacity was exceeded (an overflowing plan is memory-safe).
+                # plan and render are enqueued back to back. The plan's last kernel writes the frame's counters into
+                # pinned host memory; an event recorded between the two stages lets the host read them -- the one
+                # host wait of the frame -- WHILE the render stage runs, so the wrapper's epilogue, the caller's loss
+                # and the backward's launch overlap with the compositing kernel instead of following a drained
+                # stream. Both stages are redone in the rare case a capacity was exceeded (an overflowing plan is
+                # memory-safe).
+                pinned = _pinned.get(dev.index)
+                if pinned is None:
+                    pinned = _pinned[dev.index] = (torch.empty(8, dtype=torch.int64).pin_memory(),
+                                                   torch.cuda.Event(enable_timing=False, blocking=False))
+                pin, ev = pinned
+                tstream = torch.cuda.current_stream(dev)
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
-                                                     bins.numel(), cap, ccap, stream))
+                                                     bins.numel(), cap, ccap, L.C.c_void_p(pin.data_ptr()), stream))
+                ev.record(tstream)
                 L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins),
                                                        bins.numel(), cap, ccap, -1, L.ptr(color), L.ptr(depth),
                                                        L.ptr(alpha), L.ptr(image), 0 if image is None else image.numel(),
                                                        stream))
                 cnt = L.SfgsRasterCounters()
-                pinned = _pinned.get(dev.index)
-                if pinned is None:
-                    pinned = _pinned[dev.index] = torch.empty(8, dtype=torch.int64).pin_memory()
-                L.check(lib.sfgs_raster_read_counters_pinned(L.ptr(tiles), L.C.c_void_p(pinned.data_ptr()),
-                                                             L.C.byref(cnt), stream))
+                if _stats["full"]:  # diagnostics: wait for the render too, so that max_tile_list is included
+                    L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))
+                else:
+                    ev.synchronize()
+                    L.check(lib.sfgs_raster_counters_decode(L.C.c_void_p(pin.data_ptr()), L.C.byref(cnt)))
                 D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
                 if not cnt.overflow and D <= cap and cmax <= ccap:
                     break

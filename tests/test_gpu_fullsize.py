@@ -39,10 +39,14 @@ def _render(frame, t, colors=None, grad=False, **kw):
 
 
 def test_full_size_counters_and_sanity(full):
-    from diff_gauss import last_counters
+    from diff_gauss import collect_full_counters, last_counters
     frame, t = full
-    with torch.no_grad():
-        (color, depth, norm, alpha, radii, _), _ = _render(frame, t)
+    collect_full_counters(True)
+    try:
+        with torch.no_grad():
+            (color, depth, norm, alpha, radii, _), _ = _render(frame, t)
+    finally:
+        collect_full_counters(False)
     c = last_counters()
     assert c["num_visible"] == int((radii > 0).sum()) and c["num_visible"] > 0.99 * N
     assert c["num_duplicates"] > N and c["max_tile_list"] < 4096

@@ -109,7 +109,7 @@ def test_gpu_free_entry_points_and_error_convention():
     with pytest.raises(RuntimeError, match="libsfgs error"):
         L.check(lib.sfgs_raster_sizes(-1, 64, 64, 0, 0, C.byref(sizes)))
     # a NULL frame is rejected before any HIP call
-    assert lib.sfgs_raster_forward_plan(None, None, None, None, 0, None, 0, None, 0, 0, 0, None) == -1
+    assert lib.sfgs_raster_forward_plan(None, None, None, None, 0, None, 0, None, 0, 0, 0, None, None) == -1
     assert lib.sfgs_ssim_scratch_bytes(1, 3, 1080, 1920, 1) > 3 * 3 * 1080 * 1920 * 4
     assert lib.sfgs_knn_scratch_bytes(1000) == 0
     assert lib.sfgs_profile_kernel_count() >= 10 and lib.sfgs_profile_kernel_name(1) == b"preprocess"
