@@ -166,6 +166,74 @@ def make_sh_grad_golden(eval_sh):
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def _ref_functions(path, names, namespace):
+    """exec only the named top-level functions of a reference file (its module-level imports are too heavy)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), namespace)
+    return [namespace[n] for n in names]
+
+
+def make_ply_golden(gm):
+    """the REAL save_ply / save_fused_ply / load_ply (scene/gaussian_model.py:418-547),
+    load_standard_ply / detect_sh_degree_from_ply (render_video_from_ply.py:163-275) and storePly / fetchPly
+    (scene/dataset_readers.py:126-148) run on top of sfgs.ply's plyfile stand-in (plyfile itself is not installed
+    here): pins the column names / order / transposes / dtypes the reference produces and expects."""
+    import tempfile
+    import types
+    sys.path.insert(0, os.path.join(HERE, "..", "..", "skyfall-gs_amd"))
+    from sfgs import ply as sply
+    assert gm.PlyData is object  # the stub main() installed for the heavy import
+    gm.PlyData, gm.PlyElement = sply.PlyData, sply.PlyElement
+    sys.modules["plyfile"].PlyData, sys.modules["plyfile"].PlyElement = sply.PlyData, sply.PlyElement
+    g = torch.Generator().manual_seed(2468)
+    out = {}
+    m = gm.GaussianModel(1, False, 4, 32)
+    n = 37
+    m._xyz = torch.randn(n, 3, generator=g) * 4
+    m._features_dc = torch.randn(n, 1, 3, generator=g)
+    m._features_rest = torch.randn(n, 3, 3, generator=g) * 0.2
+    m._opacity = torch.randn(n, 1, generator=g)
+    m._scaling = torch.randn(n, 3, generator=g) - 1.5
+    m._rotation = torch.randn(n, 4, generator=g)
+    m.filter_3D = torch.exp(torch.randn(n, 1, generator=g) - 2.5)
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "filter_3D"):
+        out["ply_in" + k] = getattr(m, k).numpy().copy()
+    with tempfile.TemporaryDirectory() as td:
+        p1, p2, p3 = (os.path.join(td, "sub", f) for f in ("a.ply", "fused.ply", "pts.ply"))
+        m.save_ply(p1)
+        m.save_fused_ply(p2)
+        out["ply_save_bytes"] = np.fromfile(p1, dtype=np.uint8)
+        out["ply_fused_bytes"] = np.fromfile(p2, dtype=np.uint8)
+        m2 = gm.GaussianModel(1, False, 4, 32)
+        m2.load_ply(p1)
+        out["ply_load_filter_3D"] = m2.filter_3D.numpy().copy()
+        out["ply_load_active_sh_degree"] = np.int64(m2.active_sh_degree)
+        assert m2._xyz.numel() == 0  # the reference's load_ply leaves the parameters untouched (assignments commented out)
+        ns = {"np": np, "torch": torch, "GaussianModel": gm.GaussianModel}
+        load_standard_ply, detect = _ref_functions(os.path.join(REF, "render_video_from_ply.py"),
+                                                   ["load_standard_ply", "detect_sh_degree_from_ply"], ns)
+        out["ply_detect_sh_degree"] = np.int64(detect(p2))
+        m3 = gm.GaussianModel(1, False, 4, 32)
+        load_standard_ply(m3, p2)
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "filter_3D"):
+            out["ply_std" + k] = getattr(m3, k).detach().numpy().copy()
+        ns2 = {"np": np, "PlyData": sply.PlyData, "PlyElement": sply.PlyElement,
+               "BasicPointCloud": lambda points, colors, normals: (points, colors, normals)}
+        fetchPly, storePly = _ref_functions(os.path.join(REF, "scene", "dataset_readers.py"), ["fetchPly", "storePly"], ns2)
+        xyz = (torch.randn(29, 3, generator=g) * 10).numpy()
+        rgb = (torch.rand(29, 3, generator=g) * 255).numpy()
+        storePly(p3, xyz, rgb)
+        out["ply_store_xyz"], out["ply_store_rgb"] = xyz, rgb
+        out["ply_store_bytes"] = np.fromfile(p3, dtype=np.uint8)
+        pts, cols, nrm = fetchPly(p3)
+        out["ply_fetch_points"], out["ply_fetch_colors"], out["ply_fetch_normals"] = pts, cols, nrm
+    path = os.path.join(HERE, "reference_ply.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     _cpu_redirect()
     sys.path.insert(0, REF)
@@ -305,6 +373,7 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
     make_optimizer_golden(gm)
     make_sh_grad_golden(eval_sh)
+    make_ply_golden(gm)
 
 
 if __name__ == "__main__":
