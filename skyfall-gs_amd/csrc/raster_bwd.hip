@@ -131,7 +131,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[4];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // readfirstlane: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[wave];
@@ -169,6 +170,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   unsigned kmax = last;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, d));
+  kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)kmax);
 
   // list entries behind every pixel's last contributor receive zero gradient
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);

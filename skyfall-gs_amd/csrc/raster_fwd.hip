@@ -545,7 +545,9 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out) {
   __shared__ float4 stage[4][64 * 3];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // readfirstlane: tells the compiler the wave index (hence the tile, its list range and every loop bound below)
+  // is wave-uniform -> scalar loads, SGPR loop counters and s_cbranch instead of exec-mask loops
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   const int W = kf.W, H = kf.H;
@@ -600,7 +602,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     }
     __builtin_amdgcn_wave_barrier();
   }
-  const float T = ps.T_out, C0 = ps.C0, C1 = ps.C1, C2 = ps.C2, D = ps.D;
+  const float T = pixel_fwd_final_T(ps), C0 = ps.C0, C1 = ps.C1, C2 = ps.C2, D = ps.D;
   const unsigned last = ps.last;
   if (inside) {
     const size_t P = (size_t)W * H;

@@ -406,29 +406,31 @@ SFGS_HD SplatEval eval_splat(float mx, float my, float qa, float qb, float qc, f
 }
 
 struct PixelFwd {
-  float T;       // live transmittance; becomes 0 when the pixel saturates (then nothing can be accepted any more)
-  float T_out;   // transmittance after the last ACCEPTED splat = the reference's final T
+  // live transmittance, SIGNED: > 0 while the pixel can still accept splats; when the pixel saturates it becomes
+  // -|T| (the transmittance after the last ACCEPTED splat, sign-flipped), which makes every later test_T negative,
+  // i.e. "stop" again, without a separate saturated flag or a second T register. |T| is the reference's final T.
+  float T;
   float C0, C1, C2, D;
   unsigned last; // 1-based list position of the last accepted splat
 };
 
 SFGS_HD void pixel_fwd_init(PixelFwd& s, bool inside) {
-  s.T = inside ? 1.f : 0.f; s.T_out = 1.f;
+  s.T = inside ? 1.f : -1.f;   // pixels outside the image: saturated from the start, never written
   s.C0 = s.C1 = s.C2 = s.D = 0.f; s.last = 0;
 }
 
+SFGS_HD float pixel_fwd_final_T(const PixelFwd& s) { return fabsf(s.T); }
+
 // k = 0-based list position. Branch-free restatement of SURVEY A.4:
 //   skip if power > 0 or alpha < 1/255;  stop (splat NOT applied) if T (1 - alpha) < 1e-4;  else blend.
-// A stopped pixel keeps T = 0, so every later splat "stops" again and nothing is accumulated.
 SFGS_HD void pixel_fwd_step(PixelFwd& s, const SplatEval& e, float depth, float r, float g, float b, unsigned k) {
   const float test_T = s.T * (1.0f - e.alpha);
   const bool acc = e.ok && !(test_T < 0.0001f);
   const float w = acc ? e.alpha * s.T : 0.f;
   s.C0 = fmaf(r, w, s.C0); s.C1 = fmaf(g, w, s.C1); s.C2 = fmaf(b, w, s.C2);
   s.D = fmaf(depth, w, s.D);
-  s.T_out = acc ? test_T : s.T_out;
   s.last = acc ? k + 1 : s.last;
-  s.T = acc ? test_T : (e.ok ? 0.f : s.T);
+  s.T = acc ? test_T : (e.ok ? -fabsf(s.T) : s.T);
 }
 
 struct PixelBwd {

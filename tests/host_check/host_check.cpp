@@ -94,13 +94,13 @@ int hc_render(const HcFrame* hf, int32_t N, const float* means, const float* sca
         const SplatEval ev = eval_splat(r.mx, r.my, r.qa, r.qb, r.qc, r.op, sx, sy);
         pixel_fwd_step(ps, ev, r.depth, r.r, r.g, r.b, (unsigned)k);
       }
-      out_color[pix] = fmaf(ps.T_out, f.bg[0], ps.C0);
-      out_color[P + pix] = fmaf(ps.T_out, f.bg[1], ps.C1);
-      out_color[2 * P + pix] = fmaf(ps.T_out, f.bg[2], ps.C2);
-      const float a = 1.0f - ps.T_out;
+      out_color[pix] = fmaf(pixel_fwd_final_T(ps), f.bg[0], ps.C0);
+      out_color[P + pix] = fmaf(pixel_fwd_final_T(ps), f.bg[1], ps.C1);
+      out_color[2 * P + pix] = fmaf(pixel_fwd_final_T(ps), f.bg[2], ps.C2);
+      const float a = 1.0f - pixel_fwd_final_T(ps);
       out_alpha[pix] = a;
       out_depth[pix] = f.depth_mode == 0 ? ps.D / a : ps.D;
-      n_contrib[pix] = ps.last; final_T[pix] = ps.T_out; dacc[pix] = ps.D;
+      n_contrib[pix] = ps.last; final_T[pix] = pixel_fwd_final_T(ps); dacc[pix] = ps.D;
     }
   if (!g_means3D) return 0;
 
