@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "skyfall-gs_amd")):
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+VALU_PEAK_TFLOPS = 157.3    # MI355X FP32 vector peak (MI355X_MICROARCH.md): 256 CUs x 128 lanes x 2 FLOP x 2.4 GHz
 FP32_PEAK_TFLOPS = 157.3
 APPEARANCE_MLP_FLOATS = 24966  # shared parameters all-reduced per step (scene/gaussian_model.py:52-58)
 
@@ -186,6 +187,15 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(dom),
                     "avg_launch_ms": round(per_kernel[dom]["ms_per_step"], 4),
                     "algorithmic_bytes_per_launch": int(kb.get(dom, 0))}
+        if dom.startswith("composite"):
+            # SURVEY 8(d)'s second line for the compositing kernels, which are VALU- not HBM-bound: every binned
+            # (Gaussian, 8x8 tile) pair is evaluated on the wave's 64 pixel lanes; 22 FLOP per (pixel, splat)
+            # evaluation is SURVEY's count for the forward blend (the backward does ~2.5x that, not credited)
+            pairs = 64 * D_eff
+            tf = pairs * 22 / dur / 1e12
+            roofline["valu"] = {"pair_evaluations_per_launch": int(pairs), "flop_per_pair": 22,
+                                "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / VALU_PEAK_TFLOPS, 4)}
     step_ach = B_step / (ms_step * 1e-3) / 1e9
     roofline_step = {"bound": "hbm", "achieved": round(step_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(step_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(B_step),

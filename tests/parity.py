@@ -8,7 +8,7 @@ GRAD_RTOL_L2 = 1e-3        # relative L2 per gradient tensor
 GRAD_RTOL_MAX = 2e-3       # relative L-inf (normalised by max |ref|)
 
 
-def image_report(name, got, ref):
+def image_report(name, got, ref, rtol=RGB_DEPTH_RTOL):
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
@@ -18,13 +18,13 @@ def image_report(name, got, ref):
     scale = max(np.abs(ref[ok]).max(), 1e-30) if ok.any() else 1.0
     err = np.zeros_like(ref)
     err[ok] = np.abs(got[ok] - ref[ok]) / scale
-    bad = err > RGB_DEPTH_RTOL
+    bad = err > rtol
     return dict(name=name, max_rel=float(err.max()), bad=int(bad.sum()), total=int(err.size))
 
 
-def assert_image_close(name, got, ref):
-    r = image_report(name, got, ref)
-    assert r["bad"] <= max(1, int(BORDERLINE_FRAC * r["total"])) or r["max_rel"] <= RGB_DEPTH_RTOL, r
+def assert_image_close(name, got, ref, rtol=RGB_DEPTH_RTOL):
+    r = image_report(name, got, ref, rtol)
+    assert r["bad"] <= max(1, int(BORDERLINE_FRAC * r["total"])) or r["max_rel"] <= rtol, r
     assert r["max_rel"] < 5e-2, r   # a flipped borderline splat moves a pixel by <= alpha*T*|c| ~ 1/255
     return r
 
