@@ -424,61 +424,62 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: per-tile sort by 64-bit key (depth bits << 32 | Gaussian id) == ascending (depth, Gaussian id),
-// SURVEY A.3. Normalised bitonic network: every comparator sorts ascending, so +inf padding stays at
-// the tail. One wave per tile, keys + 16-bit local payload indices in LDS.
+// K4b: per-tile sort of the lists the register network does not take (512 < L <= CAP), by 64-bit key
+// (depth bits << 32 | Gaussian id) == ascending (depth, Gaussian id), SURVEY A.3. Normalised bitonic network (every
+// comparator sorts ascending, so +inf padding stays at the tail) on keys + 16-bit local indices in LDS (40 KB: four
+// workgroups per CU); one 256-thread workgroup per tile, persistent over the device-side list of long tiles. Dense
+// frames (e.g. 16 M Gaussians at 1080p: every list ~1 800 long) run entirely through this kernel.
 template <int CAP>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 sort_tiles_lds_kernel(int lo, int hi, const uint32_t* __restrict__ long_tiles,
                       const unsigned long long* __restrict__ hdr, const uint2* __restrict__ tile_range,
                       const uint4* __restrict__ items, uint32_t* __restrict__ sorted_id,
                       uint32_t* __restrict__ sorted_dup) {
   __shared__ unsigned long long k[CAP];
-  __shared__ uint32_t dups[CAP];
   __shared__ unsigned short vi[CAP];
+  constexpr int NT = 256;
   const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
+  const int tid = threadIdx.x;
   for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
-  const uint2 tr = tile_range[long_tiles[li]];
-  const unsigned s = tr.x, e = tr.x + tr.y;
-  const int L = (int)(e - s);
-  if (L <= lo || L > hi) continue;
-  const int lane = threadIdx.x;
-  __syncthreads();
-  int n = 1;
-  while (n < L) n <<= 1;
-  for (int i = lane; i < n; i += 64) {
-    if (i < L) {
-      const uint4 it = items[s + i];
-      k[i] = ((unsigned long long)it.y << 32) | it.x;
-      dups[i] = it.z;
-    } else {
-      k[i] = ~0ull;
-    }
-    vi[i] = (unsigned short)i;
-  }
-  __syncthreads();
-  for (int size = 2; size <= n; size <<= 1) {
-    const int half = size >> 1;
-    for (int c = lane; c < (n >> 1); c += 64) {
-      const int blk = c / half, o = c - blk * half;
-      const int i = blk * size + o, j = blk * size + size - 1 - o;
-      const unsigned long long a = k[i], b = k[j];
-      if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
+    const uint2 tr = tile_range[long_tiles[li]];
+    const unsigned s = tr.x;
+    const int L = (int)tr.y;
+    if (L <= lo || L > hi) continue;
+    __syncthreads();
+    int n = 1;
+    while (n < L) n <<= 1;
+    for (int i = tid; i < n; i += NT) {
+      unsigned long long key = ~0ull;
+      if (i < L) {
+        const uint4 it = items[s + i];
+        key = ((unsigned long long)it.y << 32) | it.x;
+      }
+      k[i] = key;
+      vi[i] = (unsigned short)i;
     }
     __syncthreads();
-    for (int stride = half >> 1; stride >= 1; stride >>= 1) {
-      for (int c = lane; c < (n >> 1); c += 64) {
-        const int i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
+    for (int size = 2; size <= n; size <<= 1) {
+      const int half = size >> 1;
+      for (int c = tid; c < (n >> 1); c += NT) {
+        const int blk = c / half, o = c - blk * half;
+        const int i = blk * size + o, j = blk * size + size - 1 - o;
         const unsigned long long a = k[i], b = k[j];
         if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
       }
       __syncthreads();
+      for (int stride = half >> 1; stride >= 1; stride >>= 1) {
+        for (int c = tid; c < (n >> 1); c += NT) {
+          const int i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
+          const unsigned long long a = k[i], b = k[j];
+          if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
+        }
+        __syncthreads();
+      }
     }
-  }
-  for (int i = lane; i < L; i += 64) {
-    sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull);
-    sorted_dup[s + i] = dups[vi[i]];
-  }
+    for (int i = tid; i < L; i += NT) {
+      sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull);
+      sorted_dup[s + i] = items[s + vi[i]].z;  // payload fetched through the sorted local index (L2-resident)
+    }
   }
 }
 
@@ -788,7 +789,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
                          bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
     { ProfScope ps_(KID_SORT_MEDIUM, stream);
-      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(256), dim3(64), 0, stream, SORT_SMALL, SORT_CAP,
+      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(std::min(T8, 1024)), dim3(256), 0, stream, SORT_SMALL, SORT_CAP,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
     { ProfScope ps_(KID_SORT_GLOBAL, stream);
