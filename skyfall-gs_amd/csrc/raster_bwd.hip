@@ -298,7 +298,48 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
                       float* __restrict__ g_rots, float* __restrict__ g_opac, float* __restrict__ g_colors,
                       float* __restrict__ g_shs) {
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  if (g >= N) return;
+  const bool valid = g < N;
+  const int lane = threadIdx.x & 63;
+  // ---- sum this Gaussian's per-duplicate records (fixed order -> deterministic) -----------------------------------
+  // A splat that covers many tiles owns thousands of records: summing them in its own lane would leave the other 63
+  // lanes idle for that long, so above COOP records the whole wave strides over them and reduces across lanes.
+  constexpr unsigned COOP = 96;
+  const bool vis = valid && radii[g] > 0;
+  unsigned d0 = 0, cnt = 0;
+  if (vis) { const uint2 dr = dup[g]; d0 = dr.x; cnt = dr.y; }
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+  if (cnt <= COOP) {
+    for (unsigned d = d0; d < d0 + cnt; ++d) {
+      const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
+      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+    }
+  }
+  for (unsigned long long todo = __ballot(cnt > COOP); todo; todo &= todo - 1) {
+    const int src = __builtin_ctzll(todo);
+    const unsigned b0 = (unsigned)__shfl((int)d0, src), bn = (unsigned)__shfl((int)cnt, src);
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = 0.f;
+    for (unsigned i = lane; i < bn; i += 64) {
+      const size_t d = (size_t)(b0 + i) * 3;
+      const float4 x0 = dupgrad[d], x1 = dupgrad[d + 1], x2 = dupgrad[d + 2];
+      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w;
+      v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+      v[8] += x2.x; v[9] += x2.y; v[10] += x2.z; v[11] += x2.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v[i] += __shfl_xor(v[i], d);
+    }
+    if (lane == src) {
+      a0 = make_float4(v[0], v[1], v[2], v[3]); a1 = make_float4(v[4], v[5], v[6], v[7]);
+      a2 = make_float4(v[8], v[9], v[10], v[11]);
+    }
+  }
+  if (!valid) return;
   FrameParams f = load_frame(kf);
   f.sh_degree = DEG; f.sh_coeffs = K;
   GaussGrads out;
@@ -311,16 +352,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   float gshl[ROW];
 #pragma unroll
   for (int i = 0; i < ROW; ++i) gshl[i] = 0.f;
-  if (radii[g] > 0) {
-    const uint2 dr = dup[g];
-    const unsigned d0 = dr.x, d1 = dr.x + dr.y;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    for (unsigned d = d0; d < d1; ++d) {
-      const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
-      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
-    }
+  if (vis) {
     Grad2D A;
     A.gmx = a0.x; A.gmy = a0.y; A.absx = a0.z; A.absy = a0.w;
     A.gA = a1.x; A.gB = a1.y; A.gC = a1.z; A.gop = a1.w;

@@ -19,16 +19,33 @@
 
 namespace sfgs {
 
+constexpr int REG_SORT_SMALL = 512;  // lists up to here: sort_tiles_reg_kernel (<= 8 keys per lane, 8 waves per SIMD)
+constexpr int REG_SORT_MAX = 2048;   // lists up to here: register network too (16 / 32 keys per lane), separate kernel
+
 // ------------------------------------------------------------------------------------------------
 // max |subpixel_offset| -> header (float bits; non-negative floats order like unsigned ints)
 __global__ void __launch_bounds__(256) subpix_bound_kernel(const float* __restrict__ subpix, int64_t n,
                                                            unsigned long long* __restrict__ hdr) {
+  // float4 loads, a few hundred workgroups, ONE atomic per workgroup and none at all for an all-zero tensor (what the
+  // reference's render() passes when ray jitter is off): atomics to one address serialise at ~12 ns each
+  __shared__ float s_m[4];
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(subpix) & 15) ? 0 : (n >> 2);  // unaligned view: scalar tail only
+  const float4* __restrict__ v4 = reinterpret_cast<const float4*>(subpix);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = v4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(subpix[i]));
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-  if (lane_id() == 0) atomicMax((unsigned int*)&hdr[HDR_SUBPIX_BOUND], __float_as_uint(m));
+  if (lane_id() == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (m > 0.f) atomicMax((unsigned int*)&hdr[HDR_SUBPIX_BOUND], __float_as_uint(m));
+  }
 }
 
 // 16-bit hit mask of the 4x4 tiles of coarse bin (cbx, cby) that lie inside the walk range `br`
@@ -283,7 +300,7 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
       const int tx = (cb % CX) * COARSE + (tid & (COARSE - 1)), ty = (cb / CX) * COARSE + (tid / COARSE);
       if (tx < TX8 && ty < TY8) {
         tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
-        if (c > 512) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
+        if (c > REG_SORT_SMALL) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
       }
       cnt[tid] = off;  // becomes the per-tile cursor
       if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
@@ -416,121 +433,148 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
   if (t >= T8) return;
   const uint2 tr = tile_range[t];
   const int L = (int)tr.y;
-  if (L == 0 || L > 512) return;
+  if (L == 0 || L > REG_SORT_SMALL) return;
   if (L <= 64) sort_tile_in_registers<1>(tr.x, L, lane, items, sorted_id, sorted_dup);
   else if (L <= 128) sort_tile_in_registers<2>(tr.x, L, lane, items, sorted_id, sorted_dup);
   else if (L <= 256) sort_tile_in_registers<4>(tr.x, L, lane, items, sorted_id, sorted_dup);
   else sort_tile_in_registers<8>(tr.x, L, lane, items, sorted_id, sorted_dup);
 }
 
-// ------------------------------------------------------------------------------------------------
-// K4b: per-tile sort of the lists the register network does not take (512 < L <= CAP), by 64-bit key
-// (depth bits << 32 | Gaussian id) == ascending (depth, Gaussian id), SURVEY A.3. Normalised bitonic network (every
-// comparator sorts ascending, so +inf padding stays at the tail) on keys + 16-bit local indices in LDS (40 KB: four
-// workgroups per CU); one 256-thread workgroup per tile, persistent over the device-side list of long tiles. Dense
-// frames (e.g. 16 M Gaussians at 1080p: every list ~1 800 long) run entirely through this kernel.
-template <int CAP>
+// K4a': the same register network with EPL = 16 / 32 keys per lane for lists of 513..1024 / 1025..2048 entries
+// (low-elevation views, dense frames). Kernels of their own: 99 / 195 VGPRs would otherwise cut the occupancy of the
+// common short lists (and of each other). One wave per tile, persistent over the device-side list of long tiles.
+template <int EPL>
 __global__ void __launch_bounds__(256)
-sort_tiles_lds_kernel(int lo, int hi, const uint32_t* __restrict__ long_tiles,
-                      const unsigned long long* __restrict__ hdr, const uint2* __restrict__ tile_range,
-                      const uint4* __restrict__ items, uint32_t* __restrict__ sorted_id,
-                      uint32_t* __restrict__ sorted_dup) {
-  __shared__ unsigned long long k[CAP];
-  __shared__ unsigned short vi[CAP];
-  constexpr int NT = 256;
+sort_tiles_reg_long_kernel(const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
+                           const uint2* __restrict__ tile_range, const uint4* __restrict__ items,
+                           uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
   const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
-  const int tid = threadIdx.x;
-  for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  for (unsigned li = blockIdx.x * 4 + wave; li < n_long; li += gridDim.x * 4) {
     const uint2 tr = tile_range[long_tiles[li]];
-    const unsigned s = tr.x;
     const int L = (int)tr.y;
-    if (L <= lo || L > hi) continue;
-    __syncthreads();
-    int n = 1;
-    while (n < L) n <<= 1;
-    for (int i = tid; i < n; i += NT) {
-      unsigned long long key = ~0ull;
-      if (i < L) {
-        const uint4 it = items[s + i];
-        key = ((unsigned long long)it.y << 32) | it.x;
-      }
-      k[i] = key;
-      vi[i] = (unsigned short)i;
-    }
-    __syncthreads();
-    for (int size = 2; size <= n; size <<= 1) {
-      const int half = size >> 1;
-      for (int c = tid; c < (n >> 1); c += NT) {
-        const int blk = c / half, o = c - blk * half;
-        const int i = blk * size + o, j = blk * size + size - 1 - o;
-        const unsigned long long a = k[i], b = k[j];
-        if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
-      }
-      __syncthreads();
-      for (int stride = half >> 1; stride >= 1; stride >>= 1) {
-        for (int c = tid; c < (n >> 1); c += NT) {
-          const int i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
-          const unsigned long long a = k[i], b = k[j];
-          if (a > b) { k[i] = b; k[j] = a; const unsigned short x = vi[i]; vi[i] = vi[j]; vi[j] = x; }
-        }
-        __syncthreads();
-      }
-    }
-    for (int i = tid; i < L; i += NT) {
-      sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull);
-      sorted_dup[s + i] = items[s + vi[i]].z;  // payload fetched through the sorted local index (L2-resident)
-    }
+    if (L > 32 * EPL && L <= 64 * EPL) sort_tile_in_registers<EPL>(tr.x, L, lane, items, sorted_id, sorted_dup);
   }
 }
 
-// Long lists: same network on the tile's segment of 16-byte items in global memory (virtual padding:
-// comparators that reach past the end are no-ops). Rare path; agent-scope relaxed accesses bypass the
-// per-CU L1 so that waves of the block see each other's exchanges after the barrier.
+// K4b: per-tile sort of the lists the register network does not take (L > 512), by 64-bit key
+// (depth bits << 32 | Gaussian id) == ascending (depth, Gaussian id), SURVEY A.3. One 256-thread workgroup per tile,
+// persistent over the device-side list of long tiles; normalised bitonic network (every comparator sorts ascending,
+// so the +inf padding stays at the tail and comparators reaching past the end of the list are no-ops).
+//   L <= CAP : one pass in LDS (keys + payload, 48 KB: three workgroups per CU). Dense frames (16 M Gaussians at
+//              1080p: every list ~1 800 long) run entirely through this path.
+//   L  > CAP : hybrid -- every CAP-chunk is sorted in LDS, then for each larger network size only the exchanges
+//              with stride >= CAP touch global memory (in place, on the tile's own segment of 16-byte items); the
+//              strides below CAP of that size are again one LDS pass per chunk. Global accesses are agent-scope
+//              relaxed (they bypass the per-CU L1, so the waves of the workgroup see each other's exchanges after
+//              the barrier).
+template <int CAP>
 __global__ void __launch_bounds__(256)
-sort_tiles_global_kernel(int lo, const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
-                         const uint2* __restrict__ tile_range, uint4* items, uint32_t* __restrict__ sorted_id,
-                         uint32_t* __restrict__ sorted_dup) {
+sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
+                       const uint2* __restrict__ tile_range, uint4* items, uint32_t* __restrict__ sorted_id,
+                       uint32_t* __restrict__ sorted_dup) {
+  __shared__ unsigned long long k[CAP];
+  __shared__ uint32_t pl[CAP];
+  constexpr int NT = 256;
   const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
-  for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
-  const uint2 tr = tile_range[long_tiles[li]];
-  const unsigned s = tr.x, e = tr.x + tr.y;
-  const long long L = (long long)e - s;
-  if (L <= lo) continue;
-  __syncthreads();
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(items + s);  // item i = words 2i (key), 2i+1 (dup)
-  long long n = 1;
-  while (n < L) n <<= 1;
-  auto ld = [&](long long i) { return __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto st = [&](long long i, unsigned long long v) {
-    __hip_atomic_store(&w[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto cmpx = [&](long long i, long long j) {
-    const unsigned long long a = ld(2 * i), b = ld(2 * j);
-    if (a > b) {
-      const unsigned long long pa = ld(2 * i + 1), pb = ld(2 * j + 1);
-      st(2 * i, b); st(2 * j, a); st(2 * i + 1, pb); st(2 * j + 1, pa);
-    }
-  };
-  for (long long size = 2; size <= n; size <<= 1) {
-    const long long half = size >> 1;
-    for (long long c = threadIdx.x; c < (n >> 1); c += 256) {
-      const long long blk = c / half, o = c - blk * half;
-      const long long i = blk * size + o, j = blk * size + size - 1 - o;
-      if (j < L) cmpx(i, j);
+  const int tid = threadIdx.x;
+
+  // comparators (i, i ^ mask-ish) of one network step restricted to LDS-resident positions [0, m)
+  auto lds_mirror = [&](int m, int size) {   // first step of `size`: i <-> block_end - 1 - offset
+    const int half = size >> 1;
+    for (int c = tid; c < (m >> 1); c += NT) {
+      const int blk = c / half, o = c - blk * half;
+      const int i = blk * size + o, j = blk * size + size - 1 - o;
+      const unsigned long long a = k[i], b = k[j];
+      if (a > b) { k[i] = b; k[j] = a; const uint32_t x = pl[i]; pl[i] = pl[j]; pl[j] = x; }
     }
     __syncthreads();
-    for (long long stride = half >> 1; stride >= 1; stride >>= 1) {
-      for (long long c = threadIdx.x; c < (n >> 1); c += 256) {
-        const long long i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
-        if (j < L) cmpx(i, j);
+  };
+  auto lds_strides = [&](int m, int first_stride) {  // strides first_stride, first_stride/2, ..., 1
+    for (int stride = first_stride; stride >= 1; stride >>= 1) {
+      for (int c = tid; c < (m >> 1); c += NT) {
+        const int i = 2 * stride * (c / stride) + (c % stride), j = i + stride;
+        const unsigned long long a = k[i], b = k[j];
+        if (a > b) { k[i] = b; k[j] = a; const uint32_t x = pl[i]; pl[i] = pl[j]; pl[j] = x; }
       }
       __syncthreads();
     }
-  }
-  for (long long i = threadIdx.x; i < L; i += 256) {
-    sorted_id[s + i] = (unsigned)(ld(2 * i) & 0xffffffffull);
-    sorted_dup[s + i] = (unsigned)(ld(2 * i + 1) & 0xffffffffull);
-  }
+  };
+
+  for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
+    const uint2 tr = tile_range[long_tiles[li]];
+    const unsigned s = tr.x;
+    const long long L = (long long)tr.y;
+    if (L <= lo) continue;
+    __syncthreads();
+    long long n = 1;
+    while (n < L) n <<= 1;
+    if (n <= CAP) {  // ---- whole list in LDS -------------------------------------------------------------------
+      const int m = (int)n;
+      for (int i = tid; i < m; i += NT) {
+        unsigned long long key = ~0ull;
+        uint32_t d = 0;
+        if (i < L) { const uint4 it = items[s + i]; key = ((unsigned long long)it.y << 32) | it.x; d = it.z; }
+        k[i] = key; pl[i] = d;
+      }
+      __syncthreads();
+      for (int size = 2; size <= m; size <<= 1) { lds_mirror(m, size); lds_strides(m, size >> 2); }
+      for (int i = tid; i < L; i += NT) { sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull); sorted_dup[s + i] = pl[i]; }
+      continue;
+    }
+    // ---- hybrid: item i of the tile = 64-bit words 2i (key: id | depth << 32) and 2i + 1 (dup) ---------------------
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(items + s);
+    auto ld = [&](long long i) { return __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st = [&](long long i, unsigned long long v) { __hip_atomic_store(&w[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto chunk_load = [&](long long base) {
+      for (int i = tid; i < CAP; i += NT) {
+        unsigned long long key = ~0ull;
+        uint32_t d = 0;
+        if (base + i < L) { key = ld(2 * (base + i)); d = (uint32_t)ld(2 * (base + i) + 1); }
+        k[i] = key; pl[i] = d;
+      }
+      __syncthreads();
+    };
+    auto chunk_store = [&](long long base) {
+      for (int i = tid; i < CAP; i += NT)
+        if (base + i < L) { st(2 * (base + i), k[i]); st(2 * (base + i) + 1, (unsigned long long)pl[i]); }
+      __syncthreads();
+    };
+    auto global_cmpx = [&](long long i, long long j) {
+      if (j >= L) return;  // +inf padding never moves down
+      const unsigned long long a = ld(2 * i), b = ld(2 * j);
+      if (a > b) {
+        const unsigned long long pa = ld(2 * i + 1), pb = ld(2 * j + 1);
+        st(2 * i, b); st(2 * j, a); st(2 * i + 1, pb); st(2 * j + 1, pa);
+      }
+    };
+    for (long long base = 0; base < L; base += CAP) {  // every chunk fully sorted (network sizes 2 .. CAP)
+      chunk_load(base);
+      for (int size = 2; size <= CAP; size <<= 1) { lds_mirror(CAP, size); lds_strides(CAP, size >> 2); }
+      chunk_store(base);
+    }
+    for (long long size = 2 * (long long)CAP; size <= n; size <<= 1) {
+      const long long half = size >> 1;
+      for (long long c = tid; c < (n >> 1); c += NT) {  // mirror step of this size: always crosses chunks
+        const long long blk = c / half, o = c - blk * half;
+        global_cmpx(blk * size + o, blk * size + size - 1 - o);
+      }
+      __syncthreads();
+      for (long long stride = half >> 1; stride >= CAP; stride >>= 1) {
+        for (long long c = tid; c < (n >> 1); c += NT) global_cmpx(2 * stride * (c / stride) + (c % stride),
+                                                                      2 * stride * (c / stride) + (c % stride) + stride);
+        __syncthreads();
+      }
+      for (long long base = 0; base < L; base += CAP) {  // strides CAP/2 .. 1 stay inside a chunk
+        chunk_load(base);
+        lds_strides(CAP, CAP >> 1);
+        chunk_store(base);
+      }
+    }
+    for (long long i = tid; i < L; i += NT) {
+      sorted_id[s + i] = (unsigned)(ld(2 * i) & 0xffffffffull);
+      sorted_dup[s + i] = (unsigned)(ld(2 * i + 1) & 0xffffffffull);
+    }
   }
 }
 
@@ -697,7 +741,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
   if (frame->subpixel_offset) {
     const int64_t n = (int64_t)W * H * 2;
-    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 512));
     { ProfScope ps_(KID_SUBPIX, stream);
       hipLaunchKernelGGL(subpix_bound_kernel, dim3(blocks), dim3(256), 0, stream, frame->subpixel_offset, n, tv.hdr); }
     SFGS_POST_LAUNCH("subpix_bound", stream, frame->debug);
@@ -756,7 +800,7 @@ extern "C" int sfgs_raster_read_counters_pinned(const void* tiles, void* pinned_
   return SFGS_OK;
 }
 
-constexpr int SORT_SMALL = 512, SORT_CAP = 4096;
+constexpr int SORT_CAP = 4096;
 
 extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
                                           void* bins, size_t bins_sz, int64_t dup_capacity, int64_t coarse_capacity,
@@ -789,13 +833,15 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
                          bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
     { ProfScope ps_(KID_SORT_MEDIUM, stream);
-      hipLaunchKernelGGL(sort_tiles_lds_kernel<SORT_CAP>, dim3(std::min(T8, 1024)), dim3(256), 0, stream, SORT_SMALL, SORT_CAP,
+      hipLaunchKernelGGL(sort_tiles_reg_long_kernel<16>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
+                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
+      hipLaunchKernelGGL(sort_tiles_reg_long_kernel<32>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
-    SFGS_POST_LAUNCH("sort_tiles_medium", stream, frame->debug);
+    SFGS_POST_LAUNCH("sort_tiles_reg_long", stream, frame->debug);
     { ProfScope ps_(KID_SORT_GLOBAL, stream);
-      hipLaunchKernelGGL(sort_tiles_global_kernel, dim3(64), dim3(256), 0, stream, SORT_CAP, tv.long_tiles, tv.hdr,
-                         tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
-    SFGS_POST_LAUNCH("sort_tiles_global", stream, frame->debug);
+      hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_MAX,
+                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
+    SFGS_POST_LAUNCH("sort_tiles_long", stream, frame->debug);
   }
   ImageView iv = {nullptr, nullptr, nullptr};
   if (image) iv = image_view(image, W, H);
