@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, co
   return m;
 }
 
-constexpr int BIG_WALK = 16;  // coarse bins above which a splat's walk is done by the whole wave
+constexpr int BIG_WALK = 6;  // coarse bins above which a splat's walk is done by the whole wave
 
 struct WalkArgs { SplatRec r; BinRange br; float thr; int cx0, cx1, cy0, cy1; };
 
@@ -76,6 +76,25 @@ __device__ __forceinline__ WalkArgs broadcast_walk(const SplatRec& r, const BinR
   a.thr = __shfl(thr, L);
   a.cx0 = __shfl(cx0, L); a.cx1 = __shfl(cx1, L); a.cy0 = __shfl(cy0, L); a.cy1 = __shfl(cy1, L);
   return a;
+}
+
+// Cooperative walk, lane = TILE: lanes 16q..16q+15 test the 16 tiles of coarse bin number 4*it + q of the walk
+// (row-major over [cx0,cx1) x [cy0,cy1)); the ballot's 16-bit slice q is that bin's mask, identical to coarse_hits().
+// A mid-size splat (6..63 coarse bins) keeps all 64 lanes busy this way; one lane per coarse bin would use 6..63.
+__device__ __forceinline__ unsigned long long walk_ballot4(const WalkArgs& a, int it, int lane, int W, int H,
+                                                           float bound, int* cb_index, int CX) {
+  const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
+  const int i = it * 4 + (lane >> 4), t = lane & 15;
+  bool hit = false;
+  int cb = 0;
+  if (i < ncb) {
+    const int cx = a.cx0 + i % nx, cy = a.cy0 + i / nx;
+    const int tx = cx * COARSE + (t & (COARSE - 1)), ty = cy * COARSE + (t / COARSE);
+    cb = cy * CX + cx;
+    if (tx >= a.br.x0 && tx < a.br.x1 && ty >= a.br.y0 && ty < a.br.y1) hit = bin_test(a.r, a.thr, tx, ty, W, H, bound);
+  }
+  *cb_index = cb;
+  return __ballot(hit);
 }
 
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
@@ -166,11 +185,18 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     const WalkArgs a = broadcast_walk(r, br, thr, cx0, cx1, cy0, cy1, L);
     const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
     unsigned total = 0;
-    for (int i0 = 0; i0 < ncb; i0 += 64) {
-      const int i = i0 + lane;
-      unsigned c = 0;
-      if (i < ncb) c = (unsigned)__popc(coarse_hits(a.r, a.thr, a.br, a.cx0 + i % nx, a.cy0 + i / nx, f.W, f.H, bound));
-      total += wave_sum_u32(c);
+    if (ncb < 64) {  // mid-size splat: lane = tile keeps the wave full
+      for (int it = 0; it * 4 < ncb; ++it) {
+        int cb;
+        total += (unsigned)__popcll(walk_ballot4(a, it, lane, f.W, f.H, bound, &cb, CX));
+      }
+    } else {         // huge splat: lane = coarse bin (16 tile tests per lane and iteration, index math amortised)
+      for (int i0 = 0; i0 < ncb; i0 += 64) {
+        const int i = i0 + lane;
+        unsigned c = 0;
+        if (i < ncb) c = (unsigned)__popc(coarse_hits(a.r, a.thr, a.br, a.cx0 + i % nx, a.cy0 + i / nx, f.W, f.H, bound));
+        total += wave_sum_u32(c);
+      }
     }
     if (lane == L) n_dup = total;
   }
@@ -204,23 +230,39 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     const unsigned g_L = (unsigned)__shfl((int)g, L), depth_L = __shfl(depth_bits, L);
     unsigned dup = __shfl((unsigned)(base + ex), L);
     const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
-    for (int i0 = 0; i0 < ncb; i0 += 64) {
-      const int i = i0 + lane;
-      unsigned m = 0;
-      int cb = 0;
-      if (i < ncb) {
-        const int cx = a.cx0 + i % nx, cy = a.cy0 + i / nx;
-        m = coarse_hits(a.r, a.thr, a.br, cx, cy, f.W, f.H, bound);
-        cb = cy * CX + cx;
+    if (ncb >= 64) {
+      for (int i0 = 0; i0 < ncb; i0 += 64) {
+        const int i = i0 + lane;
+        unsigned m = 0;
+        int cb = 0;
+        if (i < ncb) {
+          const int cx = a.cx0 + i % nx, cy = a.cy0 + i / nx;
+          m = coarse_hits(a.r, a.thr, a.br, cx, cy, f.W, f.H, bound);
+          cb = cy * CX + cx;
+        }
+        const unsigned c = (unsigned)__popc(m);
+        const unsigned incl = wave_incl_scan_u32(c);
+        if (m) {
+          const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+          if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + incl - c, m);
+          else hdr[HDR_OVERFLOW] = 1ull;
+        }
+        dup += __shfl(incl, 63);
       }
-      const unsigned c = (unsigned)__popc(m);
-      const unsigned incl = wave_incl_scan_u32(c);
-      if (m) {
+      continue;
+    }
+    for (int it = 0; it * 4 < ncb; ++it) {
+      int cb;
+      const unsigned long long bal = walk_ballot4(a, it, lane, f.W, f.H, bound, &cb, CX);
+      const int q = lane >> 4;
+      const unsigned m = (unsigned)(bal >> (16 * q)) & 0xffffu;
+      if ((lane & 15) == 0 && m) {  // the first lane of each 16-lane group appends its coarse bin's item
+        const unsigned before = (unsigned)__popcll(bal & ((1ull << (16 * q)) - 1ull));
         const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
-        if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + incl - c, m);
+        if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + before, m);
         else hdr[HDR_OVERFLOW] = 1ull;
       }
-      dup += __shfl(incl, 63);
+      dup += (unsigned)__popcll(bal);
     }
   }
   // per-block statistics (summed by plan_scan; no contended atomics)
