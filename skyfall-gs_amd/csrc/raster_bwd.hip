@@ -303,7 +303,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   // ---- sum this Gaussian's per-duplicate records (fixed order -> deterministic) -----------------------------------
   // A splat that covers many tiles owns thousands of records: summing them in its own lane would leave the other 63
   // lanes idle for that long, so above COOP records the whole wave strides over them and reduces across lanes.
-  constexpr unsigned COOP = 96;
+  constexpr unsigned COOP = 16;
   const bool vis = valid && radii[g] > 0;
   unsigned d0 = 0, cnt = 0;
   if (vis) { const uint2 dr = dup[g]; d0 = dr.x; cnt = dr.y; }
