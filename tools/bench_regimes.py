@@ -24,6 +24,8 @@ REGIMES = {
     "uhd_2M_2160p": dict(n=2_000_000, W=3840, H=2160, kw={}),
     "dense_8M_1080p": dict(n=8_000_000, W=1920, H=1080, kw={}),
     "jittered_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw=dict(jitter=True)),
+    # exactly what the reference's render() passes when ray jitter is off: an all-zero [H,W,2] tensor
+    "zero_subpixel_tensor_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw={}, zero_subpix=True),
 }
 dev = torch.device("cuda:0")
 only = sys.argv[1:]
@@ -32,7 +34,7 @@ for name, c in REGIMES.items():
         continue
     frame, g = scene(c["n"], c["W"], c["H"], seed=0, **c["kw"])
     gc, gd = (t.to(dev) for t in upstream_grads(c["W"], c["H"], 0))
-    sub = frame.get("subpix")
+    sub = torch.zeros(c["H"], c["W"], 2) if c.get("zero_subpix") else frame.get("subpix")
     settings = GaussianRasterizationSettings(
         image_height=frame["H"], image_width=frame["W"], tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"],
         kernel_size=frame["kernel_size"], subpixel_offset=None if sub is None else sub.to(dev), bg=frame["bg"].to(dev),
