@@ -22,10 +22,14 @@ CASES = {
     # the headline scene generator at its full viewport, 1/10 of the Gaussians (the oracle needs ~1 s for it)
     "cfg2_200k_1080p": dict(n=200000, W=1920, H=1080, kw=dict()),
     "cfg4_like_1440p": dict(n=150000, W=2560, H=1440, kw=dict(zrange=(500., 700.))),
-    # per-tile lists of ~2000 (LDS sort path) and ~6000 entries (global-memory sort path); low opacity so that
+    # long per-tile lists, one case per sort path: ~800 (register network, 16 keys per lane), ~2000 (32 keys per lane),
+    # ~3000 (LDS), ~6000 (LDS chunks + one global-memory level), ~10000 (two global-memory levels); low opacity so that
     # pixels do not saturate after a few dozen splats and the long lists are really composited
-    "lists_2k": dict(n=2000, W=72, H=56, kw=dict(zrange=(3., 6.), scale_range=(0.5, 1.5), opacity_range=(0.004, 0.02))),
-    "lists_6k": dict(n=6000, W=40, H=40, kw=dict(zrange=(3., 6.), scale_range=(0.5, 1.5), opacity_range=(0.004, 0.01))),
+    "lists_800": dict(n=900, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.03))),
+    "lists_2k": dict(n=2000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.02))),
+    "lists_3k": dict(n=3000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
+    "lists_6k": dict(n=6000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
+    "lists_10k": dict(n=18000, W=16, H=16, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
 }
 
 
@@ -80,6 +84,10 @@ def test_forward_backward_parity(case):
     for k in G:
         reps.append(parity.assert_grad_close(k, out["grads"][k], G[k]))
     print(case, out["counters"], reps)
+    want_list = {"lists_800": (513, 1024), "lists_2k": (1025, 2048), "lists_3k": (2049, 4096), "lists_6k": (4097, 8192),
+                 "lists_10k": (8193, 1 << 20)}.get(case)
+    if want_list:  # the case really exercises the sort path it is named after
+        assert want_list[0] <= out["counters"]["max_tile_list"] <= want_list[1], out["counters"]
 
 
 def test_host_emulation_agrees_bitwise_on_integers():
