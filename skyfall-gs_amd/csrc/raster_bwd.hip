@@ -185,15 +185,28 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const bool on_grid = !(kf.subpix && (unsigned)hdr[HDR_SUBPIX_BOUND] != 0u);
   const float ocx = (float)(tx * 8) + 3.5f, ocy = (float)(ty * 8) + 3.5f;  // tile centre
   const int nbatch = (int)((kmax + B - 1) / B);
+  // Software pipeline over the batches (back to front): the dependent id -> record gathers of the NEXT batch are in
+  // flight while this one is processed, the ids of the one after are fetched alongside (as in the forward).
+  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+  unsigned dup_cur = 0, id_next = 0, dup_next = 0;
+  {
+    const unsigned b0 = (unsigned)(nbatch - 1) * B;
+    if ((unsigned)lane < kmax - b0) {
+      const unsigned id = sorted_id[s + b0 + lane];
+      dup_cur = sorted_dup[s + b0 + lane];
+      n0 = rec[3 * (size_t)id]; n1 = rec[3 * (size_t)id + 1]; n2 = rec[3 * (size_t)id + 2];
+    }
+    if (nbatch >= 2 && lane < B) { id_next = sorted_id[s + b0 - B + lane]; dup_next = sorted_dup[s + b0 - B + lane]; }
+  }
   for (int bi = nbatch - 1; bi >= 0; --bi) {
     const unsigned b0 = (unsigned)bi * B;
     const unsigned cnt = min((unsigned)B, kmax - b0);
-    unsigned my_dup = 0;
-    if ((unsigned)lane < cnt) {
-      const unsigned id = sorted_id[s + b0 + lane];
-      my_dup = sorted_dup[s + b0 + lane];
-      const float4 a0 = rec[3 * (size_t)id], a1 = rec[3 * (size_t)id + 1], a2 = rec[3 * (size_t)id + 2];
-      lds.recs[lane * 3] = a0; lds.recs[lane * 3 + 1] = a1; lds.recs[lane * 3 + 2] = a2;
+    const unsigned my_dup = dup_cur;
+    if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
+    if (bi >= 1 && lane < B) {  // batches below the last one are always full
+      n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2];
+      dup_cur = dup_next;
+      if (bi >= 2) { id_next = sorted_id[s + b0 - 2 * B + lane]; dup_next = sorted_dup[s + b0 - 2 * B + lane]; }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
