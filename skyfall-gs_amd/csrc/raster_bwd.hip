@@ -211,11 +211,17 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 1: lane = pixel -------------------------------------------------------------------
+    // the (broadcast) LDS reads of entry j - 1 are issued before entry j is evaluated
+    float4 r0n = lds.recs[(cnt - 1) * 3], r1n = lds.recs[(cnt - 1) * 3 + 1];
+    float2 r2n = *reinterpret_cast<const float2*>(&lds.recs[(cnt - 1) * 3 + 2]);
 #pragma unroll 4
     for (int j = (int)cnt - 1; j >= 0; --j) {
       const unsigned k = b0 + (unsigned)j;
-      const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
-      const float2 r2 = *reinterpret_cast<const float2*>(&lds.recs[j * 3 + 2]);
+      const float4 r0 = r0n, r1 = r1n;
+      const float2 r2 = r2n;
+      const int jn = j > 0 ? j - 1 : 0;
+      r0n = lds.recs[jn * 3]; r1n = lds.recs[jn * 3 + 1];
+      r2n = *reinterpret_cast<const float2*>(&lds.recs[jn * 3 + 2]);
       const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
       const bool act = k < last && ev.ok;
       float u = 0.f, w = 0.f;
