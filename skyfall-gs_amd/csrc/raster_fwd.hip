@@ -671,9 +671,9 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const unsigned k0 = b - s;
     unsigned j = 0;
-    for (; j + 4 <= cnt; j += 4) {  // 4 entries per early-exit check
+    for (; j + 8 <= cnt; j += 8) {  // 8 entries per early-exit check
 #pragma unroll
-      for (unsigned u = 0; u < 4; ++u) {
+      for (unsigned u = 0; u < 8; ++u) {
         const float4 r0 = st[(j + u) * 3], r1 = st[(j + u) * 3 + 1];
         const float2 r2 = *reinterpret_cast<const float2*>(&st[(j + u) * 3 + 2]);
         const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
@@ -874,13 +874,13 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
       hipLaunchKernelGGL(sort_tiles_reg_kernel, dim3((T8 + 3) / 4), dim3(256), 0, stream, T8, tv.tile_range, bv.items,
                          bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
-    { ProfScope ps_(KID_SORT_MEDIUM, stream);
+    { ProfScope ps_(KID_SORT_REG_LONG, stream);
       hipLaunchKernelGGL(sort_tiles_reg_long_kernel<16>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
       hipLaunchKernelGGL(sort_tiles_reg_long_kernel<32>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_reg_long", stream, frame->debug);
-    { ProfScope ps_(KID_SORT_GLOBAL, stream);
+    { ProfScope ps_(KID_SORT_LDS, stream);
       hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_MAX,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_long", stream, frame->debug);
