@@ -92,14 +92,19 @@ class FusedAdam(torch.optim.Adam):
                 bc2 = 1 - beta2 ** t_step
                 rec = L.SfgsAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                        (lr / bc1) * -1, 1 - beta1, beta2, 1 - beta2, bc2 ** 0.5, eps, wd, 0.0)
-                per_device.setdefault(p.device, ([], []))
+                per_device.setdefault(p.device, ([], [], []))
                 per_device[p.device][0].append(rec)
                 per_device[p.device][1].append(g)  # keep contiguous copies alive until the launch is enqueued
-        for dev, (recs, _keep) in per_device.items():
+                per_device[p.device][2].extend((p, m, v))
+        for dev, (recs, _keep, mutated) in per_device.items():
             arr = (L.SfgsAdamTensor * len(recs))(*recs)
             with torch.cuda.device(dev):
                 stream = L.C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 L.check(L.load().sfgs_adam_step(arr, len(recs), stream))
+            # the kernel wrote through raw pointers: tell autograd (and anything keyed on tensor versions, e.g.
+            # sfgs.prepass's per-iteration cache) that these tensors changed in place, as torch's own step() does
+            for t in mutated:
+                torch.autograd.graph.increment_version(t)
         return loss
 
 

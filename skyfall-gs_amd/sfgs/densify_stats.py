@@ -31,6 +31,9 @@ def add_densification_stats(model, viewspace_point_tensor, update_filter):
         stream = L.C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         L.check(L.load().sfgs_densify_stats(N, L.ptr(grad), L.ptr(f), L.ptr(bufs[0]), L.ptr(bufs[1]), L.ptr(bufs[2]),
                                             L.ptr(bufs[3]), stream))
+    for b in bufs:  # written through raw pointers: bump the autograd version counters like an in-place torch op
+        if b is not None:
+            torch.autograd.graph.increment_version(b)
 
 
 _ORIG = {}

@@ -207,7 +207,9 @@ def test_install_rehomes_the_optimizer_training_setup_builds():
         m.training_setup(None)
         assert isinstance(m.optimizer, adam.FusedAdam) and m.optimizer.param_groups[0]["params"][0] is m._xyz
         m._xyz.grad = torch.ones_like(m._xyz)
+        v0 = m._xyz._version
         m.optimizer.step()
+        assert m._xyz._version > v0   # in-place update is visible to autograd / version-keyed caches (sfgs.prepass)
         torch.testing.assert_close(m._xyz.detach(), torch.full((10, 3), -0.5, device="cuda:0"), rtol=1e-6, atol=0)
         sd = m.optimizer.state_dict()     # capture()/restore() path (scene/gaussian_model.py:163-201)
         m2 = GaussianModel(); m2.training_setup(None); m2.optimizer.load_state_dict(sd)
