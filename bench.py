@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="Gaussians in the CPU-baseline sample (-1 = the whole workload, ~10-30 s; 0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="report render FPS instead of train-step Gaussians/s")
+    ap.add_argument("--d2h-async", action="store_true", help="with --forward-only: download every frame through sfgs.video.FrameDownloader (pinned ring, side stream; informational)")
+    ap.add_argument("--d2h-copy", action="store_true", help="with --forward-only: copy every frame to the host like render_video.py:181 (informational; never the headline value)")
     ap.add_argument("--sh-degree", type=int, default=-1, help=">= 0: colour path B (in-kernel SH of this degree) instead of colors_precomp")
     args = ap.parse_args()
 
@@ -90,11 +92,20 @@ def main():
     gc, gd = gc.to(dev), gd.to(dev)
     shared_grad = torch.zeros(APPEARANCE_MLP_FLOATS, device=dev)
 
+    downloader = None
+    if args.d2h_async:
+        from sfgs.video import FrameDownloader
+        downloader = FrameDownloader(depth=3, device=dev)
+
     def step():
         if args.forward_only:
             with torch.no_grad():
-                rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=t["colors_precomp"],
-                     opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+                out = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=t["colors_precomp"],
+                           opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+                if args.d2h_copy:
+                    out[0].cpu()   # rendering.cpu() of the reference's video loop: a synchronous 24.9 MB PCIe copy at 1080p
+                elif args.d2h_async:
+                    downloader.submit(out[0])
             return
         for v in list(t.values()) + [means2D]:
             if v is not None:
@@ -163,7 +174,9 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     if args.forward_only:
         B_step = 60 * N + 32 * Nvis + 80 * D_ref + 36 * P
-        metric, unit, value = "render FPS (forward raster, no D2H copy)", "frames/s", world / (ms_step * 1e-3)
+        metric = "render FPS (forward raster, %s)" % ("with the per-frame D2H copy of render_video.py:181" if args.d2h_copy else
+                                                      "frames downloaded through a pinned ring on a side stream" if args.d2h_async else "no D2H copy")
+        unit, value = "frames/s", world / (ms_step * 1e-3)
     else:
         B_step = 128 * N + 184 * Nvis + 124 * D_ref + 64 * P
         metric, unit = "train-step Gaussians/s (fwd+bwd raster) @1080p", "Gaussians/s"

@@ -46,7 +46,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 _last_counters = {}
 _stats = {"full": False}
-_pinned = {}     # device index -> pinned host buffer the counters are read through
+_pinned = {}     # (device index, stream) -> (pinned host buffer the counters are read through, event)
 _ncb_cache = {}  # (W, H) -> number of coarse bins
 _zeros = {}      # device index -> 1-element zero tensor
 
@@ -180,12 +180,13 @@ class _Rasterize(torch.autograd.Function):
                 # and the backward's launch overlap with the compositing kernel instead of following a drained
                 # stream. Both stages are redone in the rare case a capacity was exceeded (an overflowing plan is
                 # memory-safe).
-                pinned = _pinned.get(dev.index)
-                if pinned is None:
-                    pinned = _pinned[dev.index] = (torch.empty(8, dtype=torch.int64).pin_memory(),
-                                                   torch.cuda.Event(enable_timing=False, blocking=False))
-                pin, ev = pinned
                 tstream = torch.cuda.current_stream(dev)
+                pkey = (dev.index, tstream.cuda_stream)   # one buffer per (device, stream): frames on different
+                pinned = _pinned.get(pkey)                # streams / host threads never share a counter buffer
+                if pinned is None:
+                    pinned = _pinned[pkey] = (torch.empty(8, dtype=torch.int64).pin_memory(),
+                                              torch.cuda.Event(enable_timing=False, blocking=False))
+                pin, ev = pinned
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
                                                      bins.numel(), cap, ccap, L.C.c_void_p(pin.data_ptr()), stream))
