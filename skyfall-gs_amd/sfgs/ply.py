@@ -23,7 +23,8 @@ import numpy as np
 import torch
 
 __all__ = ["read_ply", "write_ply", "save_ply", "save_fused_ply", "load_ply", "load_standard_ply", "fetch_ply",
-           "store_ply", "detect_sh_degree", "PlyData", "PlyElement", "install", "uninstall", "install_as_plyfile"]
+           "store_ply", "detect_sh_degree", "merge_fused_plys", "PlyData", "PlyElement", "install", "uninstall",
+           "install_as_plyfile"]
 
 # PLY scalar type names <-> numpy codes (both spellings are legal in headers; plyfile writes the short ones)
 _PLY2NP = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
@@ -308,6 +309,33 @@ def detect_sh_degree(path):
     table = _vertex_table(path)
     n_rest = len([n for n in table.dtype.names if n.startswith("f_rest_")])
     return 0 if n_rest == 0 else int(np.sqrt((n_rest / 3) + 1)) - 1
+
+
+def merge_fused_plys(paths, offsets=None, out_path=None):
+    """Concatenate per-scene fused PLYs (save_fused_ply output: no filter_3D column) into one joint scene, each
+    shifted by its world offset [x,y,z] (the reference has no multi-scene merge; the joint scene is what
+    `sfgs.shard.render_joint` renders band-sharded). All files must have the same columns (same SH degree).
+    Returns the merged vertex table; writes it when out_path is given."""
+    tables = [_vertex_table(p) for p in paths]
+    if not tables:
+        raise ValueError("no input files")
+    names = tables[0].dtype.names
+    for p, t in zip(paths, tables):
+        if t.dtype.names != names:
+            raise ValueError(f"{p}: columns differ from {paths[0]} (different SH degree or filter_3D present?)")
+    if offsets is None:
+        offsets = [(0.0, 0.0, 0.0)] * len(tables)
+    if len(offsets) != len(tables):
+        raise ValueError("one offset per file expected")
+    merged = np.concatenate(tables)
+    row = 0
+    for t, off in zip(tables, offsets):
+        for axis, name in enumerate(("x", "y", "z")):
+            merged[name][row:row + len(t)] += np.float32(off[axis])
+        row += len(t)
+    if out_path is not None:
+        write_ply(out_path, merged)
+    return merged
 
 
 def fetch_ply(path):

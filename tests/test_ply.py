@@ -162,3 +162,24 @@ def test_large_table_round_trip(tmp_path):
     assert len(t) == n and len(t.dtype.names) == 6 + 3 + 45 + 1 + 3 + 4 + 1
     assert np.array_equal(t["f_rest_17"], m._features_rest.transpose(1, 2).flatten(start_dim=1)[:, 17].numpy())
     assert np.array_equal(t["filter_3D"], m.filter_3D[:, 0].numpy())
+
+
+def test_merge_fused_plys(tmp_path):
+    a, b = tmp_path / "a.ply", tmp_path / "b.ply"
+    a.write_bytes(G["ply_fused_bytes"].tobytes())
+    b.write_bytes(G["ply_fused_bytes"].tobytes())
+    merged = ply.merge_fused_plys([str(a), str(b)], offsets=[(0, 0, 0), (512.0, -256.0, 1.5)], out_path=str(tmp_path / "j.ply"))
+    one = ply.read_ply(str(a))[0][1]
+    n = len(one)
+    assert len(merged) == 2 * n and merged.dtype == one.dtype
+    assert np.array_equal(merged[:n], one)
+    assert np.array_equal(merged["x"][n:], one["x"] + np.float32(512.0)) and np.array_equal(merged["z"][n:], one["z"] + np.float32(1.5))
+    assert np.array_equal(merged["opacity"][n:], one["opacity"]) and np.array_equal(merged["rot_2"][n:], one["rot_2"])
+    assert np.array_equal(ply.read_ply(str(tmp_path / "j.ply"))[0][1], merged)
+    m = types.SimpleNamespace(max_sh_degree=1)
+    ply.load_standard_ply(m, str(tmp_path / "j.ply"), device="cpu")      # the joint scene loads like any fused PLY
+    assert m._xyz.shape == (2 * n, 3)
+    save = tmp_path / "s.ply"
+    save.write_bytes(G["ply_save_bytes"].tobytes())
+    with pytest.raises(ValueError, match="columns differ"):
+        ply.merge_fused_plys([str(a), str(save)])
