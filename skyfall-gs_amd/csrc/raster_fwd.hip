@@ -4,10 +4,12 @@
 // behind the C ABI of include/sfgs.h. Kernel chain (all wave64, no MFMA: the path is gather/sort/VALU
 // bound):
 //
-//   plan:    subpix_bound  -> preprocess (per Gaussian: project, radii, record, opacity-aware
-//            8x8-tile count) -> plan_scan (tile starts, per-block duplicate bases, counters)
-//   render:  scatter (per Gaussian: emit (depth|dup) keys into per-tile segments)
-//            -> sort_tiles (per tile: normalised bitonic network in LDS / global for long lists)
+//   plan:    subpix_bound -> preprocess (per Gaussian: project, radii, 48-B record; opacity-aware COARSE binning:
+//            one 16-B item per (Gaussian, 32x32-px coarse bin) with the mask of the 8x8 tiles it can contribute to)
+//            -> plan_scan (counters for the host, published straight into pinned host memory)
+//   render:  fine_bin (per coarse bin: LDS-ranked expansion into per-tile item segments)
+//            -> sort_tiles (per tile: normalised bitonic network in registers up to 2 048 entries, LDS and an
+//               LDS/global hybrid beyond)
 //            -> composite (one wave per 8x8 tile, front to back, records staged through LDS)
 //
 // Compile with -ffp-contract=off: integer outputs depend on exact float32 sequences (raster_math.h).
