@@ -631,8 +631,10 @@ __global__ void __launch_bounds__(256)
 composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const float4* __restrict__ rec,
                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                     uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out) {
+                     uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out,
+                     const unsigned long long* __restrict__ hdr) {
   __shared__ float4 stage[4][64 * 3];
+  __shared__ __attribute__((aligned(4))) unsigned char rowlist[4][4][64];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
   // readfirstlane: tells the compiler the wave index (hence the tile, its list range and every loop bound below)
   // is wave-uniform -> scalar loads, SGPR loop counters and s_cbranch instead of exec-mask loops
@@ -649,6 +651,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int t = ty * TX8 + tx;
   const uint2 tr = tile_range[t];
   const unsigned s = tr.x, e = tr.x + tr.y;
+  const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
   PixelFwd ps;
   pixel_fwd_init(ps, inside);
   float4* st = stage[wave];
@@ -665,6 +668,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     if (__ballot(ps.T > 0.f) == 0ull) break;  // every pixel of the tile is saturated
     const unsigned cnt = min(64u, e - b);
     st[lane * 3] = n0; st[lane * 3 + 1] = n1; st[lane * 3 + 2] = n2;
+    const float stage_my = n0.y, stage_ey = n2.w;
     if (b + 64 + lane < e) {  // prefetch: records of the next batch, ids of the one after
       n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2];
     }
@@ -672,22 +676,48 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const unsigned k0 = b - s;
-    unsigned j = 0;
-    for (; j + 8 <= cnt; j += 8) {  // 8 entries per early-exit check
+    // Strip skipping: lanes 16r..16r+15 (one DPP row) own pixel rows 2r, 2r+1 of the tile. An entry whose
+    // alpha >= 1/255 region (y-extent my +- ey, margins included) misses those two rows cannot be accepted by any of
+    // the row's pixels, so each row walks only the entries that can touch it. The rows advance in lockstep through
+    // their own bit sets; the wave leaves a half-batch when the longest set is exhausted.
+    {
+      const float my = stage_my, ey = stage_ey;   // this lane's STAGED entry (entry index = lane)
+      const float ylo = (float)(ty * 8) - bound, yhi = (float)(ty * 8 + 1) + bound;
+      const bool live = (unsigned)lane < cnt;
+      const unsigned long long b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
+      const unsigned long long b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
+      const unsigned long long b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
+      const unsigned long long b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
+      // per-row compact entry lists (bytes) in LDS: entry `lane` goes to position rank(lane) of every row it touches
+      unsigned char* Lw = &rowlist[wave][0][0];
+      auto rank = [&](unsigned long long m) {
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      };
+      if ((b0 >> lane) & 1ull) Lw[0 * 64 + rank(b0)] = (unsigned char)lane;
+      if ((b1 >> lane) & 1ull) Lw[1 * 64 + rank(b1)] = (unsigned char)lane;
+      if ((b2 >> lane) & 1ull) Lw[2 * 64 + rank(b2)] = (unsigned char)lane;
+      if ((b3 >> lane) & 1ull) Lw[3 * 64 + rank(b3)] = (unsigned char)lane;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int n0r = __popcll(b0), n1r = __popcll(b1), n2r = __popcll(b2), n3r = __popcll(b3);
+      const int row = lane >> 4;
+      const int len = row == 0 ? n0r : row == 1 ? n1r : row == 2 ? n2r : n3r;
+      const int maxlen = max(max(n0r, n1r), max(n2r, n3r));
+      const unsigned char* Lr = Lw + row * 64;
+      for (int i = 0; i < maxlen; i += 4) {   // 4 list positions per early-exit check
+        const unsigned j4 = *reinterpret_cast<const unsigned*>(Lr + i);   // four byte indices at once (i % 4 == 0)
 #pragma unroll
-      for (unsigned u = 0; u < 8; ++u) {
-        const float4 r0 = st[(j + u) * 3], r1 = st[(j + u) * 3 + 1];
-        const float2 r2 = *reinterpret_cast<const float2*>(&st[(j + u) * 3 + 2]);
-        const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-        pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, k0 + j + u);
+        for (int u = 0; u < 4; ++u) {
+          if (i + u < len) {
+            const unsigned j = (j4 >> (8 * u)) & 0xffu;
+            const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
+            const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
+            const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
+            pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, k0 + j);
+          }
+        }
+        if (__ballot(ps.T > 0.f) == 0ull) break;
       }
-      if (__ballot(ps.T > 0.f) == 0ull) break;
-    }
-    for (; j < cnt; ++j) {
-      const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
-      const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
-      const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-      pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, k0 + j);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -892,7 +922,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_FWD, stream);
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
-                       bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T, iv.dacc); }
+                       bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T, iv.dacc, tv.hdr); }
   SFGS_POST_LAUNCH("composite_fwd", stream, frame->debug);
   return SFGS_OK;
 }
