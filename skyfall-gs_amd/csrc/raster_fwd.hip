@@ -634,7 +634,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out,
                      const unsigned long long* __restrict__ hdr) {
   __shared__ float4 stage[4][64 * 3];
-  __shared__ __attribute__((aligned(4))) unsigned char rowlist[4][4][64];
+  __shared__ __attribute__((aligned(8))) unsigned char rowlist[4][4][64];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
   // readfirstlane: tells the compiler the wave index (hence the tile, its list range and every loop bound below)
   // is wave-uniform -> scalar loads, SGPR loop counters and s_cbranch instead of exec-mask loops
@@ -676,10 +676,13 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const unsigned k0 = b - s;
-    // Strip skipping: lanes 16r..16r+15 (one DPP row) own pixel rows 2r, 2r+1 of the tile. An entry whose
-    // alpha >= 1/255 region (y-extent my +- ey, margins included) misses those two rows cannot be accepted by any of
-    // the row's pixels, so each row walks only the entries that can touch it. The rows advance in lockstep through
-    // their own bit sets; the wave leaves a half-batch when the longest set is exhausted.
+    // Strip skipping. Only ~25 % of the (pixel, splat) pairs of a tile list hit (splats of a few pixels on an 8x8
+    // tile), and a wave cannot skip per lane -- but it can per strip: lanes 16r..16r+15 (one DPP row) own pixel rows
+    // 2r, 2r+1, and an entry whose alpha >= 1/255 region (y-extent my +- ey, margins included) misses those two rows
+    // cannot be accepted by any of their pixels. Each strip therefore walks its own compact list of the batch entries
+    // that can touch it (~65 % of them); the four strips advance in lockstep and the wave leaves the batch when the
+    // longest list is exhausted. Exact: the skipped pairs are pairs the per-pixel test would have rejected.
+    // (Eight single-row lists need fewer steps but twice the list set-up: same time.)
     {
       const float my = stage_my, ey = stage_ey;   // this lane's STAGED entry (entry index = lane)
       const float ylo = (float)(ty * 8) - bound, yhi = (float)(ty * 8 + 1) + bound;
@@ -704,12 +707,12 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       const int len = row == 0 ? n0r : row == 1 ? n1r : row == 2 ? n2r : n3r;
       const int maxlen = max(max(n0r, n1r), max(n2r, n3r));
       const unsigned char* Lr = Lw + row * 64;
-      for (int i = 0; i < maxlen; i += 4) {   // 4 list positions per early-exit check
-        const unsigned j4 = *reinterpret_cast<const unsigned*>(Lr + i);   // four byte indices at once (i % 4 == 0)
+      for (int i = 0; i < maxlen; i += 8) {   // 8 list positions per early-exit check
+        const uint2 j8 = *reinterpret_cast<const uint2*>(Lr + i);   // eight byte indices at once (i % 8 == 0)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           if (i + u < len) {
-            const unsigned j = (j4 >> (8 * u)) & 0xffu;
+            const unsigned j = ((u < 4 ? j8.x : j8.y) >> (8 * (u & 3))) & 0xffu;
             const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
             const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
             const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
