@@ -64,6 +64,7 @@ __device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, co
 }
 
 constexpr int BIG_WALK = 6;  // coarse bins above which a splat's walk is done by the whole wave
+static_assert(BIG_WALK <= 8, "the per-lane walk keeps one 16-bit mask per coarse bin in two 64-bit registers");
 
 struct WalkArgs { SplatRec r; BinRange br; float thr; int cx0, cx1, cy0, cy1; };
 
@@ -128,7 +129,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int CX = (((f.W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
   unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
-  unsigned long long cached = 0ull;  // masks of the first four coarse bins of the walk (16 bits each)
+  unsigned long long mask_lo = 0ull, mask_hi = 0ull;  // 16-bit tile masks of the (<= BIG_WALK) coarse bins of the walk
   bool big = false;                  // walk handled cooperatively by the wave
   const int lane = threadIdx.x & 63;
   SplatRec r;
@@ -168,13 +169,20 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         cy0 = br.y0 / COARSE; cy1 = (br.y1 - 1) / COARSE + 1;
         big = (cx1 - cx0) * (cy1 - cy0) > BIG_WALK;
         if (!big) {
-          int k = 0;
-          for (int cy = cy0; cy < cy1; ++cy)
-            for (int cx = cx0; cx < cx1; ++cx, ++k) {
-              const unsigned m = coarse_hits(r, thr, br, cx, cy, f.W, f.H, bound);
-              if (k < 4) cached |= (unsigned long long)m << (16 * k);
-              n_dup += (unsigned)__popc(m);
+          // ONE flat loop over the tiles of the walk range (a 4-deep coarse-bin x tile loop nest with per-lane
+          // bounds costs as much in divergent loop control as the tile tests themselves); hits are ORed into the
+          // 16-bit mask of their coarse bin, BIG_WALK (= 6) masks = 96 bits in two registers
+          const int w_t = br.x1 - br.x0, ncx = cx1 - cx0;
+          int tx = br.x0, ty = br.y0;
+          for (int q = (br.y1 - br.y0) * w_t; q > 0; --q) {
+            if (bin_test(r, thr, tx, ty, f.W, f.H, bound)) {
+              const int slot = (ty / COARSE - cy0) * ncx + (tx / COARSE - cx0);
+              const int pos = slot * 16 + (ty % COARSE) * COARSE + (tx % COARSE);
+              if (pos < 64) mask_lo |= 1ull << pos; else mask_hi |= 1ull << (pos - 64);
+              ++n_dup;
             }
+            if (++tx == br.x1) { tx = br.x0; ++ty; }
+          }
         }
       }
     }
@@ -213,18 +221,18 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   if (g < N) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
   if (fits && n_dup && !big) {
     unsigned dup = (unsigned)(base + ex);
-    int k = 0;
-    for (int cy = cy0; cy < cy1; ++cy)
-      for (int cx = cx0; cx < cx1; ++cx, ++k) {
-        const unsigned m = k < 4 ? (unsigned)((cached >> (16 * k)) & 0xffffu) : coarse_hits(r, thr, br, cx, cy, f.W, f.H, bound);
-        if (m) {
-          const int cb = cy * CX + cx;
-          const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
-          if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4((unsigned)g, depth_bits, dup, m);
-          else hdr[HDR_OVERFLOW] = 1ull;
-          dup += (unsigned)__popc(m);
-        }
+    int cx = cx0, cy = cy0;
+    for (int k = 0, nb = (cx1 - cx0) * (cy1 - cy0); k < nb; ++k) {
+      const unsigned m = (unsigned)((k < 4 ? mask_lo >> (16 * k) : mask_hi >> (16 * (k - 4))) & 0xffffull);
+      if (m) {
+        const int cb = cy * CX + cx;
+        const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+        if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4((unsigned)g, depth_bits, dup, m);
+        else hdr[HDR_OVERFLOW] = 1ull;
+        dup += (unsigned)__popc(m);
       }
+      if (++cx == cx1) { cx = cx0; ++cy; }
+    }
   }
   for (unsigned long long bl = fits ? big_lanes : 0ull; bl; bl &= bl - 1) {  // cooperative emission (fits is block-uniform)
     const int L = __builtin_ctzll(bl);
