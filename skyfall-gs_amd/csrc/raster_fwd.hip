@@ -553,6 +553,27 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
     }
   };
 
+  // full sort of the m (power of two, <= CAP) entries in LDS. For m = 4096 each of the four waves first sorts its own
+  // 1024 entries in REGISTERS (the network of sort_tile_in_registers, 16 keys per lane: no barriers, no LDS traffic),
+  // which leaves only the 23 merge steps of sizes 2048 and 4096 to LDS instead of all 78
+  auto sort_lds = [&](int m) {
+    int first = 2;
+    if (m == 4 * 1024) {
+      constexpr int E = 16;
+      const int wv = tid >> 6, ln = tid & 63, cb = 1024 * wv;
+      unsigned long long key[E];
+      unsigned pay[E];
+#pragma unroll
+      for (int r = 0; r < E; ++r) { key[r] = k[cb + r * 64 + ln]; pay[r] = pl[cb + r * 64 + ln]; }
+      wave_bitonic_sort<E>(key, pay, ln);
+#pragma unroll
+      for (int r = 0; r < E; ++r) { k[cb + ln * E + r] = key[r]; pl[cb + ln * E + r] = pay[r]; }
+      __syncthreads();
+      first = 2048;
+    }
+    for (int size = first; size <= m; size <<= 1) { lds_mirror(m, size); lds_strides(m, size >> 2); }
+  };
+
   for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
     const uint2 tr = tile_range[long_tiles[li]];
     const unsigned s = tr.x;
@@ -570,7 +591,7 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
         k[i] = key; pl[i] = d;
       }
       __syncthreads();
-      for (int size = 2; size <= m; size <<= 1) { lds_mirror(m, size); lds_strides(m, size >> 2); }
+      sort_lds(m);
       for (int i = tid; i < L; i += NT) { sorted_id[s + i] = (unsigned)(k[i] & 0xffffffffull); sorted_dup[s + i] = pl[i]; }
       continue;
     }
@@ -602,7 +623,7 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
     };
     for (long long base = 0; base < L; base += CAP) {  // every chunk fully sorted (network sizes 2 .. CAP)
       chunk_load(base);
-      for (int size = 2; size <= CAP; size <<= 1) { lds_mirror(CAP, size); lds_strides(CAP, size >> 2); }
+      sort_lds(CAP);
       chunk_store(base);
     }
     for (long long size = 2 * (long long)CAP; size <= n; size <<= 1) {
