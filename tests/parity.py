@@ -8,23 +8,28 @@ GRAD_RTOL_L2 = 1e-3        # relative L2 per gradient tensor
 GRAD_RTOL_MAX = 2e-3       # relative L-inf (normalised by max |ref|)
 
 
-def image_report(name, got, ref, rtol=RGB_DEPTH_RTOL):
+def image_report(name, got, ref, rtol=RGB_DEPTH_RTOL, nan_flips=0):
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     nan_g, nan_r = np.isnan(got), np.isnan(ref)
-    assert (nan_g == nan_r).all(), f"{name}: NaN pattern differs at {(nan_g != nan_r).sum()} pixels"
-    ok = ~nan_r
+    # depth is NaN where nothing was blended: a pixel whose ONLY contributor sits within an ulp of the 1/255
+    # threshold flips between NaN and a number -- counted with the borderline pixels when the caller allows it
+    n_flip = int((nan_g != nan_r).sum())
+    assert n_flip <= nan_flips, f"{name}: NaN pattern differs at {n_flip} pixels"
+    ok = ~nan_r & ~nan_g
     scale = max(np.abs(ref[ok]).max(), 1e-30) if ok.any() else 1.0
     err = np.zeros_like(ref)
     err[ok] = np.abs(got[ok] - ref[ok]) / scale
     bad = err > rtol
-    return dict(name=name, max_rel=float(err.max()), bad=int(bad.sum()), total=int(err.size))
+    return dict(name=name, max_rel=float(err.max()), bad=int(bad.sum()) + n_flip, total=int(err.size))
 
 
-def assert_image_close(name, got, ref, rtol=RGB_DEPTH_RTOL):
-    r = image_report(name, got, ref, rtol)
-    assert r["bad"] <= max(1, int(BORDERLINE_FRAC * r["total"])) or r["max_rel"] <= rtol, r
+def assert_image_close(name, got, ref, rtol=RGB_DEPTH_RTOL, borderline_min=1):
+    """borderline_min: pixels one borderline splat may flip on a small image (the 0.01 % rule of SURVEY A.7 is a
+    statement about large images; one such splat covers a handful of pixels)."""
+    r = image_report(name, got, ref, rtol, nan_flips=borderline_min if borderline_min > 1 else 0)
+    assert r["bad"] <= max(borderline_min, int(BORDERLINE_FRAC * r["total"])) or r["max_rel"] <= rtol, r
     assert r["max_rel"] < 5e-2, r   # a flipped borderline splat moves a pixel by <= alpha*T*|c| ~ 1/255
     return r
 
