@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 6
+#define SFGS_ABI_VERSION 7
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -108,7 +108,8 @@ typedef struct SfgsRasterSizes {
   size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile ranges, duplicate offsets      */
   size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials */
   size_t bins_bytes;     /* f(D, coarse_capacity): coarse-bin slabs, per-tile duplicates, sorted lists */
-  size_t image_bytes;    /* f(W,H): per-pixel last contributor, final T, raw depth (for backward)*/
+  size_t image_bytes;    /* f(W,H,D): per-pixel last contributor, final T, raw depth, and one 8-byte
+                            blended-entries mask per pixel and 64-entry list batch (for backward) */
   size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
   int64_t coarse_bins;   /* number of 32x32-pixel coarse bins of this image (informational)      */
 } SfgsRasterSizes;
@@ -137,10 +138,12 @@ int sfgs_profile_kernel_count(void);
 const char* sfgs_profile_kernel_name(int32_t id);
 int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);
 
-/* Blob sizes for N Gaussians, a W x H image, a duplicate capacity D (bins, dupgrad) and a per-coarse-bin
- * item capacity (bins). */
+/* Blob sizes for N Gaussians, a W x H image, a list-slot capacity D (bins, image, dupgrad) and a per-coarse-bin
+ * item capacity (bins). Every 8x8 tile's list starts on a multiple of 64 slots, so a frame with num_duplicates
+ * (Gaussian, tile) pairs needs D >= sfgs_raster_slot_capacity(W, H, num_duplicates) = num_duplicates + 64 * tiles. */
 int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse_capacity,
                       SfgsRasterSizes* out);
+int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates);
 
 /* Forward, stage 1 ("plan"): preprocess every Gaussian (cull, EWA projection, 2D mip filter,
  * radius, SH->RGB), write radii[N] (int32) and bin every Gaussian COARSELY: one 16-byte item per
@@ -182,11 +185,12 @@ int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* ge
 
 /* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
  * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same capacities, image)
- * and radii unchanged. `dupgrad` is scratch for dup_capacity duplicates (sfgs_raster_sizes). Every
- * gradient tensor in `grads` is fully overwritten. Deterministic (no float atomics). Asynchronous. */
+ * and radii unchanged. `dupgrad` is scratch: 48 bytes for each of the num_duplicates (Gaussian, tile) pairs the
+ * plan counted (sfgs_raster_sizes(N, W, H, num_duplicates, ..).dupgrad_bytes). Every gradient tensor in `grads` is
+ * fully overwritten. Deterministic (no float atomics). Asynchronous. */
 int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                          const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
-                         int64_t coarse_capacity, const void* image, const float* dL_dcolor,
+                         int64_t coarse_capacity, int64_t num_duplicates, const void* image, const float* dL_dcolor,
                          const float* dL_ddepth, const float* dL_dalpha, void* dupgrad,
                          size_t dupgrad_bytes, const SfgsGaussianGrads* grads, void* stream);
 

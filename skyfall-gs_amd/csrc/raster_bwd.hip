@@ -21,22 +21,28 @@ namespace sfgs {
 // Compositing backward. Workgroup = 4 independent waves = 2x2 tiles of 8x8 pixels (as the forward).
 // The tile's list is walked back to front in batches of B entries, each batch in two phases:
 //
-//   phase 1 (lane = pixel): for every entry, advance the pixel's transmittance / "colour behind"
-//            recurrences and store the two scalars all 12 gradients derive from -- u = G dL/dalpha and
-//            w = alpha T -- into wave-private LDS matrices U[j][p], Wm[j][p] (row stride 65: both the
-//            pixel-major writes and the entry-major reads below are bank-conflict free).
-//   phase 2 (lane = entry j, 64/B lanes per entry each owning B pixels): accumulate the 12 sums over
-//            pixels in registers -- the per-(splat, tile) reduction becomes in-lane adds instead of a
-//            12-value cross-lane reduction per entry -- then combine the 64/B partial lanes and write
-//            ONE 64-byte line per duplicate.
+//   phase 1 (lane = pixel): SPARSE. Only ~24 % of the (pixel, entry) pairs of a list were blended by the forward,
+//            which recorded them: one bit per (pixel, entry) in the image blob's hit-mask words. Every lane walks ITS
+//            OWN set bits of the batch (most significant first = back to front), reads that entry's record from the
+//            LDS stage with a per-lane address, advances the pixel's transmittance / "colour behind" recurrences and
+//            stores the two scalars all 12 gradients derive from -- u = G dL/dalpha and w = alpha T -- into
+//            wave-private LDS matrices U[j][p], Wm[j][p] (zero-filled per batch; row stride 65: both the pixel-major
+//            writes and the entry-major reads below are bank-conflict free). The wave leaves the phase after
+//            max_p popcount steps: 0.44 B on the headline scene instead of B (tools/workmodel), and no pair is
+//            re-tested (no compare / select chain; the forward's decisions are replayed bit for bit).
+//   phase 2 (lane = entry j, 64/B lanes per entry each owning B pixels): accumulate the 12 sums over pixels in
+//            registers -- the per-(splat, tile) reduction becomes in-lane adds instead of a 12-value cross-lane
+//            reduction per entry -- then combine the 64/B partial lanes and write ONE 48-byte record per duplicate.
 //
 // No float atomics anywhere: gradients are bit-reproducible run to run.
 template <int B>
-struct BwdLds {
+struct alignas(16) BwdLds {
   static constexpr int ROW = 65;
-  float U[B * ROW];
-  float Wm[B * ROW];
-  float4 recs[B * 3];
+  // UW[j][p] = (u, w) of entry j at pixel p; row B is a dummy row (written by lanes that have no blended entry left in
+  // the batch, never read). Row stride 65 pairs: the pixel-major 8-byte writes and the entry-major 8-byte reads of
+  // phase 2 are both bank-conflict free on the 64-bank LDS.
+  float2 UW[(B + 1) * ROW];
+  float4 recs[(B + 1) * 3];   // staged records of the batch; record B is all zeros (the dummy entry: alpha = 0)
 };
 
 // value of lane I of the caller's 16-lane row, broadcast to the whole row (DPP row_newbcast; folds into
@@ -126,8 +132,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                     const float* __restrict__ dL_dalpha, float4* __restrict__ dupgrad,
-                     const unsigned long long* __restrict__ hdr) {
+                     const float* __restrict__ dL_dalpha, const uint2* __restrict__ hitmask,
+                     float4* __restrict__ dupgrad, const unsigned long long* __restrict__ hdr) {
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[4];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
@@ -136,6 +142,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[wave];
+  if (lane < 3) lds.recs[B * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy entry (see phase 1)
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
@@ -198,50 +205,66 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     }
     if (nbatch >= 2 && lane < B) { id_next = sorted_id[s + b0 - B + lane]; dup_next = sorted_dup[s + b0 - B + lane]; }
   }
+  // hit-mask words of the tile's 64-entry groups (one uint2 per pixel and group), fetched one group ahead
+  static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
+  int g_cur = (nbatch - 1) >> 2;
+  uint2 mw = hitmask[(size_t)s + 64u * (unsigned)g_cur + lane];
+  uint2 mw_next = make_uint2(0u, 0u);
+  if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
   for (int bi = nbatch - 1; bi >= 0; --bi) {
     const unsigned b0 = (unsigned)bi * B;
     const unsigned cnt = min((unsigned)B, kmax - b0);
     const unsigned my_dup = dup_cur;
+    if ((bi >> 2) != g_cur) {
+      g_cur = bi >> 2;
+      mw = mw_next;
+      if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
+    }
+    // this pixel's blended entries of the batch: bit j <=> entry b0 + j
+    unsigned pm = (((bi & 2) ? mw.y : mw.x) >> (16 * (bi & 1))) & 0xffffu;
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
     if (bi >= 1 && lane < B) {  // batches below the last one are always full
       n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2];
       dup_cur = dup_next;
       if (bi >= 2) { id_next = sorted_id[s + b0 - 2 * B + lane]; dup_next = sorted_dup[s + b0 - 2 * B + lane]; }
     }
+    {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2
+      float4* z = reinterpret_cast<float4*>(lds.UW);
+      constexpr int NZ = B * ROW / 2;
+      static_assert((B * ROW) % 2 == 0, "zero fill in 16-byte stores");
+#pragma unroll
+      for (int i = 0; i < (NZ + 63) / 64; ++i)
+        if (i * 64 + lane < NZ) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- phase 1: lane = pixel -------------------------------------------------------------------
-    // the (broadcast) LDS reads of entry j - 1 are issued before entry j is evaluated
-    float4 r0n = lds.recs[(cnt - 1) * 3], r1n = lds.recs[(cnt - 1) * 3 + 1];
-    float2 r2n = *reinterpret_cast<const float2*>(&lds.recs[(cnt - 1) * 3 + 2]);
-#pragma unroll 4
-    for (int j = (int)cnt - 1; j >= 0; --j) {
-      const unsigned k = b0 + (unsigned)j;
-      const float4 r0 = r0n, r1 = r1n;
-      const float2 r2 = r2n;
-      const int jn = j > 0 ? j - 1 : 0;
-      r0n = lds.recs[jn * 3]; r1n = lds.recs[jn * 3 + 1];
-      r2n = *reinterpret_cast<const float2*>(&lds.recs[jn * 3 + 2]);
+    // ---- phase 1: lane = pixel, each lane walks its own blended entries back to front -------------------------
+    // Divergence-free: a lane whose bits are exhausted keeps stepping on the DUMMY entry B (a zero record: alpha = 0,
+    // so 1 / (1 - alpha) = 1 and w = 0 leave Tr untouched; the lazily applied "colour behind" update runs once and is
+    // then a no-op because last_alpha becomes 0; its (u, w) goes to the dummy row). No exec masking, no state copies:
+    // the loop body is one straight basic block.
+    while (__ballot(pm != 0u) != 0ull) {
+      const unsigned j = min(31u - (unsigned)__clz(pm), (unsigned)B);   // __clz(0) = 32 -> wraps -> B
+      pm = __builtin_amdgcn_ubfe(pm, 0u, j);                            // clear bit j and everything above it
+      const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
+      const float2 r2 = *reinterpret_cast<const float2*>(&lds.recs[j * 3 + 2]);
       const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-      const bool act = k < last && ev.ok;
-      float u = 0.f, w = 0.f;
-      if (act) pixel_bwd_scalars(ps, ev, r1.z, r1.w, r2.x, r2.y, u, w);
-      lds.U[j * ROW + lane] = u;
-      lds.Wm[j * ROW + lane] = w;
+      float u, w;
+      pixel_bwd_scalars(ps, ev, r1.z, r1.w, r2.x, r2.y, u, w);
+      lds.UW[j * ROW + lane] = make_float2(u, w);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
     // Every lane runs the 16 steps (a DPP source lane must be active); lanes of entries beyond cnt read
-    // stale U/Wm rows and their sums are discarded below.
+    // zero U/Wm rows and their sums are discarded below.
     Phase2Acc pa;
     float op, cA, cB, cC;
     {
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
       const float mx = r0.x, my = r0.y;
       cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x; op = r1.y;
-      const float* Urow = &lds.U[ej * ROW + grp * B];
-      const float* Wrow = &lds.Wm[ej * ROW + grp * B];
+      const float2* UWrow = &lds.UW[ej * ROW + grp * B];
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
       // rolled loops over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
       // compiler from hoisting all 32 LDS loads above the arithmetic, which costs ~30 VGPRs
@@ -252,7 +275,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         const float ky0 = fmaf(cC, dy0, cB * mxl), ky1 = fmaf(cC, dy1, cB * mxl);
         const float ncA = -cA, ncB = -cB;
         Phase2Grid pg = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define SFGS_P2(I) phase2_grid_step<I>(pg, Urow[I], Wrow[I], ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
+#define SFGS_P2(I) phase2_grid_step<I>(pg, UWrow[I].x, UWrow[I].y, ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
 #pragma nounroll
         for (int c = 0; c < 4; ++c) {
           switch (c) {
@@ -266,7 +289,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
       } else {
         pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define SFGS_P2(I) phase2_step<I>(pa, Urow[I], Wrow[I], mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
+#define SFGS_P2(I) phase2_step<I>(pa, UWrow[I].x, UWrow[I].y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
 #pragma nounroll
         for (int c = 0; c < 4; ++c) {
           switch (c) {
@@ -410,7 +433,8 @@ using namespace sfgs;
 
 extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                                     const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
-                                    int64_t coarse_capacity, const void* image, const float* dL_dcolor, const float* dL_ddepth,
+                                    int64_t coarse_capacity, int64_t num_duplicates, const void* image,
+                                    const float* dL_dcolor, const float* dL_ddepth,
                                     const float* dL_dalpha, void* dupgrad, size_t dupgrad_sz,
                                     const SfgsGaussianGrads* grads, void* stream_) {
   SFGS_REQUIRE(frame && frame->struct_size == sizeof(SfgsFrame), SFGS_E_ARG, "SfgsFrame.struct_size mismatch");
@@ -426,9 +450,11 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_REQUIRE((g->colors_precomp != nullptr) == (grads->colors_precomp != nullptr) &&
                    (g->shs != nullptr) == (grads->shs != nullptr),
                SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
-  SFGS_REQUIRE(dup_capacity >= 0 && dupgrad_sz >= dupgrad_bytes(dup_capacity), SFGS_E_CAPACITY,
-               "dupgrad blob: %zu bytes given, %zu needed", dupgrad_sz, dupgrad_bytes(dup_capacity));
-  SFGS_REQUIRE(dup_capacity == 0 || (bins && dupgrad), SFGS_E_ARG, "bins / dupgrad is NULL");
+  SFGS_REQUIRE(dup_capacity >= 0 && num_duplicates >= 0 && num_duplicates <= dup_capacity, SFGS_E_ARG,
+               "bad dup_capacity / num_duplicates");
+  SFGS_REQUIRE(dupgrad_sz >= dupgrad_bytes(num_duplicates), SFGS_E_CAPACITY,
+               "dupgrad blob: %zu bytes given, %zu needed", dupgrad_sz, dupgrad_bytes(num_duplicates));
+  SFGS_REQUIRE(num_duplicates == 0 || (bins && dupgrad), SFGS_E_ARG, "bins / dupgrad is NULL");
   const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
   const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity, coarse_bins(W, H), coarse_capacity);
@@ -439,7 +465,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, (float4*)dupgrad, tv.hdr); }
+                       dL_dalpha, iv.hitmask, (float4*)dupgrad, tv.hdr); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);

@@ -324,8 +324,9 @@ plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, con
 // every coarse item into its per-tile duplicates: items[slot] = (id, depth, dup index, 0).
 __global__ void __launch_bounds__(256)
 fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ coarse_count,
-                const uint4* __restrict__ slabs, unsigned coarse_capacity, uint2* __restrict__ tile_range,
-                uint4* __restrict__ items, uint32_t* __restrict__ long_tiles, unsigned long long* __restrict__ hdr) {
+                const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long slot_capacity,
+                uint2* __restrict__ tile_range, uint4* __restrict__ items, uint32_t* __restrict__ long_tiles,
+                unsigned long long* __restrict__ hdr) {
   __shared__ unsigned cnt[COARSE_TILES];
   __shared__ unsigned long long s_base;
   const int cb = blockIdx.x, tid = threadIdx.x;
@@ -340,19 +341,30 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
   __syncthreads();
   if (tid < 64) {  // first wave: exclusive scan of the 16 counts, one allocation for the whole bin
     const unsigned c = tid < COARSE_TILES ? cnt[tid] : 0u;
-    unsigned incl = c;
+    // every list starts on a multiple of LIST_ALIGN (= 64) slots: the compositing kernels load ids 64 at a time from
+    // 256-byte aligned addresses, and slot s + 64 b + lane doubles as the index of the per-pixel hit-mask word of the
+    // tile's b-th batch (image blob). Costs index space only (<= 63 unused slots per tile), no traffic.
+    const unsigned ca = (c + LIST_ALIGN - 1) & ~(unsigned)(LIST_ALIGN - 1);
+    unsigned incl = ca;
 #pragma unroll
     for (int d = 1; d < COARSE_TILES; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (tid >= d) incl += t; }
     const unsigned total = __shfl(incl, COARSE_TILES - 1);
     unsigned long long base = 0;
-    if (tid == 0) { if (total) base = atomicAdd(&hdr[HDR_ITEM_ALLOC], (unsigned long long)total); s_base = base; }
+    if (tid == 0) {
+      if (total) base = atomicAdd(&hdr[HDR_ITEM_ALLOC], (unsigned long long)total);
+      // memory safety when the caller's slot capacity is too small (the wrapper sizes it as D + 64 T8, which always
+      // suffices): the bin's lists are dropped and the frame is flagged
+      if (base + total > slot_capacity) { hdr[HDR_OVERFLOW] = 1ull; base = ~0ull; }
+      s_base = base;
+    }
     base = __shfl(base, 0);
-    const unsigned off = incl - c;
+    const bool dropped = base == ~0ull;
+    const unsigned off = incl - ca;
     if (tid < COARSE_TILES) {
       const int tx = (cb % CX) * COARSE + (tid & (COARSE - 1)), ty = (cb / CX) * COARSE + (tid / COARSE);
       if (tx < TX8 && ty < TY8) {
-        tile_range[ty * TX8 + tx] = make_uint2((unsigned)base + off, c);
-        if (c > REG_SORT_SMALL) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
+        tile_range[ty * TX8 + tx] = dropped ? make_uint2(0u, 0u) : make_uint2((unsigned)base + off, c);
+        if (c > REG_SORT_SMALL && !dropped) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
       }
       cnt[tid] = off;  // becomes the per-tile cursor
       if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
@@ -360,6 +372,7 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
   }
   __syncthreads();
   const unsigned long long base = s_base;
+  if (base == ~0ull) return;
   for (unsigned i = tid; i < n; i += 256) {
     const uint4 it = slab[i];
     unsigned m = it.w, dup = it.z;
@@ -656,12 +669,16 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
 // a wave owns pixel (l & 7, l >> 3) of its tile. Records of 64 list entries at a time are gathered
 // (48 B each) into a wave-private LDS stage and consumed with uniform-address (broadcast) reads.
 // No barriers: a wave only ever reads what it wrote itself.
+// TRAIN (a backward will follow): every pixel also records WHICH entries it blended, one bit per entry, and the
+// wave stores one 8-byte word per pixel and 64-entry batch (image blob, `hitmask`): the backward then walks each
+// pixel's own blended entries instead of re-testing every (pixel, entry) pair of the list (raster_bwd.hip).
+template <bool TRAIN>
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const float4* __restrict__ rec,
                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
                      uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out,
-                     const unsigned long long* __restrict__ hdr) {
+                     uint2* __restrict__ hitmask, const unsigned long long* __restrict__ hdr) {
   __shared__ float4 stage[4][64 * 3];
   __shared__ __attribute__((aligned(8))) unsigned char rowlist[4][4][64];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
@@ -712,16 +729,19 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // that can touch it (~65 % of them); the four strips advance in lockstep and the wave leaves the batch when the
     // longest list is exhausted. Exact: the skipped pairs are pairs the per-pixel test would have rejected.
     // (Eight single-row lists need fewer steps but twice the list set-up: same time.)
-    {
-      const float my = stage_my, ey = stage_ey;   // this lane's STAGED entry (entry index = lane)
-      const float ylo = (float)(ty * 8) - bound, yhi = (float)(ty * 8 + 1) + bound;
-      const bool live = (unsigned)lane < cnt;
-      const unsigned long long b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
-      const unsigned long long b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
-      const unsigned long long b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
-      const unsigned long long b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
-      // per-row compact entry lists (bytes) in LDS: entry `lane` goes to position rank(lane) of every row it touches
-      unsigned char* Lw = &rowlist[wave][0][0];
+    const float my = stage_my, ey = stage_ey;   // this lane's STAGED entry (entry index = lane)
+    const float ylo = (float)(ty * 8) - bound, yhi = (float)(ty * 8 + 1) + bound;
+    const bool live = (unsigned)lane < cnt;
+    const unsigned long long b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
+    const unsigned long long b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
+    const unsigned long long b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
+    const unsigned long long b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
+    // per-row compact entry lists (bytes) in LDS
+    unsigned char* Lw = &rowlist[wave][0][0];
+    const int row = lane >> 4;
+    const unsigned char* Lr = Lw + row * 64;
+    if constexpr (!TRAIN) {
+      // entry `lane` goes to position rank(lane) of every row it touches
       auto rank = [&](unsigned long long m) {
         return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
       };
@@ -732,10 +752,8 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const int n0r = __popcll(b0), n1r = __popcll(b1), n2r = __popcll(b2), n3r = __popcll(b3);
-      const int row = lane >> 4;
       const int len = row == 0 ? n0r : row == 1 ? n1r : row == 2 ? n2r : n3r;
       const int maxlen = max(max(n0r, n1r), max(n2r, n3r));
-      const unsigned char* Lr = Lw + row * 64;
       for (int i = 0; i < maxlen; i += 8) {   // 8 list positions per early-exit check
         const uint2 j8 = *reinterpret_cast<const uint2*>(Lr + i);   // eight byte indices at once (i % 8 == 0)
 #pragma unroll
@@ -750,6 +768,48 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         }
         if (__ballot(ps.T > 0.f) == 0ull) break;
       }
+    } else {
+      // The batch is walked as two halves of 32 entries (row lists: positions 0.. for entries 0..31, positions 32..
+      // for entries 32..63), so that a pixel's blended-entry bits of one half live in ONE 32-bit register and the
+      // bit index is the entry index itself (v_lshl_or uses the low five bits of j).
+      auto pos = [&](unsigned long long m) {
+        const unsigned lo = __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u);
+        const unsigned hi = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), 0u);
+        return lane < 32 ? lo : 32u + hi;
+      };
+      if ((b0 >> lane) & 1ull) Lw[0 * 64 + pos(b0)] = (unsigned char)lane;
+      if ((b1 >> lane) & 1ull) Lw[1 * 64 + pos(b1)] = (unsigned char)lane;
+      if ((b2 >> lane) & 1ull) Lw[2 * 64 + pos(b2)] = (unsigned char)lane;
+      if ((b3 >> lane) & 1ull) Lw[3 * 64 + pos(b3)] = (unsigned char)lane;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int n0r = __popc((unsigned)(b0 >> (32 * half))), n1r = __popc((unsigned)(b1 >> (32 * half)));
+        const int n2r = __popc((unsigned)(b2 >> (32 * half))), n3r = __popc((unsigned)(b3 >> (32 * half)));
+        const int len = row == 0 ? n0r : row == 1 ? n1r : row == 2 ? n2r : n3r;
+        const int maxlen = max(max(n0r, n1r), max(n2r, n3r));
+        unsigned& m = half ? mhi : mlo;
+        bool done = false;
+        for (int i = 0; i < maxlen; i += 8) {
+          const uint2 j8 = *reinterpret_cast<const uint2*>(Lr + 32 * half + i);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (i + u < len) {
+              const unsigned j = ((u < 4 ? j8.x : j8.y) >> (8 * (u & 3))) & 0xffu;
+              const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
+              const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
+              const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
+              pixel_fwd_step_mask(ps, ev, r1.z, r1.w, r2.x, r2.y, j, m);
+            }
+          }
+          if (__ballot(ps.T > 0.f) == 0ull) { done = true; break; }
+        }
+        if (done) break;
+      }
+      if (mlo | mhi) ps.last = k0 + (mhi ? 63u - (unsigned)__clz(mhi) : 31u - (unsigned)__clz(mlo)) + 1u;
+      hitmask[(size_t)b + lane] = make_uint2(mlo, mhi);   // b is a multiple of 64: one 512-byte store per batch
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -763,7 +823,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const float a = 1.0f - T;
     out_alpha[pix] = a;
     out_depth[pix] = kf.depth_mode == SFGS_DEPTH_NORMALISED ? D / a : D;
-    if (n_contrib) { n_contrib[pix] = last; final_T[pix] = T; dacc_out[pix] = D; }
+    if constexpr (TRAIN) { n_contrib[pix] = last; final_T[pix] = T; dacc_out[pix] = D; }
   }
 }
 
@@ -814,10 +874,15 @@ extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int
   out->geom_bytes = geom_bytes(N);
   out->tiles_bytes = tb;
   out->bins_bytes = bins_bytes(D, coarse_bins(W, H), coarse_capacity);
-  out->image_bytes = image_bytes(W, H);
+  out->image_bytes = image_bytes(W, H, D);
   out->dupgrad_bytes = dupgrad_bytes(D);
   out->coarse_bins = coarse_bins(W, H);
   return SFGS_OK;
+}
+
+extern "C" int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates) {
+  if (W <= 0 || H <= 0 || num_duplicates < 0) return -1;
+  return num_duplicates + (int64_t)LIST_ALIGN * tiles8(W, H);
 }
 
 extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* geom,
@@ -918,12 +983,13 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const int64_t NCB = coarse_bins(W, H);
   SFGS_REQUIRE(N >= 0 && tiles && out_color && out_depth && out_alpha && bins, SFGS_E_ARG, "NULL argument");
   SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0, SFGS_E_ARG, "bad capacity");
-  SFGS_REQUIRE(num_duplicates <= dup_capacity, SFGS_E_CAPACITY,
-               "num_duplicates %lld exceeds dup_capacity %lld: redo the plan with a larger bins blob",
-               (long long)num_duplicates, (long long)dup_capacity);
+  SFGS_REQUIRE(num_duplicates < 0 || sfgs_raster_slot_capacity(W, H, num_duplicates) <= dup_capacity, SFGS_E_CAPACITY,
+               "%lld duplicates need %lld list slots, dup_capacity is %lld: redo the plan with larger blobs",
+               (long long)num_duplicates, (long long)sfgs_raster_slot_capacity(W, H, num_duplicates),
+               (long long)dup_capacity);
   SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
                "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
-  SFGS_REQUIRE(image == nullptr || image_sz >= image_bytes(W, H), SFGS_E_CAPACITY, "image blob too small");
+  SFGS_REQUIRE(image == nullptr || image_sz >= image_bytes(W, H, dup_capacity), SFGS_E_CAPACITY, "image blob too small");
   const TilesView tv = tiles_view(tiles, W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
   const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
@@ -931,7 +997,8 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
   { ProfScope ps_(KID_FINE_BIN, stream);
     hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
-                       tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr); }
+                       tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.tile_range,
+                       bv.items, tv.long_tiles, tv.hdr); }
   SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
   if (num_duplicates != 0) {  // < 0: unknown (render enqueued before the counters were read)
     { ProfScope ps_(KID_SORT_SMALL, stream);
@@ -949,12 +1016,18 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_long", stream, frame->debug);
   }
-  ImageView iv = {nullptr, nullptr, nullptr};
-  if (image) iv = image_view(image, W, H);
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_FWD, stream);
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
-                       bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T, iv.dacc, tv.hdr); }
+    if (image) {
+      const ImageView iv = image_view(image, W, H);
+      hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk,
+                         tv.tile_range, bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T,
+                         iv.dacc, iv.hitmask, tv.hdr);
+    } else {
+      hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk,
+                         tv.tile_range, bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, (uint32_t*)nullptr,
+                         (float*)nullptr, (float*)nullptr, (uint2*)nullptr, tv.hdr);
+    } }
   SFGS_POST_LAUNCH("composite_fwd", stream, frame->debug);
   return SFGS_OK;
 }

@@ -433,6 +433,20 @@ SFGS_HD void pixel_fwd_step(PixelFwd& s, const SplatEval& e, float depth, float 
   s.T = acc ? test_T : (e.ok ? -fabsf(s.T) : s.T);
 }
 
+// Training-mode variant: instead of the last-contributor index, the pixel records WHICH entries it blended as a bit
+// mask (bit = entry index within the current 32-entry half batch; the shift uses the low five bits of j). The
+// backward walks exactly these bits, so it never re-tests a pair (raster_bwd.hip). Same arithmetic as pixel_fwd_step.
+SFGS_HD void pixel_fwd_step_mask(PixelFwd& s, const SplatEval& e, float depth, float r, float g, float b, unsigned j,
+                                 unsigned& mask) {
+  const float test_T = s.T * (1.0f - e.alpha);
+  const bool acc = e.ok && !(test_T < 0.0001f);
+  const float w = acc ? e.alpha * s.T : 0.f;
+  s.C0 = fmaf(r, w, s.C0); s.C1 = fmaf(g, w, s.C1); s.C2 = fmaf(b, w, s.C2);
+  s.D = fmaf(depth, w, s.D);
+  mask |= (acc ? 1u : 0u) << (j & 31u);
+  s.T = acc ? test_T : (e.ok ? -fabsf(s.T) : s.T);
+}
+
 struct PixelBwd {
   float Tr, last_alpha;
   float A, q_prev;   // A = sum_ch accum_ch * g_ch, q_prev = sum_ch value_ch(previous splat) * g_ch  (see below)

@@ -188,17 +188,24 @@ static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coa
   return b;
 }
 
+constexpr int LIST_ALIGN = 64;  // every tile list starts on a multiple of 64 slots (fine_bin_kernel)
+
 struct ImageView {
   uint32_t* n_contrib;  // [P] list position (1-based) of the last contributor
   float* final_T;       // [P]
   float* dacc;          // [P] un-normalised accumulated depth
+  uint2* hitmask;       // [slot capacity] word (first slot of the tile + 64 b + lane) = which of the 64 entries of the
+                        //   tile's b-th batch pixel `lane` BLENDED (bit j of .x: entry j, bit j of .y: entry 32 + j)
 };
-static inline size_t image_bytes(int W, int H) { return 3 * align_up((size_t)W * H * 4, 256); }
+static inline size_t image_bytes(int W, int H, int64_t D) {
+  return 3 * align_up((size_t)W * H * 4, 256) + align_up((size_t)D * 8, 256);
+}
 static inline ImageView image_view(void* base, int W, int H) {
   ImageView v;
   char* p = (char*)base;
   const size_t plane = align_up((size_t)W * H * 4, 256);
   v.n_contrib = (uint32_t*)p; v.final_T = (float*)(p + plane); v.dacc = (float*)(p + 2 * plane);
+  v.hitmask = (uint2*)(p + 3 * plane);
   return v;
 }
 

@@ -152,7 +152,8 @@ class _Rasterize(torch.autograd.Function):
                 L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
                 ncb = _ncb_cache[(W, H)] = max(int(sizes.coarse_bins), 1)
             hint = _cap_hint.get((dev.index, W, H), (0, 0))
-            cap = max(hint[0], 4 * N, 1024)
+            slots = lambda d: int(lib.sfgs_raster_slot_capacity(W, H, d))   # every tile list is 64-slot aligned
+            cap = max(hint[0], slots(4 * N))
             ccap = max(hint[1], 8 * N // ncb, 256)
             need_bwd = any(ctx.needs_input_grad[:7])
             # few, large allocations: the Python time before the first launch is GPU idle time
@@ -202,11 +203,11 @@ class _Rasterize(torch.autograd.Function):
                     ev.synchronize()
                     L.check(lib.sfgs_raster_counters_decode(L.C.c_void_p(pin.data_ptr()), L.C.byref(cnt)))
                 D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
-                if not cnt.overflow and D <= cap and cmax <= ccap:
+                if not cnt.overflow and slots(D) <= cap and cmax <= ccap:
                     break
-                cap = max(cap, int(D * 1.25) + 1024)
+                cap = max(cap, slots(int(D * 1.25) + 1024))
                 ccap = max(ccap, int(cmax * 1.25) + 256)
-            _cap_hint[(dev.index, W, H)] = (max(int(D * 1.25) + 1024, min(cap, 2 * D + 1024)),
+            _cap_hint[(dev.index, W, H)] = (max(slots(int(D * 1.25) + 1024), min(cap, slots(2 * D + 1024))),
                                     max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
             _last_counters.clear()
             _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
@@ -218,7 +219,7 @@ class _Rasterize(torch.autograd.Function):
         norm = _zero(dev).expand(3, H, W)
         ctx.mark_non_differentiable(radii, norm)
         if need_bwd:
-            ctx.settings, ctx.D, ctx.ccap, ctx.sh_coeffs = settings, cap, ccap, sh_coeffs
+            ctx.settings, ctx.D, ctx.ccap, ctx.sh_coeffs, ctx.ndup = settings, cap, ccap, sh_coeffs, D
             ctx.keep = keep
             ctx.has_colors, ctx.has_shs = colors_precomp is not None, shs is not None
             ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, geom, tiles, bins,
@@ -257,12 +258,12 @@ class _Rasterize(torch.autograd.Function):
             g_shs = take(3 * K, (N, K, 3)) if ctx.has_shs else None
             grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
                                         L.ptr(g_scales), L.ptr(g_rot), L.ptr(g_opac), L.ptr(g_col), L.ptr(g_shs))
-            dupgrad = torch.empty(max((D * 48 + 255) // 256 * 256, 1), dtype=torch.uint8, device=dev)
+            dupgrad = torch.empty(max((ctx.ndup * 48 + 255) // 256 * 256, 1), dtype=torch.uint8, device=dev)
             gc = None if g_color is None else g_color.contiguous().float()
             gd = None if g_depth is None else g_depth.contiguous().float()
             ga = None if g_alpha is None else g_alpha.contiguous().float()
             L.check(lib.sfgs_raster_backward(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom), L.ptr(tiles),
-                                             L.ptr(bins), D, ctx.ccap, L.ptr(image), L.ptr(gc), L.ptr(gd), L.ptr(ga),
+                                             L.ptr(bins), D, ctx.ccap, ctx.ndup, L.ptr(image), L.ptr(gc), L.ptr(gd), L.ptr(ga),
                                              L.ptr(dupgrad), dupgrad.numel(), L.C.byref(grads), stream))
         return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None
 

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsfgs.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -67,6 +67,7 @@ SYMBOLS = {
     "sfgs_profile_kernel_name": (C.c_char_p, [_I32]),
     "sfgs_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
     "sfgs_raster_sizes": (C.c_int, [_I32, _I32, _I32, _I64, _I64, C.POINTER(SfgsRasterSizes)]),
+    "sfgs_raster_slot_capacity": (C.c_int64, [_I32, _I32, _I64]),
     "sfgs_raster_forward_plan": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _V, _SZ, _V, _SZ,
                                             _I64, _I64, _V, _V]),
     "sfgs_raster_counters_decode": (C.c_int, [_V, C.POINTER(SfgsRasterCounters)]),
@@ -74,7 +75,7 @@ SYMBOLS = {
     "sfgs_raster_read_counters_pinned": (C.c_int, [_V, _V, C.POINTER(SfgsRasterCounters), _V]),
     "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _I64, _I64, _V, _V, _V,
                                               _V, _SZ, _V]),
-    "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _I64, _V,
+    "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _I64, _I64, _V,
                                         _V, _V, _V, _V, _SZ, C.POINTER(SfgsGaussianGrads), _V]),
     "sfgs_ssim_scratch_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32]),
     "sfgs_ssim_forward": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _V, _V, _V, _SZ, _I32, _V]),

@@ -30,6 +30,7 @@ def kernel_stats(path):
 
 
 TRAFFIC = {}
+SQ = {}   # kernel -> {counter: average per launch}
 
 
 def pmc_stats(path):
@@ -45,11 +46,55 @@ def pmc_stats(path):
         print(f"{short(n):44s} {cn:12s} {c:6d} {v:14.1f} {b:14.0f} {corr:14.0f} {d/1e3:9.2f}")
         if is_sz and "sfgs" in n:
             TRAFFIC.setdefault(short(n), {})[cn] = corr
+        if cn.startswith("SQ_") and "sfgs" in n:
+            e = SQ.setdefault(short(n), {})
+            e[cn] = v
+            e.setdefault("avg_us", d / 1e3)
     print()
+
+
+def sq_derived():
+    """One number each per kernel from the SQ passes (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* /
+    SQ_ACTIVE_INST_* count quad-cycles summed over waves; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES):
+      valu_util      = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   share of SIMD issue time doing VALU
+      valu_of_wave   = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES                      share of a wave's lifetime issuing VALU
+      wait_any       = SQ_WAIT_ANY / SQ_WAVE_CYCLES                              parked on s_waitcnt / barrier
+      wait_inst      = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                         issue stalls (pipe busy)
+      lds_stall      = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
+      lds_conflict   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE                  extra LDS cycles from bank conflicts
+      occupancy      = SQ_WAVE_CYCLES x 4 / (SQ_BUSY_CU_CYCLES x 4 SIMDs)        average resident waves per SIMD
+      valu_per_wave  = SQ_INSTS_VALU / SQ_WAVES"""
+    out = {}
+    print("# derived SQ metrics (per kernel, averages per launch)")
+    hdr = ["kernel", "avg_us", "occup/SIMD", "VALU util", "VALU/wave-life", "wait_any", "wait_inst", "lds_stall",
+           "lds_conflict", "VALU/wave", "LDS/wave", "SALU/wave"]
+    print(" ".join(f"{h:>14s}" if i else f"{h:32s}" for i, h in enumerate(hdr)))
+    for k, c in SQ.items():
+        g = lambda n: c.get(n, float("nan"))
+        wc, bcu = g("SQ_WAVE_CYCLES"), g("SQ_BUSY_CU_CYCLES")
+        waves = g("SQ_WAVES")
+        d = dict(avg_us=c.get("avg_us"), occupancy_waves_per_simd=wc * 4 / (bcu * 4) if bcu == bcu else float("nan"),
+                 valu_util=g("SQ_ACTIVE_INST_VALU") * 4 / (bcu * 4), valu_of_wave=g("SQ_ACTIVE_INST_VALU") / wc,
+                 wait_any=g("SQ_WAIT_ANY") / wc, wait_inst=g("SQ_WAIT_INST_ANY") / wc,
+                 lds_stall=g("SQ_WAIT_INST_LDS") / wc,
+                 lds_conflict=g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else float("nan"),
+                 valu_per_wave=g("SQ_INSTS_VALU") / waves, lds_per_wave=g("SQ_INSTS_LDS") / waves,
+                 salu_per_wave=g("SQ_INSTS_SALU") / waves, raw=c)
+        out[k] = d
+        vals = [d["avg_us"], d["occupancy_waves_per_simd"], d["valu_util"], d["valu_of_wave"], d["wait_any"],
+                d["wait_inst"], d["lds_stall"], d["lds_conflict"], d["valu_per_wave"], d["lds_per_wave"], d["salu_per_wave"]]
+        print(f"{k:32s} " + " ".join(f"{v:14.3f}" if v is not None else f"{'':14s}" for v in vals))
+    print()
+    return out
 
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    sq_json = None
+    if "--sq-json" in args:
+        i = args.index("--sq-json")
+        sq_json = args[i + 1]
+        args = args[:i] + args[i + 2:]
     json_out = None
     if "--json" in args:
         i = args.index("--json")
@@ -64,6 +109,11 @@ if __name__ == "__main__":
         kernel_stats(p)
     for p in pmcs:
         pmc_stats(p)
+    derived = sq_derived() if SQ else {}
+    if sq_json and derived:
+        import json
+        with open(sq_json, "w") as f:
+            json.dump(derived, f, indent=1)
     if json_out:
         import json
         with open(json_out, "w") as f:

@@ -1,0 +1,136 @@
+// workmodel.cpp -- CPU work model of the compositing kernels (design tool, not product, not oracle).
+// Builds the product's per-8x8-tile lists with the product's own math header (raster_math.h compiled by g++),
+// composites a window of tiles and counts, for candidate wave schedules of the backward, how many wave steps
+// each would take. Used to size design decisions before spending GPU time.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../skyfall-gs_amd/csrc/raster_math.h"
+
+using namespace sfgs;
+
+extern "C" {
+struct WmFrame {
+  int32_t W, H;
+  float tanfovx, tanfovy, kernel_size, scale_modifier;
+  const float* bg; const float* view; const float* proj; const float* campos;
+};
+
+// window of tiles [tx0,tx1) x [ty0,ty1); out[] receives the statistics (see tools/workmodel/run.py)
+int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales, const float* rots, const float* opac,
+           int tx0, int tx1, int ty0, int ty1, double* out, int n_out) {
+  FrameParams f;
+  memset(&f, 0, sizeof(f));
+  f.W = hf->W; f.H = hf->H; f.tanfovx = hf->tanfovx; f.tanfovy = hf->tanfovy;
+  f.kernel_size = hf->kernel_size; f.scale_modifier = hf->scale_modifier;
+  for (int i = 0; i < 16; ++i) { f.view[i] = hf->view[i]; f.proj[i] = hf->proj[i]; }
+  for (int i = 0; i < 3; ++i) { f.campos[i] = hf->campos[i]; f.bg[i] = hf->bg[i]; }
+  const int W = f.W, H = f.H;
+  const int TX8 = (W + 7) / 8;
+  const int wx = tx1 - tx0, wy = ty1 - ty0;
+  std::vector<std::vector<unsigned long long>> lists((size_t)wx * wy);
+  std::vector<SplatRec> recs;
+  std::vector<int> dup_per_gauss;
+  long long D_all = 0;
+  for (int g = 0; g < N; ++g) {
+    const Projected pr = project_gaussian(f, means + 3 * (size_t)g, scales + 3 * (size_t)g, rots + 4 * (size_t)g);
+    if (!pr.visible) continue;
+    const float rgb[3] = {0.5f, 0.5f, 0.5f};
+    SplatRec r = make_record(pr, opac[g], rgb);
+    const BinRange br = bin_range(r, W, H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, 0.f);
+    const float thr = alpha_threshold_log2(r.op);
+    uint32_t depth_bits; memcpy(&depth_bits, &r.depth, 4);
+    int idx = -1;
+    for (int ty = br.y0; ty < br.y1; ++ty)
+      for (int tx = br.x0; tx < br.x1; ++tx)
+        if (bin_test(r, thr, tx, ty, W, H, 0.f)) {
+          ++D_all;
+          if (tx >= tx0 && tx < tx1 && ty >= ty0 && ty < ty1) {
+            if (idx < 0) { idx = (int)recs.size(); recs.push_back(r); }
+            lists[(size_t)(ty - ty0) * wx + (tx - tx0)].push_back(((unsigned long long)depth_bits << 32) | (unsigned)idx);
+          }
+        }
+  }
+  (void)TX8;
+  // statistics
+  double n_tiles = 0, sumL = 0, sumK = 0, hits = 0, dense16 = 0;
+  double sp16 = 0, sp32 = 0, sp64 = 0, spInf = 0;        // per-lane sparse phase-1 steps with batch B
+  double q16 = 0, q64 = 0;                                // quadrant lists (4x4), lockstep max over quadrants
+  double strip16 = 0;                                     // row-pair strips (8x2)
+  double dead_entries = 0, live_entries = 0, behind = 0;  // entries < kmax with no accepted pixel; entries >= kmax
+  double task_nonzero = 0, task_total = 0;                // (entry, row-pair) tasks of phase 2
+  double hist_hits[65] = {0};
+  double live16_batches = 0, all16_batches = 0;           // batches (of 16) after dropping dead entries
+  for (int ty = 0; ty < wy; ++ty)
+    for (int tx = 0; tx < wx; ++tx) {
+      auto& l = lists[(size_t)ty * wx + tx];
+      std::sort(l.begin(), l.end());
+      const int L = (int)l.size();
+      if (!L) continue;
+      n_tiles += 1; sumL += L;
+      std::vector<unsigned long long> emask(L, 0ull);  // per entry: accepted-pixel mask
+      int kmax = 0;
+      for (int p = 0; p < 64; ++p) {
+        const int px = (tx0 + tx) * 8 + (p & 7), py = (ty0 + ty) * 8 + (p >> 3);
+        if (px >= W || py >= H) continue;
+        PixelFwd ps; pixel_fwd_init(ps, true);
+        for (int k = 0; k < L; ++k) {
+          const SplatRec& r = recs[(unsigned)(l[k] & 0xffffffffull)];
+          const SplatEval ev = eval_splat(r.mx, r.my, r.qa, r.qb, r.qc, r.op, (float)px, (float)py);
+          const unsigned before = ps.last;
+          pixel_fwd_step(ps, ev, r.depth, r.r, r.g, r.b, (unsigned)k);
+          if (ps.last != before) emask[k] |= 1ull << p;
+          if (!(ps.T > 0.f)) break;
+        }
+        kmax = std::max(kmax, (int)ps.last);
+      }
+      sumK += kmax; behind += L - kmax;
+      dense16 += (kmax + 15) / 16 * 16;
+      int pixhits[64] = {0};
+      int nlive = 0;
+      for (int k = 0; k < kmax; ++k) {
+        const int c = __builtin_popcountll(emask[k]);
+        hits += c; hist_hits[c] += 1;
+        if (c) { ++live_entries; ++nlive; } else ++dead_entries;
+        for (int rp = 0; rp < 4; ++rp) { task_total += 1; if ((emask[k] >> (16 * rp)) & 0xffffull) task_nonzero += 1; }
+        for (int p = 0; p < 64; ++p) pixhits[p] += (emask[k] >> p) & 1;
+      }
+      all16_batches += (kmax + 15) / 16; live16_batches += (nlive + 15) / 16;
+      spInf += *std::max_element(pixhits, pixhits + 64);
+      auto sparse = [&](int B) {
+        double steps = 0;
+        for (int b0 = 0; b0 < kmax; b0 += B) {
+          int cnt[64] = {0};
+          for (int k = b0; k < std::min(kmax, b0 + B); ++k) for (int p = 0; p < 64; ++p) cnt[p] += (emask[k] >> p) & 1;
+          steps += *std::max_element(cnt, cnt + 64);
+        }
+        return steps;
+      };
+      sp16 += sparse(16); sp32 += sparse(32); sp64 += sparse(64);
+      auto quad = [&](int B, bool strips) {
+        double steps = 0;
+        for (int b0 = 0; b0 < kmax; b0 += B) {
+          int cnt[4] = {0, 0, 0, 0};
+          for (int k = b0; k < std::min(kmax, b0 + B); ++k)
+            for (int q = 0; q < 4; ++q) {
+              unsigned long long qm = 0;
+              if (strips) qm = 0xffffull << (16 * q);
+              else for (int y = 0; y < 4; ++y) qm |= 0xfull << (((q >> 1) * 4 + y) * 8 + (q & 1) * 4);
+              if (emask[k] & qm) ++cnt[q];
+            }
+          steps += *std::max_element(cnt, cnt + 4);
+        }
+        return steps;
+      };
+      q16 += quad(16, false); q64 += quad(64, false); strip16 += quad(16, true);
+    }
+  double vals[] = {n_tiles, sumL, sumK, hits, dense16, sp16, sp32, sp64, spInf, q16, q64, strip16, dead_entries,
+                   live_entries, behind, task_nonzero, task_total, (double)D_all, all16_batches, live16_batches};
+  int nv = (int)(sizeof(vals) / sizeof(vals[0]));
+  for (int i = 0; i < nv && i < n_out; ++i) out[i] = vals[i];
+  for (int i = 0; i < 65 && nv + i < n_out; ++i) out[nv + i] = hist_hits[i];
+  return nv;
+}
+}
