@@ -95,19 +95,28 @@ __device__ __forceinline__ void phase2_grid_step(Phase2Grid& a, float u, float w
                                                  float g3) {
   constexpr float cx = (float)(I & 7) - 3.5f;
   float lx, ly;
-  if constexpr (I < 8) {
-    a.S0 += u; a.X0 = fmaf(u, cx, a.X0); a.XX0 = fmaf(u, cx * cx, a.XX0);
-    lx = fmaf(ncA, cx, kx0); ly = fmaf(ncB, cx, ky0);
+  // the first pixel of each row / of the group INITIALISES its accumulators (no zero-fill, no add)
+  if constexpr (I == 0) { a.S0 = u; a.X0 = u * cx; a.XX0 = u * (cx * cx); }
+  else if constexpr (I < 8) { a.S0 += u; a.X0 = fmaf(u, cx, a.X0); a.XX0 = fmaf(u, cx * cx, a.XX0); }
+  else if constexpr (I == 8) { a.S1 = u; a.X1 = u * cx; a.XX1 = u * (cx * cx); }
+  else { a.S1 += u; a.X1 = fmaf(u, cx, a.X1); a.XX1 = fmaf(u, cx * cx, a.XX1); }
+  if constexpr (I < 8) { lx = fmaf(ncA, cx, kx0); ly = fmaf(ncB, cx, ky0); }
+  else { lx = fmaf(ncA, cx, kx1); ly = fmaf(ncB, cx, ky1); }
+  if constexpr (I == 0) {
+    a.ax = fabsf(u) * fabsf(lx);
+    a.ay = fabsf(u) * fabsf(ly);
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.r) : "v"(g0), "v"(w), "n"(I));
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.g) : "v"(g1), "v"(w), "n"(I));
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.b) : "v"(g2), "v"(w), "n"(I));
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.d) : "v"(g3), "v"(w), "n"(I));
   } else {
-    a.S1 += u; a.X1 = fmaf(u, cx, a.X1); a.XX1 = fmaf(u, cx * cx, a.XX1);
-    lx = fmaf(ncA, cx, kx1); ly = fmaf(ncB, cx, ky1);
+    a.ax = fmaf(fabsf(u), fabsf(lx), a.ax);
+    a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(I));
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(I));
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(I));
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
   }
-  a.ax = fmaf(fabsf(u), fabsf(lx), a.ax);
-  a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(I));
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(I));
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(I));
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
 }
 
 // raw moments -> the sums about the mean that Phase2Acc carries (mxl = m_x - tile centre x, dy_r = m_y - y of row r)
@@ -123,6 +132,25 @@ __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, flo
   o.yy = (dy0 * dy0) * a.S0 + (dy1 * dy1) * a.S1;
   o.ax = a.ax; o.ay = a.ay; o.r = a.r; o.g = a.g; o.b = a.b; o.d = a.d;
   return o;
+}
+
+// Phase 1 of one batch (see the kernel's header comment): every lane walks its own blended entries, most significant
+// bit first; exhausted lanes step on the dummy entry B.
+template <int B, bool HAS_BG>
+__device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsigned pm, float sx, float sy, int lane) {
+  constexpr int ROW = BwdLds<B>::ROW;
+  while (__ballot(pm != 0u) != 0ull) {
+    unsigned fb;
+    asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));            // 0xffffffff for pm == 0
+    const unsigned j = min(fb ^ 31u, (unsigned)B);             // -> B (the dummy entry) for pm == 0
+    pm = __builtin_amdgcn_ubfe(pm, 0u, j);                     // clear bit j and everything above it
+    const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
+    const float2 r2 = *reinterpret_cast<const float2*>(&lds.recs[j * 3 + 2]);
+    const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
+    float u, w;
+    pixel_bwd_scalars<HAS_BG>(ps, ev, r1.z, r1.w, r2.x, r2.y, u, w);
+    lds.UW[j * ROW + lane] = make_float2(u, w);
+  }
 }
 
 template <int B>
@@ -172,6 +200,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
   }
   static_assert(B == 16, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 rows");
+  // wave-uniform (same for the whole frame): with a black background the bg term of dL/dalpha vanishes identically
+  const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
   unsigned kmax = last;
@@ -243,16 +273,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // so 1 / (1 - alpha) = 1 and w = 0 leave Tr untouched; the lazily applied "colour behind" update runs once and is
     // then a no-op because last_alpha becomes 0; its (u, w) goes to the dummy row). No exec masking, no state copies:
     // the loop body is one straight basic block.
-    while (__ballot(pm != 0u) != 0ull) {
-      const unsigned j = min(31u - (unsigned)__clz(pm), (unsigned)B);   // __clz(0) = 32 -> wraps -> B
-      pm = __builtin_amdgcn_ubfe(pm, 0u, j);                            // clear bit j and everything above it
-      const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
-      const float2 r2 = *reinterpret_cast<const float2*>(&lds.recs[j * 3 + 2]);
-      const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-      float u, w;
-      pixel_bwd_scalars(ps, ev, r1.z, r1.w, r2.x, r2.y, u, w);
-      lds.UW[j * ROW + lane] = make_float2(u, w);
-    }
+    if (has_bg) phase1_walk<B, true>(lds, ps, pm, sx, sy, lane);
+    else phase1_walk<B, false>(lds, ps, pm, sx, sy, lane);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
@@ -274,17 +296,19 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         const float kx0 = fmaf(cA, mxl, cB * dy0), kx1 = fmaf(cA, mxl, cB * dy1);
         const float ky0 = fmaf(cC, dy0, cB * mxl), ky1 = fmaf(cC, dy1, cB * mxl);
         const float ncA = -cA, ncB = -cB;
-        Phase2Grid pg = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define SFGS_P2(I) phase2_grid_step<I>(pg, UWrow[I].x, UWrow[I].y, ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
-#pragma nounroll
-        for (int c = 0; c < 4; ++c) {
-          switch (c) {
-            case 0: SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); break;
-            case 1: SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7); break;
-            case 2: SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); break;
-            default: SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15); break;
-          }
-        }
+        Phase2Grid pg;
+        // straight line, four pixels per LDS round trip (the asm fences keep the compiler from hoisting all sixteen
+        // 8-byte loads above the arithmetic, which would cost ~30 VGPRs and the fourth wave per SIMD)
+#define SFGS_P2(I) phase2_grid_step<I>(pg, uw##I.x, uw##I.y, ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
+#define SFGS_P2x4(A, Bq, C, D)                                                                  \
+  { const float2 uw##A = UWrow[A], uw##Bq = UWrow[Bq], uw##C = UWrow[C], uw##D = UWrow[D];       \
+    SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D); }                                           \
+  asm volatile("" ::: "memory");
+        SFGS_P2x4(0, 1, 2, 3)
+        SFGS_P2x4(4, 5, 6, 7)
+        SFGS_P2x4(8, 9, 10, 11)
+        SFGS_P2x4(12, 13, 14, 15)
+#undef SFGS_P2x4
 #undef SFGS_P2
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
       } else {
