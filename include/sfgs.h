@@ -220,15 +220,18 @@ int sfgs_knn_dist2(const float* xyz, int32_t N, float* out, void* scratch, size_
  *   scales    = sqrt(exp(scaling_raw)^2 + filter3d^2)        GaussianModel.get_scaling_with_3D_filter  scene/gaussian_model.py:207-213
  *   opacities = sigmoid(opacity_raw) * sqrt(prod s^2 / prod (s^2 + filter3d^2))  get_opacity_with_3D_filter  :237-249
  *   rotations = normalize(rotation_raw)                       get_rotation                               :216-217
- * filter3d is [N,1] float64 (training) or float32 (after load_ply): filter_is_f64 says which. Outputs float32.
+ * filter3d is [N,1] float64 (training) or float32 (after load_ply); opacity_raw is float32 until the reference's first
+ * reset_opacity (scene/gaussian_model.py:483-501), float64 afterwards (the reset divides by a float64 coefficient).
+ * f64_mask: bit 0 = filter3d is float64, bit 1 = opacity_raw (and, in the backward, g_opacity_raw) is float64; torch's
+ * type promotion is followed in every combination. Outputs float32.
  * backward: gradients w.r.t. the three raw tensors given gradients of the three outputs (each may be NULL = 0). */
-int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const float* opacity_raw,
-                         const float* rotation_raw, const void* filter3d, int32_t filter_is_f64,
+int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const void* opacity_raw,
+                         const float* rotation_raw, const void* filter3d, int32_t f64_mask,
                          float* scales, float* opacities, float* rotations, void* stream);
-int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const float* opacity_raw,
-                          const float* rotation_raw, const void* filter3d, int32_t filter_is_f64,
+int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const void* opacity_raw,
+                          const float* rotation_raw, const void* filter3d, int32_t f64_mask,
                           const float* g_scales, const float* g_opacities, const float* g_rotations,
-                          float* g_scaling_raw, float* g_opacity_raw, float* g_rotation_raw, void* stream);
+                          float* g_scaling_raw, void* g_opacity_raw, float* g_rotation_raw, void* stream);
 
 /* GaussianModel.compute_3D_filter (scene/gaussian_model.py:255-308): filter_out[N] (float64) =
  * (smallest camera-space depth at which any camera sees the point with a 15 % screen margin) / max_focal *
@@ -252,22 +255,25 @@ int sfgs_densify_stats(int32_t N, const float* viewspace_grad, const unsigned ch
  *   g' = grad + weight_decay*param (if weight_decay != 0);  m += (1-b1)*(g'-m);  v = v*b2 + (1-b2)*g'*g';
  *   param += neg_step_size * (m / (sqrt(v)/bias_correction2_sqrt + eps))
  * The host computes, in double like torch does, neg_step_size = -lr/(1-b1^t) and bias_correction2_sqrt =
- * sqrt(1-b2^t) for the tensor's own step count t (already incremented), then rounds to float. `tensors` is a HOST
- * array; all pointers are device pointers to contiguous float32 storage of `count` elements, updated in place. */
+ * sqrt(1-b2^t) for the tensor's own step count t (already incremented). `tensors` is a HOST array; all pointers are
+ * device pointers to contiguous float32 (or, with SFGS_ADAM_F64, float64) storage of `count` elements, updated in place. */
+#define SFGS_ADAM_F64 1u   /* flags: param, grad and both moments are float64 (the reference's `_opacity` group after
+                              reset_opacity, scene/gaussian_model.py:483-501); the update then runs in float64 like torch's */
 typedef struct SfgsAdamTensor {
-  float* param;
-  const float* grad;
-  float* exp_avg;
-  float* exp_avg_sq;
+  void* param;
+  const void* grad;
+  void* exp_avg;
+  void* exp_avg_sq;
   int64_t count;
-  float neg_step_size;
-  float one_minus_beta1;
-  float beta2;
-  float one_minus_beta2;
-  float bias_correction2_sqrt;
-  float eps;
-  float weight_decay;
-  float reserved;
+  double neg_step_size;           /* the scalars as torch forms them (Python floats = double); the float32 path */
+  double one_minus_beta1;         /* rounds them to float, the float64 path uses them as they are             */
+  double beta2;
+  double one_minus_beta2;
+  double bias_correction2_sqrt;
+  double eps;
+  double weight_decay;
+  uint32_t flags;                 /* SFGS_ADAM_* */
+  uint32_t reserved;
 } SfgsAdamTensor;
 int sfgs_adam_step(const SfgsAdamTensor* tensors, int32_t count, void* stream);
 

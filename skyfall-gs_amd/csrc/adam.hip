@@ -26,14 +26,21 @@ struct AdamTable {
   int count;
 };
 
-struct AdamScalars { float wd, w1, b2, w2, bc2s, eps, step; };
+template <typename T>
+struct AdamScalars { T wd, w1, b2, w2, bc2s, eps, step; };
 
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamScalars& s) {
-  if (s.wd != 0.0f) g = g + s.wd * p;
+template <typename T>
+__device__ __forceinline__ T sqrt_of(T v);
+template <> __device__ __forceinline__ float sqrt_of<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double sqrt_of<double>(double v) { return sqrt(v); }
+
+template <typename T>
+__device__ __forceinline__ void adam_update(T& p, T g, T& m, T& v, const AdamScalars<T>& s) {
+  if (s.wd != (T)0) g = g + s.wd * p;
   m = m + s.w1 * (g - m);
   v = v * s.b2;
   v = v + s.w2 * (g * g);
-  const float d = sqrtf(v) / s.bc2s + s.eps;
+  const T d = sqrt_of<T>(v) / s.bc2s + s.eps;
   p = p + s.step * (m / d);
 }
 
@@ -46,12 +53,28 @@ adam_kernel(const AdamTable tab) {
   const unsigned first = ti ? tab.block_end[ti - 1] : 0u;
   const int64_t base = (int64_t)(blockIdx.x - first) * ADAM_CHUNK;
   const int64_t n = T.count;
-  const AdamScalars s{T.weight_decay, T.one_minus_beta1, T.beta2, T.one_minus_beta2, T.bias_correction2_sqrt, T.eps,
-                      T.neg_step_size};
-  float* __restrict__ P = T.param;
-  const float* __restrict__ G = T.grad;
-  float* __restrict__ M = T.exp_avg;
-  float* __restrict__ V = T.exp_avg_sq;
+  if (T.flags & SFGS_ADAM_F64) {
+    // float64 tensors (the reference's `_opacity` after reset_opacity): torch runs the same sequence in float64
+    const AdamScalars<double> s{T.weight_decay, T.one_minus_beta1, T.beta2, T.one_minus_beta2, T.bias_correction2_sqrt,
+                                T.eps, T.neg_step_size};
+    double* __restrict__ P = (double*)T.param;
+    const double* __restrict__ G = (const double*)T.grad;
+    double* __restrict__ M = (double*)T.exp_avg;
+    double* __restrict__ V = (double*)T.exp_avg_sq;
+    for (int64_t e = base + threadIdx.x; e < n && e < base + ADAM_CHUNK; e += ADAM_BLOCK) {
+      double p = P[e], m = M[e], v = V[e];
+      adam_update<double>(p, G[e], m, v, s);
+      P[e] = p; M[e] = m; V[e] = v;
+    }
+    return;
+  }
+  // the host formed the scalars in double like torch does; the float32 path rounds them to float as torch's kernels do
+  const AdamScalars<float> s{(float)T.weight_decay, (float)T.one_minus_beta1, (float)T.beta2, (float)T.one_minus_beta2,
+                             (float)T.bias_correction2_sqrt, (float)T.eps, (float)T.neg_step_size};
+  float* __restrict__ P = (float*)T.param;
+  const float* __restrict__ G = (const float*)T.grad;
+  float* __restrict__ M = (float*)T.exp_avg;
+  float* __restrict__ V = (float*)T.exp_avg_sq;
 
   if (tab.vec_ok[ti] && base + ADAM_CHUNK <= n) {
     float4 p[ADAM_VEC_PER_THREAD], g[ADAM_VEC_PER_THREAD], m[ADAM_VEC_PER_THREAD], v[ADAM_VEC_PER_THREAD];
@@ -65,10 +88,10 @@ adam_kernel(const AdamTable tab) {
     }
 #pragma unroll
     for (int k = 0; k < ADAM_VEC_PER_THREAD; ++k) {
-      adam_update(p[k].x, g[k].x, m[k].x, v[k].x, s);
-      adam_update(p[k].y, g[k].y, m[k].y, v[k].y, s);
-      adam_update(p[k].z, g[k].z, m[k].z, v[k].z, s);
-      adam_update(p[k].w, g[k].w, m[k].w, v[k].w, s);
+      adam_update<float>(p[k].x, g[k].x, m[k].x, v[k].x, s);
+      adam_update<float>(p[k].y, g[k].y, m[k].y, v[k].y, s);
+      adam_update<float>(p[k].z, g[k].z, m[k].z, v[k].z, s);
+      adam_update<float>(p[k].w, g[k].w, m[k].w, v[k].w, s);
       const int64_t e = base + ((int64_t)k * ADAM_BLOCK + threadIdx.x) * 4;
       *reinterpret_cast<float4*>(P + e) = p[k];
       *reinterpret_cast<float4*>(M + e) = m[k];
@@ -79,7 +102,7 @@ adam_kernel(const AdamTable tab) {
   // ragged tail / unaligned tensors
   for (int64_t e = base + threadIdx.x; e < n && e < base + ADAM_CHUNK; e += ADAM_BLOCK) {
     float p = P[e], m = M[e], v = V[e];
-    adam_update(p, G[e], m, v, s);
+    adam_update<float>(p, G[e], m, v, s);
     P[e] = p; M[e] = m; V[e] = v;
   }
 }

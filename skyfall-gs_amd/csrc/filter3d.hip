@@ -66,7 +66,11 @@ filter3d_finish_kernel(int N, const double* __restrict__ dist, const double* __r
                        double* __restrict__ out) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
-  const double d = dist[g] < 0.0 ? max_seen[0] : dist[g];
+  // No camera sees ANY point: the reference raises here (`distance[valid_points].max()` of an empty tensor,
+  // scene/gaussian_model.py:299); an asynchronous kernel cannot, so such points keep the reference's initial
+  // distance of 1e8 (:260) instead of a negative filter size.
+  const double far = max_seen[0] < 0.0 ? 1e8 : max_seen[0];
+  const double d = dist[g] < 0.0 ? far : dist[g];
   out[g] = d / focal * 0.4472135954999579;  // 0.2 ** 0.5 as Python evaluates it
 }
 

@@ -22,9 +22,13 @@ namespace sfgs {
 //   t_i   = sq_i + square(filter)                 FT
 //   det2  = prod_i t_i                            FT
 //   coef  = sqrt(det1 / det2)                     FT
-template <typename FT>
+// OT = dtype of the raw opacity parameter: float32, or float64 after the reference's reset_opacity
+// (scene/gaussian_model.py:483-501 divides by a float64 coefficient, so from the first opacity reset on -- iteration
+// 3000 of the default schedule -- `_opacity` and its Adam moments are float64 tensors and sigmoid runs in float64).
+template <typename FT, typename OT>
 struct PrepassTerms {
-  float sq[3], o, det1;
+  float sq[3], det1;
+  OT o;
   FT f2, t[3], det2, coef;
 };
 
@@ -33,11 +37,11 @@ __device__ __forceinline__ FT sqrt_t(FT v);
 template <> __device__ __forceinline__ float sqrt_t<float>(float v) { return sqrtf(v); }
 template <> __device__ __forceinline__ double sqrt_t<double>(double v) { return sqrt(v); }
 
-template <typename FT>
-__device__ __forceinline__ PrepassTerms<FT> prepass_terms(const float* __restrict__ scaling_raw,
-                                                          const float* __restrict__ opacity_raw,
-                                                          const FT* __restrict__ filter3d, int g) {
-  PrepassTerms<FT> p;
+template <typename FT, typename OT>
+__device__ __forceinline__ PrepassTerms<FT, OT> prepass_terms(const float* __restrict__ scaling_raw,
+                                                              const OT* __restrict__ opacity_raw,
+                                                              const FT* __restrict__ filter3d, int g) {
+  PrepassTerms<FT, OT> p;
   const FT f = filter3d[g];
   p.f2 = f * f;
 #pragma unroll
@@ -49,39 +53,41 @@ __device__ __forceinline__ PrepassTerms<FT> prepass_terms(const float* __restric
   p.det1 = (p.sq[0] * p.sq[1]) * p.sq[2];
   p.det2 = (p.t[0] * p.t[1]) * p.t[2];
   p.coef = sqrt_t<FT>((FT)p.det1 / p.det2);
-  p.o = 1.0f / (1.0f + expf(-opacity_raw[g]));
+  if constexpr (sizeof(OT) == 8) p.o = 1.0 / (1.0 + exp(-opacity_raw[g]));
+  else p.o = 1.0f / (1.0f + expf(-opacity_raw[g]));
   return p;
 }
 
-template <typename FT>
+template <typename FT, typename OT>
 __global__ void __launch_bounds__(256)
-prepass_fwd_kernel(int N, const float* __restrict__ scaling_raw, const float* __restrict__ opacity_raw,
+prepass_fwd_kernel(int N, const float* __restrict__ scaling_raw, const OT* __restrict__ opacity_raw,
                    const float* __restrict__ rotation_raw, const FT* __restrict__ filter3d,
                    float* __restrict__ scales, float* __restrict__ opacities, float* __restrict__ rotations) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
-  const PrepassTerms<FT> p = prepass_terms<FT>(scaling_raw, opacity_raw, filter3d, g);
+  const PrepassTerms<FT, OT> p = prepass_terms<FT, OT>(scaling_raw, opacity_raw, filter3d, g);
 #pragma unroll
   for (int i = 0; i < 3; ++i) scales[3 * (size_t)g + i] = (float)sqrt_t<FT>(p.t[i]);
-  opacities[g] = (float)((FT)p.o * p.coef);
+  if constexpr (sizeof(OT) == 8) opacities[g] = (float)(p.o * (double)p.coef);   // torch promotes to float64
+  else opacities[g] = (float)((FT)p.o * p.coef);
   const float4 q = *reinterpret_cast<const float4*>(rotation_raw + 4 * (size_t)g);
   const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
   *reinterpret_cast<float4*>(rotations + 4 * (size_t)g) = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
 }
 
-template <typename FT>
+template <typename FT, typename OT>
 __global__ void __launch_bounds__(256)
-prepass_bwd_kernel(int N, const float* __restrict__ scaling_raw, const float* __restrict__ opacity_raw,
+prepass_bwd_kernel(int N, const float* __restrict__ scaling_raw, const OT* __restrict__ opacity_raw,
                    const float* __restrict__ rotation_raw, const FT* __restrict__ filter3d,
                    const float* __restrict__ g_scales, const float* __restrict__ g_opacities,
                    const float* __restrict__ g_rotations, float* __restrict__ g_scaling_raw,
-                   float* __restrict__ g_opacity_raw, float* __restrict__ g_rotation_raw) {
+                   OT* __restrict__ g_opacity_raw, float* __restrict__ g_rotation_raw) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
-  const PrepassTerms<FT> p = prepass_terms<FT>(scaling_raw, opacity_raw, filter3d, g);
+  const PrepassTerms<FT, OT> p = prepass_terms<FT, OT>(scaling_raw, opacity_raw, filter3d, g);
   const double coef = (double)p.coef, o = (double)p.o;
   const double go = g_opacities ? (double)g_opacities[g] : 0.0;
-  g_opacity_raw[g] = (float)(go * coef * o * (1.0 - o));
+  g_opacity_raw[g] = (OT)(go * coef * o * (1.0 - o));
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     // d scales_i / d raw_i = s_i^2 / sqrt(s_i^2 + f^2) ; d (o coef) / d raw_i = o coef f^2 / (s_i^2 + f^2)
@@ -110,45 +116,57 @@ prepass_bwd_kernel(int N, const float* __restrict__ scaling_raw, const float* __
 
 using namespace sfgs;
 
-extern "C" int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const float* opacity_raw,
-                                    const float* rotation_raw, const void* filter3d, int32_t filter_is_f64,
+// dispatch on (filter dtype, raw opacity dtype)
+#define SFGS_PREPASS_DISPATCH(MASK, LAUNCH)                                      \
+  do {                                                                           \
+    switch ((MASK) & 3) {                                                        \
+      case 0: LAUNCH(float, float); break;                                       \
+      case 1: LAUNCH(double, float); break;                                      \
+      case 2: LAUNCH(float, double); break;                                      \
+      default: LAUNCH(double, double); break;                                    \
+    }                                                                            \
+  } while (0)
+
+extern "C" int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const void* opacity_raw,
+                                    const float* rotation_raw, const void* filter3d, int32_t f64_mask,
                                     float* scales, float* opacities, float* rotations, void* stream_) {
   SFGS_REQUIRE(N >= 0, SFGS_E_ARG, "negative Gaussian count");
   if (N == 0) return SFGS_OK;
   SFGS_REQUIRE(scaling_raw && opacity_raw && rotation_raw && filter3d && scales && opacities && rotations, SFGS_E_ARG,
                "NULL argument");
+  SFGS_REQUIRE((f64_mask & ~3) == 0, SFGS_E_ARG, "f64_mask: bit 0 = filter3d is float64, bit 1 = opacity_raw is float64");
   hipStream_t stream = (hipStream_t)stream_;
   const dim3 grid((N + 255) / 256), block(256);
   { ProfScope ps_(KID_PREPASS_FWD, stream);
-    if (filter_is_f64)
-      hipLaunchKernelGGL(prepass_fwd_kernel<double>, grid, block, 0, stream, N, scaling_raw, opacity_raw, rotation_raw,
-                         (const double*)filter3d, scales, opacities, rotations);
-    else
-      hipLaunchKernelGGL(prepass_fwd_kernel<float>, grid, block, 0, stream, N, scaling_raw, opacity_raw, rotation_raw,
-                         (const float*)filter3d, scales, opacities, rotations); }
+#define SFGS_LAUNCH_PF(FT, OT)                                                                                      \
+  hipLaunchKernelGGL((prepass_fwd_kernel<FT, OT>), grid, block, 0, stream, N, scaling_raw, (const OT*)opacity_raw, \
+                     rotation_raw, (const FT*)filter3d, scales, opacities, rotations)
+    SFGS_PREPASS_DISPATCH(f64_mask, SFGS_LAUNCH_PF);
+#undef SFGS_LAUNCH_PF
+  }
   SFGS_POST_LAUNCH("prepass_fwd", stream, 0);
   return SFGS_OK;
 }
 
-extern "C" int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const float* opacity_raw,
-                                     const float* rotation_raw, const void* filter3d, int32_t filter_is_f64,
+extern "C" int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const void* opacity_raw,
+                                     const float* rotation_raw, const void* filter3d, int32_t f64_mask,
                                      const float* g_scales, const float* g_opacities, const float* g_rotations,
-                                     float* g_scaling_raw, float* g_opacity_raw, float* g_rotation_raw, void* stream_) {
+                                     float* g_scaling_raw, void* g_opacity_raw, float* g_rotation_raw, void* stream_) {
   SFGS_REQUIRE(N >= 0, SFGS_E_ARG, "negative Gaussian count");
   if (N == 0) return SFGS_OK;
   SFGS_REQUIRE(scaling_raw && opacity_raw && rotation_raw && filter3d && g_scaling_raw && g_opacity_raw && g_rotation_raw,
                SFGS_E_ARG, "NULL argument");
+  SFGS_REQUIRE((f64_mask & ~3) == 0, SFGS_E_ARG, "f64_mask: bit 0 = filter3d is float64, bit 1 = opacity_raw is float64");
   hipStream_t stream = (hipStream_t)stream_;
   const dim3 grid((N + 255) / 256), block(256);
   { ProfScope ps_(KID_PREPASS_BWD, stream);
-    if (filter_is_f64)
-      hipLaunchKernelGGL(prepass_bwd_kernel<double>, grid, block, 0, stream, N, scaling_raw, opacity_raw, rotation_raw,
-                         (const double*)filter3d, g_scales, g_opacities, g_rotations, g_scaling_raw, g_opacity_raw,
-                         g_rotation_raw);
-    else
-      hipLaunchKernelGGL(prepass_bwd_kernel<float>, grid, block, 0, stream, N, scaling_raw, opacity_raw, rotation_raw,
-                         (const float*)filter3d, g_scales, g_opacities, g_rotations, g_scaling_raw, g_opacity_raw,
-                         g_rotation_raw); }
+#define SFGS_LAUNCH_PB(FT, OT)                                                                                      \
+  hipLaunchKernelGGL((prepass_bwd_kernel<FT, OT>), grid, block, 0, stream, N, scaling_raw, (const OT*)opacity_raw, \
+                     rotation_raw, (const FT*)filter3d, g_scales, g_opacities, g_rotations, g_scaling_raw,         \
+                     (OT*)g_opacity_raw, g_rotation_raw)
+    SFGS_PREPASS_DISPATCH(f64_mask, SFGS_LAUNCH_PB);
+#undef SFGS_LAUNCH_PB
+  }
   SFGS_POST_LAUNCH("prepass_bwd", stream, 0);
   return SFGS_OK;
 }

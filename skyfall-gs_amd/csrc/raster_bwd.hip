@@ -139,17 +139,27 @@ __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, flo
 template <int B, bool HAS_BG>
 __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsigned pm, float sx, float sy, int lane) {
   constexpr int ROW = BwdLds<B>::ROW;
+  // two entries per iteration: their record reads, exponentials and reciprocals are independent and overlap; only the
+  // short transmittance / "colour behind" recurrences chain them
   while (__ballot(pm != 0u) != 0ull) {
     unsigned fb;
     asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));            // 0xffffffff for pm == 0
-    const unsigned j = min(fb ^ 31u, (unsigned)B);             // -> B (the dummy entry) for pm == 0
-    pm = __builtin_amdgcn_ubfe(pm, 0u, j);                     // clear bit j and everything above it
-    const float4 r0 = lds.recs[j * 3], r1 = lds.recs[j * 3 + 1];
-    const float2 r2 = *reinterpret_cast<const float2*>(&lds.recs[j * 3 + 2]);
-    const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-    float u, w;
-    pixel_bwd_scalars<HAS_BG>(ps, ev, r1.z, r1.w, r2.x, r2.y, u, w);
-    lds.UW[j * ROW + lane] = make_float2(u, w);
+    const unsigned j1 = min(fb ^ 31u, (unsigned)B);            // -> B (the dummy entry) for pm == 0
+    pm = __builtin_amdgcn_ubfe(pm, 0u, j1);                    // clear bit j1 and everything above it
+    asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));
+    const unsigned j2 = min(fb ^ 31u, (unsigned)B);
+    pm = __builtin_amdgcn_ubfe(pm, 0u, j2);
+    const float4 a0 = lds.recs[j1 * 3], a1 = lds.recs[j1 * 3 + 1];
+    const float2 a2 = *reinterpret_cast<const float2*>(&lds.recs[j1 * 3 + 2]);
+    const float4 b0 = lds.recs[j2 * 3], b1 = lds.recs[j2 * 3 + 1];
+    const float2 b2 = *reinterpret_cast<const float2*>(&lds.recs[j2 * 3 + 2]);
+    const SplatEval e1 = eval_splat(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, sx, sy);
+    const SplatEval e2 = eval_splat(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, sx, sy);
+    float u1, w1, u2, w2;
+    pixel_bwd_scalars<HAS_BG>(ps, e1, a1.z, a1.w, a2.x, a2.y, u1, w1);
+    pixel_bwd_scalars<HAS_BG>(ps, e2, b1.z, b1.w, b2.x, b2.y, u2, w2);
+    lds.UW[j1 * ROW + lane] = make_float2(u1, w1);
+    lds.UW[j2 * ROW + lane] = make_float2(u2, w2);
   }
 }
 

@@ -156,8 +156,13 @@ class _Rasterize(torch.autograd.Function):
             cap = max(hint[0], slots(4 * N))
             ccap = max(hint[1], 8 * N // ncb, 256)
             need_bwd = any(ctx.needs_input_grad[:7])
+            if need_bwd and getattr(settings, "tile_rows", None):
+                raise ValueError("tile_rows (band rendering) is a forward-only extension: the backward needs the whole "
+                                 "frame's per-pixel state")
             # few, large allocations: the Python time before the first launch is GPU idle time
-            outs = torch.empty(5, H, W, dtype=torch.float32, device=dev)
+            # band rendering (tile_rows extension) leaves the pixels outside the band untouched: start from zeros there
+            outs = (torch.zeros if getattr(settings, "tile_rows", None) else torch.empty)(
+                5, H, W, dtype=torch.float32, device=dev)
             color, depth, alpha = outs[0:3], outs[3:4], outs[4:5]
             radii = torch.empty(N, dtype=torch.int32, device=dev)
             al = lambda n: (n + 255) // 256 * 256

@@ -42,10 +42,12 @@ class SfgsRasterSizes(C.Structure):
 
 class SfgsAdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("count", C.c_int64), ("neg_step_size", C.c_float), ("one_minus_beta1", C.c_float),
-                ("beta2", C.c_float), ("one_minus_beta2", C.c_float), ("bias_correction2_sqrt", C.c_float),
-                ("eps", C.c_float), ("weight_decay", C.c_float), ("reserved", C.c_float)]
+                ("count", C.c_int64), ("neg_step_size", C.c_double), ("one_minus_beta1", C.c_double),
+                ("beta2", C.c_double), ("one_minus_beta2", C.c_double), ("bias_correction2_sqrt", C.c_double),
+                ("eps", C.c_double), ("weight_decay", C.c_double), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
+
+ADAM_F64 = 1
 
 class SfgsCompactTensor(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]

@@ -19,7 +19,7 @@ __all__ = ["FusedAdam", "install", "uninstall"]
 
 
 class FusedAdam(torch.optim.Adam):
-    """Drop-in for `torch.optim.Adam(params, lr, betas, eps, weight_decay)` on float32 GPU parameters."""
+    """Drop-in for `torch.optim.Adam(params, lr, betas, eps, weight_decay)` on float32 / float64 GPU parameters."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         if isinstance(lr, torch.Tensor):
@@ -62,10 +62,11 @@ class FusedAdam(torch.optim.Adam):
                     continue  # torch.optim.Adam skips parameters without a gradient (no step increment either)
                 if g.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise ValueError("FusedAdam: parameters must be contiguous float32 GPU tensors "
+                # float64: the reference's `_opacity` group from its first reset_opacity on (scene/gaussian_model.py:483-501)
+                if not p.is_cuda or p.dtype not in (torch.float32, torch.float64) or not p.is_contiguous():
+                    raise ValueError("FusedAdam: parameters must be contiguous float32 / float64 GPU tensors "
                                      f"(got {p.dtype}, {p.device}, contiguous={p.is_contiguous()})")
-                if g.dtype != torch.float32 or g.device != p.device or g.shape != p.shape:
+                if g.dtype != p.dtype or g.device != p.device or g.shape != p.shape:
                     raise ValueError("FusedAdam: gradient dtype/device/shape must match its parameter")
                 st = self.state[p]
                 if len(st) == 0:  # same lazy state as torch/optim/adam.py::_init_group
@@ -74,7 +75,7 @@ class FusedAdam(torch.optim.Adam):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 for name, t in (("exp_avg", m), ("exp_avg_sq", v)):
-                    if t.dtype != torch.float32 or t.device != p.device or t.shape != p.shape:
+                    if t.dtype != p.dtype or t.device != p.device or t.shape != p.shape:
                         raise ValueError(f"FusedAdam: state '{name}' does not match its parameter "
                                          f"({tuple(t.shape)} {t.dtype} {t.device} vs {tuple(p.shape)})")
                     if not t.is_contiguous():
@@ -91,7 +92,8 @@ class FusedAdam(torch.optim.Adam):
                 bc1 = 1 - beta1 ** t_step
                 bc2 = 1 - beta2 ** t_step
                 rec = L.SfgsAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
-                                       (lr / bc1) * -1, 1 - beta1, beta2, 1 - beta2, bc2 ** 0.5, eps, wd, 0.0)
+                                       (lr / bc1) * -1, 1 - beta1, beta2, 1 - beta2, bc2 ** 0.5, eps, wd,
+                                       L.ADAM_F64 if p.dtype == torch.float64 else 0, 0)
                 per_device.setdefault(p.device, ([], [], []))
                 per_device[p.device][0].append(rec)
                 per_device[p.device][1].append(g)  # keep contiguous copies alive until the launch is enqueued

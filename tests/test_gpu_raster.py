@@ -255,7 +255,13 @@ def test_random_configurations(i):
     # only contributor, NaN <-> number in the normalised depth); its own gradient then differs at the 1/255 level
     reps = [parity.assert_image_close(name, out[name], getattr(R, name), rtol=rtol, borderline_min=4)
             for name in ("color", "alpha", "depth")]
-    flipped = any(r["bad"] for r in reps)
+    # an explicit FLIP signal only: the NaN pattern of the normalised depth changed, or a few pixels moved by
+    # the 1/255 blending quantum of one borderline splat (more than the tolerance, less than 5e-2, on at most
+    # borderline_min pixels). Any other out-of-tolerance pixel already failed assert_image_close above and never
+    # loosens the gradient bars.
+    nan_flip = int((np.isnan(out["depth"]) != np.isnan(R.depth)).sum()) > 0
+    flipped = nan_flip or any(0 < r["bad"] <= 4 and r["max_rel"] > rtol for r in reps)
+    print("borderline pixels:", {r["name"]: r["bad"] for r in reps}, "nan flip:", nan_flip)
     scale = rtol / parity.RGB_DEPTH_RTOL
     few = 2.0 if c["n"] < 64 else 1.0   # a handful of Gaussians: no averaging over the float32 chain of Sigma -> q
     # the flipped splat's own gradient moves by ~10 % of its value: L2 barely notices, the max norm does
