@@ -11,8 +11,8 @@ appearance-MLP gradient bucket (24 966 floats). Weak scaling: value = sum of Gau
 
 Prints ONE JSON line (rank 0). `roofline` describes the dominant kernel (HIP events recorded by the
 library on its launch stream during the timed region); `roofline_step` the whole step with SURVEY 8d's
-algorithmic byte count. `cpu_baseline` times the CPU oracle (a port: the reference has no CPU path) on a
-bounded sample. Only that leg touches oracle/.
+algorithmic byte count. `cpu_baseline` times the PyTorch CPU restatement of the render path (the
+reference has no CPU path) on a bounded sample, next to the C/OpenMP oracle. Only that leg touches oracle/.
 """
 import argparse
 import json
@@ -53,24 +53,49 @@ def main():
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="Gaussians in the CPU-baseline sample (-1 = the whole workload, ~10-30 s; 0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="0 = skip the CPU-baseline leg; otherwise it runs on the workload's own N (a bounded tile sample, ~30-60 s)")
     ap.add_argument("--forward-only", action="store_true", help="report render FPS instead of train-step Gaussians/s")
     ap.add_argument("--d2h-async", action="store_true", help="with --forward-only: download every frame through sfgs.video.FrameDownloader (pinned ring, side stream; informational)")
     ap.add_argument("--d2h-copy", action="store_true", help="with --forward-only: copy every frame to the host like render_video.py:181 (informational; never the headline value)")
     ap.add_argument("--sh-degree", type=int, default=-1, help=">= 0: colour path B (in-kernel SH of this degree) instead of colors_precomp")
+    ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-only", action="store_true", help="run only the CPU-baseline legs and print them")
     args = ap.parse_args()
+    if args.cpu_leg:
+        return cpu_leg(args.cpu_leg, args.n, args.width, args.height)
+    if args.cpu_only:
+        print(json.dumps(run_cpu_baseline(args.n, args.width, args.height)))
+        return
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+        # (the driver's own multi-GPU invocation already comes through torchrun and skips this)
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+                                   str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # SFGS_BENCH_BACKEND=gloo: test hook that exercises the multi-rank control flow (spawn, barriers, per-rank gather,
+    # JSON) on a box with fewer GPUs than ranks -- ranks then share GPUs and the collectives run on host tensors.
+    backend = os.environ.get("SFGS_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    local_dev = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from sfgs import _lib as L
     from sfgs.synth import scene, upstream_grads
@@ -90,7 +115,7 @@ def main():
     t = {k: (v.to(dev).requires_grad_(not args.forward_only) if v is not None else None) for k, v in g.items()}
     means2D = torch.zeros(N, 3, device=dev, requires_grad=not args.forward_only)
     gc, gd = gc.to(dev), gd.to(dev)
-    shared_grad = torch.zeros(APPEARANCE_MLP_FLOATS, device=dev)
+    shared_grad = torch.zeros(APPEARANCE_MLP_FLOATS, device=coll_dev)
 
     downloader = None
     if args.d2h_async:
@@ -115,7 +140,16 @@ def main():
                                         scales=t["scales"], rotations=t["rotations"])
         torch.autograd.backward([color, depth], [gc, gd])
         if dist is not None:
-            dist.all_reduce(shared_grad)
+            if ar_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(shared_grad)
+                e1.record()
+                ar_events.append((e0, e1))
+            else:
+                dist.all_reduce(shared_grad)
+
+    ar_events = None   # (start, end) events around the all-reduce, filled during the profiled warm-up steps only
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -138,9 +172,22 @@ def main():
         if i == args.warmup - n_prof:
             fence()
             L.profile_enable(True)
+            ar_events = [] if dist is not None else None
         step()
     fence()
+    allreduce_ms = None
+    if ar_events:
+        allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+    ar_events = None
+    # every bracketed launch carries the cost of its own event pair: measure it (empty pairs on the same stream) and take
+    # it out of the per-kernel figures, so that they add up to no more than the step
+    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    for a_, b_ in cal:
+        a_.record(); b_.record()
+    torch.cuda.synchronize(dev)
+    event_pair_ms = sorted(a_.elapsed_time(b_) for a_, b_ in cal)[len(cal) // 2]
     warm_prof = L.profile_collect() if args.warmup else {}
+    warm_prof = {k: (max(ms - event_pair_ms * n, 0.0), n) for k, (ms, n) in warm_prof.items()}
     L.profile_enable(True)
 
     def group(prof, nsteps):
@@ -161,13 +208,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = L.profile_collect()
+    prof = {k: (max(ms - event_pair_ms * n, 0.0), n) for k, (ms, n) in prof.items()}
     L.profile_enable(False)
     L.profile_select(None)
 
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allr = [torch.zeros(1, device=coll_dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, torch.tensor([elapsed], device=coll_dev, dtype=torch.float64))
+        per_rank_ms = [float(t_.item()) / args.steps * 1e3 for t_ in allr]
+        elapsed = max(float(t_.item()) for t_ in allr)
 
     cnt = last_counters()
     Nvis, D_ref, D_eff, P = cnt["num_visible"], cnt["num_duplicates_ref"], cnt["num_duplicates"], W * H
@@ -213,12 +263,13 @@ def main():
     roofline_step = {"bound": "hbm", "achieved": round(step_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(step_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(B_step),
                      "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(per_kernel.items())},
-                     "kernel_ms_source": "dominant kernel: timed region; others: warm-up steps",
+                     "kernel_ms_source": "HIP events on the launch stream minus the measured cost of an empty event pair "
+                                         f"({event_pair_ms * 1e3:.1f} us); dominant kernel: timed region; others: warm-up steps",
                      "gpu_busy_ms_per_step": round(sum(v["ms_per_step"] for v in per_kernel.values()), 4)}
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only:
-        cpu_baseline = run_cpu_baseline(N if args.cpu_sample < 0 else args.cpu_sample, W, H)
+        cpu_baseline = run_cpu_baseline(N, W, H)
 
     if rank == 0:
         out = {
@@ -229,8 +280,11 @@ def main():
                                    f"{'colors_precomp' if sh < 0 else 'SH degree %d in-kernel' % sh}, "
                                    f"kernel_size=0.1, seed=rank, one scene per GPU",
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
-                       "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}"},
+                       "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
+                       "collective_backend": backend if world > 1 else None},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
+            "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+            "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
         }
         print(json.dumps(out))
     if dist is not None:
@@ -255,15 +309,45 @@ def load_traffic(N, W, H, forward_only):
 
 
 def run_cpu_baseline(n, W, H):
-    """The reference has no CPU render path; this times OUR C/OpenMP restatement (oracle/) of the same
-    forward + backward on a bounded sample of the same workload."""
-    try:
+    """the reference has no CPU render path (gaussian_renderer/__init__.py:27,38 hard-code "cuda"), so "the
+    reference's PyTorch CPU render path" is our PyTorch restatement of the same algorithm (oracle/tiled_torch.py, autograd
+    backward), timed with torch.set_num_threads(all host cores): `value` is for THIS workload, from a bounded sample of
+    its tiles with the extrapolation stated; cfg 1 (BASELINE.json configs[0]) runs in full. The C/OpenMP oracle's time
+    (ours too, a "port") is reported alongside. Reported baselines, not targets. Every leg runs in its own process with a
+    time limit, so a slow host can never take the bench line down."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    threads = int(os.environ.get("SFGS_CPU_THREADS", cores))
+    out = {"value": None, "unit": "Gaussians/s", "cores": threads, "kind": "pytorch-restatement", "sample": None}
+
+    def leg(name, limit):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="passive", HIP_VISIBLE_DEVICES="")
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", name, "--n", str(n), "--width", str(W),
+                                "--height", str(H)], env=env, capture_output=True, text=True, timeout=limit)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            return json.loads(lines[-1]) if lines else {"failed": (r.stderr or "no output")[-300:]}
+        except subprocess.TimeoutExpired:
+            return {"failed": f"did not finish within {limit} s on {threads} threads"}
+    lim = int(os.environ.get("SFGS_CPU_LEG_LIMIT", "150"))
+    r = leg("torch_sample", lim)
+    if "value" in r:
+        out.update(value=r["value"], sample=r["sample"])
+    else:
+        out["sample"] = "pytorch restatement on this workload: " + r.get("failed", "failed")
+    out["cfg1_full"] = leg("torch_cfg1", lim)
+    out["port"] = leg("c_oracle", lim)
+    return out
+
+
+def cpu_leg(name, n, W, H):
+    """One CPU-baseline leg (own process, see run_cpu_baseline); prints one JSON line."""
+    from sfgs.synth import cfg1, scene, upstream_grads
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    if name == "c_oracle":
         from oracle import oracle as orc
-        from sfgs.synth import scene, upstream_grads
         frame, g = scene(n, W, H, seed=0)
         gc, gd = upstream_grads(W, H, 0)
-        cores = os.cpu_count() or 1
-        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
         orc.lib()
         t0 = time.perf_counter()
         R = orc.OracleRender(frame, **g)
@@ -272,11 +356,43 @@ def run_cpu_baseline(n, W, H):
         R.backward(gc, gdm)
         dt = time.perf_counter() - t0
         R.close()
-        return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-                "sample": f"one fwd+bwd of the C/OpenMP oracle on N={n} Gaussians of the same scene generator at "
-                          f"{W}x{H} ({dt:.1f} s)"}
-    except Exception as e:  # the baseline must never take the bench line down
-        return {"value": None, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps({"value": n / dt, "unit": "Gaussians/s", "cores": threads, "kind": "port",
+                          "sample": f"one fwd+bwd of the C/OpenMP oracle (oracle/sfgs_oracle.c) on the whole workload ({dt:.1f} s)"}))
+        return
+    from oracle import tiled_torch
+    torch.set_num_threads(threads)
+
+    def fwd_bwd(frame, g, gc, gd, subset):
+        t = {k: v.clone().requires_grad_(True) for k, v in g.items() if v is not None}
+        m2 = torch.zeros(g["means3D"].shape[0], 3, requires_grad=True)
+        t0 = time.perf_counter()
+        color, depth, _, _, st = tiled_torch.render_tiled(frame, t["means3D"], t["scales"], t["rotations"], t["opacities"],
+                                                          colors_precomp=t["colors_precomp"], means2D=m2, tile_subset=subset)
+        if st["tiles"]:
+            torch.autograd.backward([color, torch.nan_to_num(depth)], [gc, torch.nan_to_num(gd)])
+        return time.perf_counter() - t0, st
+    if name == "torch_cfg1":      # cfg 1 in full (50 k Gaussians, 800x800)
+        f1, g1 = cfg1()
+        gc1, gd1 = upstream_grads(800, 800, 0)
+        dt1, _ = fwd_bwd(f1, g1, gc1, gd1, None)
+        print(json.dumps({"value": 50_000 / dt1, "unit": "Gaussians/s", "seconds": round(dt1, 2), "cores": threads,
+                          "workload": "configs[0]: 50 000 Gaussians, 800x800, one fwd+bwd, all tiles"}))
+        return
+    # this workload: preprocess + binning of all Gaussians, compositing fwd+bwd on every 64th 16x16 tile
+    frame, g = scene(n, W, H, seed=0)
+    gc, gd = upstream_grads(W, H, 0)
+    TX, TY = (W + 15) // 16, (H + 15) // 16
+    sample = list(range(7, TX * TY, 64))
+    dt_pre, _ = fwd_bwd(frame, g, gc, gd, [])
+    dt_s, st = fwd_bwd(frame, g, gc, gd, sample)
+    pairs_total = st["num_duplicates"] * 256
+    scale = pairs_total / max(st["pair_evaluations"], 1)
+    est = dt_pre + max(dt_s - dt_pre, 0.0) * scale
+    print(json.dumps({"value": n / est, "sample": (
+        f"PyTorch restatement (oracle/tiled_torch.py, float32, {threads} threads) on N={n} at {W}x{H}: preprocess + "
+        f"binning of all Gaussians {dt_pre:.1f} s; compositing fwd+bwd on {len(sample)} of {TX * TY} tiles "
+        f"({st['pair_evaluations']:.3g} of {pairs_total:.3g} (entry, pixel) pairs) {max(dt_s - dt_pre, 0):.1f} s, "
+        f"EXTRAPOLATED by the pair count to {est:.0f} s per fwd+bwd")}))
 
 
 if __name__ == "__main__":

@@ -51,10 +51,9 @@ def _rotation(q):
     return R.view(-1, 3, 3)
 
 
-def render_dense(frame, means3D, scales, rotations, opacities, colors_precomp=None, shs=None,
-                 means2D=None, dtype=torch.float64):
-    """frame: dict(H,W,tanfovx,tanfovy,kernel_size,scale_modifier,sh_degree,view,proj,campos,bg,
-    subpix(optional [H,W,2]),depth_mode). Returns color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[N]."""
+def preprocess(frame, means3D, scales, rotations, opacities, colors_precomp=None, shs=None, means2D=None,
+               dtype=torch.float64):
+    """SURVEY A.2 for all Gaussians at once (autograd-tracked). Returns a dict of per-Gaussian tensors."""
     H, W = frame["H"], frame["W"]
     V = frame["view"].to(dtype)
     PM = frame["proj"].to(dtype)
@@ -127,6 +126,20 @@ def render_dense(frame, means3D, scales, rotations, opacities, colors_precomp=No
         rgb = torch.clamp_min(_eval_sh(frame["sh_degree"], sh, d) + 0.5, 0.0)
 
     op = opacities.to(dtype).reshape(-1) * coef
+
+    return dict(H=H, W=W, bg=bg, mx=mx, my=my, cA=cA, cB=cB, cC=cC, op=op, rgb=rgb, tz=tz, radius=radius, radii=radii,
+                visible=visible, rminx=rminx, rminy=rminy, rmaxx=rmaxx, rmaxy=rmaxy, N=N, TX=TX, TY=TY)
+
+
+def render_dense(frame, means3D, scales, rotations, opacities, colors_precomp=None, shs=None,
+                 means2D=None, dtype=torch.float64):
+    """frame: dict(H,W,tanfovx,tanfovy,kernel_size,scale_modifier,sh_degree,view,proj,campos,bg,
+    subpix(optional [H,W,2]),depth_mode). Returns color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[N]."""
+    P = preprocess(frame, means3D, scales, rotations, opacities, colors_precomp, shs, means2D, dtype)
+    H, W, bg, N = P["H"], P["W"], P["bg"], P["N"]
+    mx, my, cA, cB, cC, op, rgb, tz = (P[k] for k in ("mx", "my", "cA", "cB", "cC", "op", "rgb", "tz"))
+    visible, radii = P["visible"], P["radii"]
+    rminx, rminy, rmaxx, rmaxy = P["rminx"], P["rminy"], P["rmaxx"], P["rmaxy"]
 
     # order: ascending (float32 depth bits, index) -- A.3
     depth32 = tz.detach().to(torch.float32)

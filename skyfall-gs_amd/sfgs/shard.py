@@ -51,17 +51,27 @@ def scenes_for_rank(scenes, rank, world):
 
 class SharedGradBucket:
     """Flat gradient bucket of the parameters that are shared between the per-rank scenes (the appearance
-    MLP). all_reduce_() averages their .grad across ranks with a single collective."""
+    MLP). all_reduce_() averages their .grad across ranks with a single collective.
+
+    Scenes differ in length (iterations, early stops): the bucket carries one extra element, the number of ranks
+    still training. A rank whose training has ended keeps answering the collective with zeros (`drain()`, called by
+    the launcher at exit) until every rank has ended, and the training ranks average over the ACTIVE ranks only -- so
+    a short scene never blocks or dilutes the long ones."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0] if self.params else torch.zeros(0)
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.flat = torch.zeros(n + 1, dtype=ref.dtype, device=ref.device)   # [..., active-rank count]
         self._work = None
+        self.steps = 0
 
     def numel(self):
-        return self.flat.numel()
+        return self.flat.numel() - 1
+
+    @staticmethod
+    def _distributed():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def launch(self):
         """Pack the grads and start the all-reduce (async). Call right after backward()."""
@@ -73,18 +83,19 @@ class SharedGradBucket:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        self.flat[off] = 1.0
+        if self._distributed():
             self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
         return self
 
     def wait(self):
         """Finish the all-reduce and write the averaged grads back. Call before optimizer.step()."""
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if self._work is not None:
             self._work.wait()
             self._work = None
-        if world > 1:
-            self.flat.div_(world)
+        n_total = self.flat.numel() - 1
+        if self._distributed():
+            self.flat[:n_total].div_(self.flat[n_total].clamp(min=1.0))   # mean over the ranks still training
         off = 0
         for p in self.params:
             n = p.numel()
@@ -93,9 +104,23 @@ class SharedGradBucket:
             else:
                 p.grad.copy_(self.flat[off:off + n].reshape(p.shape))
             off += n
+        self.steps += 1
 
     def all_reduce_(self):
         self.launch().wait()
+
+    def drain(self):
+        """This rank's training is over: keep matching the other ranks' collectives with zeros until nobody trains.
+        Returns the number of rounds answered."""
+        if not self._distributed():
+            return 0
+        rounds = 0
+        while True:
+            self.flat.zero_()
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            rounds += 1
+            if float(self.flat[-1]) == 0.0:       # every rank is draining: all leave in the same round
+                return rounds
 
 
 def band_rows(height, world, rank):

@@ -147,3 +147,37 @@ def test_knn_oracle_matches_kdtree():
     ref = (d[:, 1:] ** 2).mean(axis=1)
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(orc.knn_dist2(pts[:2]), [((pts[0] - pts[1]) ** 2).sum()] * 2, rtol=1e-5)
+
+
+def test_tiled_torch_restatement_matches_the_c_oracle():
+    """oracle/tiled_torch.py (bench.py's "pytorch-restatement" CPU baseline) against the C oracle: forward to
+    float32 round-off, autograd gradients against the hand-derived backward."""
+    import torch
+    from oracle import tiled_torch
+    from sfgs.synth import scene, upstream_grads
+    frame, g = scene(1500, 100, 70, seed=4, zrange=(4., 8.), scale_range=(0.01, 0.25))
+    frame = dict(frame, bg=torch.tensor([0.2, 0.5, 0.1]))
+    R = orc.OracleRender(frame, **g)
+    gc, gd = upstream_grads(100, 70, 3)
+    gd = gd.clone()
+    gd[torch.from_numpy(np.isnan(R.depth))] = 0
+    G = R.backward(gc, gd)
+    t = {k: v.clone().requires_grad_(True) for k, v in g.items() if v is not None}
+    means2D = torch.zeros(1500, 3, requires_grad=True)
+    color, depth, alpha, radii, stats = tiled_torch.render_tiled(frame, t["means3D"], t["scales"], t["rotations"],
+                                                                 t["opacities"], colors_precomp=t["colors_precomp"],
+                                                                 means2D=means2D, dtype=torch.float64)
+    np.testing.assert_array_equal(radii.numpy(), R.radii)
+    assert stats["num_duplicates"] == R.num_duplicates and stats["num_visible"] == R.num_visible
+    for name, got in (("color", color), ("alpha", alpha), ("depth", depth)):
+        ref = getattr(R, name)
+        got = got.detach().numpy()
+        assert (np.isnan(got) == np.isnan(ref)).all(), name
+        m = ~np.isnan(ref)
+        assert np.abs(got[m] - ref[m]).max() <= 2e-5 * max(np.abs(ref[m]).max(), 1e-30), name
+    ((color * gc.double()).sum() + (torch.nan_to_num(depth) * gd.double()).sum()).backward()
+    for k in ("means3D", "scales", "rotations", "opacities", "colors_precomp"):
+        got, ref = t[k].grad.numpy(), G[k]
+        assert np.linalg.norm(got - ref) <= 5e-4 * np.linalg.norm(ref), k
+    got, ref = means2D.grad.numpy()[:, :2], G["means2D"][:, :2]
+    assert np.linalg.norm(got - ref) <= 5e-4 * np.linalg.norm(ref)
