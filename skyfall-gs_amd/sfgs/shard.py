@@ -144,14 +144,18 @@ def gather_bands(image, height, rank=None, world=None):
     hmax = max(b - a for a, b in spans)
     Cc, _, W = image.shape
     a, b = spans[rank]
-    mine = torch.zeros(Cc, hmax, W, dtype=image.dtype, device=image.device)
-    mine[:, :b - a] = image[:, a:b]
+    # RCCL moves device memory directly; a host-only backend (gloo: tests, or a node without xGMI) gets the band
+    # staged through host memory and the assembled frame copied back
+    staged = image.is_cuda and dist.get_backend() == "gloo"
+    src = image.cpu() if staged else image
+    mine = torch.zeros(Cc, hmax, W, dtype=src.dtype, device=src.device)
+    mine[:, :b - a] = src[:, a:b]
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
-    out = torch.empty_like(image)
+    out = torch.empty_like(src)
     for (a, b), part in zip(spans, parts):
         out[:, a:b] = part[:, :b - a]
-    return out
+    return out.to(image.device) if staged else out
 
 
 def render_joint(rasterizer_cls, settings, inputs, height):

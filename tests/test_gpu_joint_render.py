@@ -1,0 +1,117 @@
+"""Joint render of several fused scenes, end to end: per-scene fused PLYs
+(the reference's save_fused_ply format, scene/gaussian_model.py:438-481) -> sfgs.ply.merge_fused_plys with world
+offsets -> load_standard_ply (render_video_from_ply.py:229-275) -> band-sharded render. The assembled frame must equal
+the single-GPU frame BIT FOR BIT, both with the ranks emulated in one process (world = 8) and through
+sfgs.shard.render_joint / gather_bands on real processes (gloo, bands staged through host memory)."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+W, H = 640, 360
+
+
+def _scene_model(seed, n, centre):
+    g = torch.Generator().manual_seed(seed)
+    m = types.SimpleNamespace(appearance_enabled=False, max_sh_degree=1)
+    m._xyz = torch.randn(n, 3, generator=g) * torch.tensor([6.0, 4.0, 3.0]) + torch.tensor(centre)
+    m._features_dc = torch.randn(n, 1, 3, generator=g)
+    m._features_rest = torch.randn(n, 3, 3, generator=g) * 0.3
+    m._opacity = torch.randn(n, 1, generator=g)
+    m._scaling = torch.log(torch.rand(n, 3, generator=g) * 0.25 + 0.02)
+    m._rotation = torch.randn(n, 4, generator=g)
+    m.get_opacity_with_3D_filter = torch.sigmoid(m._opacity)      # what save_fused_ply bakes (filter = 0 here)
+    m.get_scaling_with_3D_filter = torch.exp(m._scaling)
+    return m
+
+
+def _write_merged(tmp):
+    from sfgs import ply
+    paths, offsets = [], [(-15.0, 0.0, 40.0), (0.0, 0.0, 45.0), (15.0, 2.0, 50.0)]
+    for i in range(3):
+        p = os.path.join(tmp, f"scene{i}.ply")
+        ply.save_fused_ply(_scene_model(10 + i, 20000 + 3000 * i, (0.0, 0.0, 0.0)), p)
+        paths.append(p)
+    out = os.path.join(tmp, "joint.ply")
+    merged = ply.merge_fused_plys(paths, offsets, out)
+    assert len(merged) == 20000 + 23000 + 26000
+    return out
+
+
+def _inputs_from_ply(path, dev):
+    from sfgs import ply
+    from sfgs.camera import fovy_from_fovx, make_frame
+    import math
+    model = types.SimpleNamespace(max_sh_degree=ply.detect_sh_degree(path))
+    ply.load_standard_ply(model, path, device=dev)
+    fovx = math.radians(60.0)
+    frame = make_frame(np.eye(3), np.zeros(3), fovx, fovy_from_fovx(fovx, W, H), W, H, kernel_size=0.1, sh_degree=1)
+    from diff_gauss import GaussianRasterizationSettings
+    settings = GaussianRasterizationSettings(H, W, frame["tanfovx"], frame["tanfovy"], 0.1, None, frame["bg"].to(dev), 1.0,
+                                             frame["view"].to(dev), frame["proj"].to(dev), 1, frame["campos"].to(dev),
+                                             False, False)
+    with torch.no_grad():
+        rot = torch.nn.functional.normalize(model._rotation)
+        inputs = dict(means3D=model._xyz.detach(), means2D=None, opacities=torch.sigmoid(model._opacity.detach()),
+                      shs=torch.cat([model._features_dc, model._features_rest], 1).detach().contiguous(),
+                      scales=torch.exp(model._scaling.detach()), rotations=rot)
+    return settings, inputs
+
+
+def test_merged_ply_band_render_equals_single_pass(tmp_path):
+    from diff_gauss import GaussianRasterizer
+    from sfgs import shard
+    dev = torch.device("cuda:0")
+    settings, inputs = _inputs_from_ply(_write_merged(str(tmp_path)), dev)
+    with torch.no_grad():
+        color, depth, _, alpha, radii, _ = GaussianRasterizer(settings)(**inputs)
+        assert int((radii > 0).sum()) > 30000 and float(alpha.mean()) > 0.05
+        acc = torch.zeros(5, H, W, device=dev)
+        for r in range(8):                                      # what rank r of 8 renders and contributes
+            t0, t1, a, b = shard.band_rows(H, 8, r)
+            c, d, _, al, _, _ = GaussianRasterizer(settings._replace(tile_rows=(t0, t1)))(**inputs)
+            acc[:, a:b] = torch.cat([c, d, al], 0)[:, a:b]
+    full = torch.cat([color, depth, alpha], 0)
+    assert torch.equal(torch.nan_to_num(acc, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
+
+
+def _worker(rank, world, port, path, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diff_gauss import GaussianRasterizer
+    from sfgs import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        settings, inputs = _inputs_from_ply(path, dev)
+        color, depth, alpha = shard.render_joint(GaussianRasterizer, settings, inputs, H)
+        ret[rank] = torch.cat([color, depth, alpha], 0).cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_render_joint_over_real_processes(tmp_path):
+    import torch.multiprocessing as mp
+    from diff_gauss import GaussianRasterizer
+    path = _write_merged(str(tmp_path))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    world = 3
+    procs = [ctx.Process(target=_worker, args=(r, world, port, path, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    settings, inputs = _inputs_from_ply(path, dev)
+    with torch.no_grad():
+        color, depth, _, alpha, _, _ = GaussianRasterizer(settings)(**inputs)
+    full = torch.cat([color, depth, alpha], 0).cpu().numpy()
+    for r in range(world):
+        np.testing.assert_array_equal(np.nan_to_num(ret[r], nan=-1.0), np.nan_to_num(full, nan=-1.0))
