@@ -303,6 +303,49 @@ int sfgs_compact_plan(const unsigned char* keep, int64_t N, void* scratch, size_
 int sfgs_compact_rows(const unsigned char* keep, int64_t N, const void* scratch, const SfgsCompactTensor* tensors,
                       int32_t count, void* stream);
 
+/* GaussianModel.densify_and_prune (scene/gaussian_model.py:603-742) as a handful of launches.
+ *
+ * sfgs_select_kth: exact order statistics of N non-negative floats by radix select, for ANY N (torch.quantile refuses
+ * more than 16 M elements and the reference then falls back to Q = 0.99, :716-723). rank_dev: DEVICE float r (as
+ * torch.quantile forms it: q * (N - 1)); out2[0] = value at rank floor(r), out2[1] = value at rank ceil(r) (device);
+ * the caller interpolates like torch (lerp). Asynchronous.
+ *
+ * sfgs_densify_decide: per Gaussian, from grad_norm[N] = |xyz_gradient_accum / denom|, grad_abs[N] (the abs column),
+ * the ACTIVATED scaling[N,3] / opacity[N] (float32, or float64 after the reference's reset_opacity) and the thresholds:
+ * clone = selected and max(scaling) <= dense_threshold, split = selected and max(scaling) > dense_threshold with
+ * selected = grad_norm >= max_grad or grad_abs >= Q (Q read from Q_dev when non-NULL, else Q_host), and which rows
+ * survive the final prune (opacity < min_opacity, or -- when use_big_threshold -- max(scaling) > big_threshold; the
+ * screen-size term never fires in the reference because densification_postfix resets max_radii2D first). Fills
+ * `scratch` (sfgs_densify_scratch_bytes) and returns, with ONE host synchronisation, totals_out[5] = rows kept of
+ * {originals, clones, children per child index} and the raw {clone, split} counts.
+ * sfgs_densify_gather: writes every dst tensor [totals[0] + totals[1] + 2 * totals[2] rows] in the reference's final
+ * order [surviving originals | clones | first children | second children]; zero_new_rows: clones / children get zeros
+ * (Adam moments). sfgs_densify_children then overwrites the child rows of xyz (parent + R(q) * sample) and of the raw
+ * scaling (log(scaling / 1.6)); samples[2 * totals[4], 3] = std * z in the layout of the reference's `samples` (:666).
+ * sfgs_densify_masks: the decisions as byte masks (tests / diagnostics). */
+typedef struct SfgsDensifyTensor {
+  const void* src;
+  void* dst;
+  int64_t row_bytes;       /* multiple of 4 */
+  int32_t zero_new_rows;
+  int32_t reserved;
+} SfgsDensifyTensor;
+size_t sfgs_select_scratch_bytes(void);
+int sfgs_select_kth(const float* values, int64_t N, const float* rank_dev, float* out2, void* scratch,
+                    size_t scratch_bytes, void* stream);
+size_t sfgs_densify_scratch_bytes(int64_t N);
+int sfgs_densify_decide(int64_t N, const float* grad_norm, const float* grad_abs, const float* scaling,
+                        const void* opacity, int32_t opacity_is_f64, const float* Q_dev, float Q_host, float max_grad,
+                        double min_opacity, float dense_threshold, float big_threshold, int32_t use_big_threshold,
+                        void* scratch, size_t scratch_bytes, int64_t totals_out[5], void* stream);
+int sfgs_densify_masks(int64_t N, const void* scratch, unsigned char* clone_out, unsigned char* split_out,
+                       unsigned char* keep_out, void* stream);
+int sfgs_densify_gather(int64_t N, const void* scratch, const int64_t totals[5], const SfgsDensifyTensor* tensors,
+                        int32_t count, void* stream);
+int sfgs_densify_children(int64_t N, const void* scratch, const int64_t totals[5], const float* xyz,
+                          const float* rotation_raw, const float* scaling, const float* samples, float* xyz_out,
+                          float* scaling_raw_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 static const char* const kKernelNames[KID_COUNT] = {
     "subpix_bound", "preprocess", "plan_scan", "fine_bin", "sort_tiles_small", "sort_tiles_reg_long",
     "sort_tiles_lds", "composite_fwd", "composite_bwd", "preprocess_bwd", "ssim_fwd", "ssim_mean", "ssim_bwd",
-    "knn_dist2", "prepass_fwd", "prepass_bwd", "filter3d", "densify_stats", "adam", "sh_eval_fwd", "sh_eval_bwd", "compact_scan", "compact_gather"};
+    "knn_dist2", "prepass_fwd", "prepass_bwd", "filter3d", "densify_stats", "adam", "sh_eval_fwd", "sh_eval_bwd", "compact_scan", "compact_gather", "densify"};
 
 struct ProfRec { int id; hipEvent_t a, b; };
 static std::mutex g_prof_mu;

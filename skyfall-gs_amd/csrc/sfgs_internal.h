@@ -33,7 +33,7 @@ void set_error(const char* fmt, ...);
 // ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
 enum KernelId {
   KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_FINE_BIN, KID_SORT_SMALL, KID_SORT_REG_LONG, KID_SORT_LDS,
-  KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN, KID_PREPASS_FWD, KID_PREPASS_BWD, KID_FILTER3D, KID_DENSIFY_STATS, KID_ADAM, KID_SH_EVAL_FWD, KID_SH_EVAL_BWD, KID_COMPACT_SCAN, KID_COMPACT_GATHER,
+  KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN, KID_PREPASS_FWD, KID_PREPASS_BWD, KID_FILTER3D, KID_DENSIFY_STATS, KID_ADAM, KID_SH_EVAL_FWD, KID_SH_EVAL_BWD, KID_COMPACT_SCAN, KID_COMPACT_GATHER, KID_DENSIFY,
   KID_COUNT
 };
 bool prof_enabled();

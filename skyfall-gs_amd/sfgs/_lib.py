@@ -53,6 +53,11 @@ class SfgsCompactTensor(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]
 
 
+class SfgsDensifyTensor(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("zero_new_rows", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class SfgsRasterCounters(C.Structure):
     _fields_ = [("num_duplicates", C.c_int64), ("num_duplicates_ref", C.c_int64), ("num_visible", C.c_int64),
                 ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64)]
@@ -93,6 +98,14 @@ SYMBOLS = {
     "sfgs_compact_scratch_bytes": (_SZ, [_I64]),
     "sfgs_compact_plan": (C.c_int, [_V, _I64, _V, _SZ, C.POINTER(C.c_int64), _V]),
     "sfgs_compact_rows": (C.c_int, [_V, _I64, _V, C.POINTER(SfgsCompactTensor), _I32, _V]),
+    "sfgs_select_scratch_bytes": (_SZ, []),
+    "sfgs_select_kth": (C.c_int, [_V, _I64, _V, _V, _V, _SZ, _V]),
+    "sfgs_densify_scratch_bytes": (_SZ, [_I64]),
+    "sfgs_densify_decide": (C.c_int, [_I64, _V, _V, _V, _V, _I32, _V, C.c_float, C.c_float, C.c_double, C.c_float,
+                                      C.c_float, _I32, _V, _SZ, C.POINTER(C.c_int64), _V]),
+    "sfgs_densify_masks": (C.c_int, [_I64, _V, _V, _V, _V, _V]),
+    "sfgs_densify_gather": (C.c_int, [_I64, _V, C.POINTER(C.c_int64), C.POINTER(SfgsDensifyTensor), _I32, _V]),
+    "sfgs_densify_children": (C.c_int, [_I64, _V, C.POINTER(C.c_int64), _V, _V, _V, _V, _V, _V, _V]),
     "sfgs_prepass_forward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V]),
     "sfgs_prepass_backward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V, _V, _V, _V]),
 }

@@ -7,6 +7,7 @@ from the golden statistics. GPU: the HIP path's means2D.grad / radii, accumulate
 add_densification_stats kernel, lead to the SAME masks bit for bit."""
 import json
 import os
+import types
 
 import numpy as np
 import pytest
@@ -85,3 +86,27 @@ def test_hip_gradients_give_the_same_masks_bit_for_bit():
           f"Q {float(d['Q']):.6e} vs {float(z['Q']):.6e}")
     for k in ("clone", "split", "prune"):
         np.testing.assert_array_equal(d[k].numpy(), z[k], err_msg=k)
+    # the PRODUCT's decision kernel (sfgs.densify / csrc/densify.hip) on the same HIP statistics: same masks, same Q
+    from sfgs import densify
+
+    class M(types.SimpleNamespace):
+        get_scaling = property(lambda self: self.scaling_act)
+        get_opacity = property(lambda self: self.opacity_act)
+    pm = M(_xyz=g["means3D"].to(dev), xyz_gradient_accum=accum, xyz_gradient_accum_abs=accum_abs, denom=denom,
+           scaling_act=scales, opacity_act=opac, percent_dense=c["percent_dense"])
+    clone, split, keep, Q = densify.decide_masks(pm, float(z["max_grad"]), c["min_opacity"], c["extent"], c["max_screen_size"])
+    np.testing.assert_array_equal(clone.cpu().numpy(), z["clone"][: c["n"]])
+    np.testing.assert_array_equal(split.cpu().numpy(), z["split"][: c["n"]])
+    # radix-select quantile == torch.quantile evaluated ON THE DEVICE on the same statistics (the CPU build of torch
+    # forms `ratio = mask.float().mean()` as sum / n, the device build as sum * (1 / n): one ulp apart, visible in Q)
+    ga = (accum / denom).nan_to_num(0.0)
+    gb = (accum_abs / denom).nan_to_num(0.0)
+    assert float(Q) == float(densify_rule.quantile_threshold(ga, gb, float(z["max_grad"])))
+    # survivors in the reference's order [originals not split | clones | children x 2] = complement of its prune mask
+    kept_ref = ~z["prune"]
+    k = keep.cpu().numpy()
+    n_o, n_c = int((~z["split"][: c["n"]]).sum()), int(z["clone"].sum())
+    np.testing.assert_array_equal(k[:, 0][~z["split"][: c["n"]]], kept_ref[:n_o])
+    np.testing.assert_array_equal(k[:, 1][z["clone"]], kept_ref[n_o:n_o + n_c])
+    ch = k[:, 2][z["split"][: c["n"]]]
+    np.testing.assert_array_equal(np.concatenate([ch, ch]), kept_ref[n_o + n_c:])

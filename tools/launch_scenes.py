@@ -45,13 +45,13 @@ def _free_port():
 # ---- hooks on the reference's GaussianModel ---------------------------------------------------------------------------
 def install_hooks(gaussian_model_cls, fused=True, shared_mlp=True):
     """Patch the reference's GaussianModel class in place (idempotent). fused: the HIP drop-ins of INTEGRATION.md
-    (pre-pass, 3D filter, densification statistics, Adam, prune compaction). shared_mlp: keep the appearance MLP in
+    (pre-pass, 3D filter, densification statistics, Adam, prune compaction, densify_and_prune). shared_mlp: keep the appearance MLP in
     step across the processes of the torch.distributed group."""
     if PKG not in sys.path:
         sys.path.insert(0, PKG)
     if fused:
-        from sfgs import adam, compact, densify_stats, filter3d, prepass
-        for mod in (prepass, filter3d, densify_stats, adam, compact):
+        from sfgs import adam, compact, densify, densify_stats, filter3d, prepass
+        for mod in (prepass, filter3d, densify_stats, adam, compact, densify):
             mod.install(gaussian_model_cls)
     if shared_mlp and not getattr(gaussian_model_cls, "_sfgs_shared_mlp", False):
         import torch.distributed as dist
