@@ -362,6 +362,47 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   }
 }
 
+// Parallel pre-reduction of the records of Gaussians with more than BWD_BIG duplicates (sfgs_internal.h): one
+// workgroup per 1024-record chunk sums the chunk in a fixed order and overwrites the chunk's FIRST record with the sum.
+__global__ void __launch_bounds__(256)
+dupgrad_reduce_kernel(const unsigned long long* __restrict__ hdr, const uint2* __restrict__ big_chunks,
+                      unsigned chunk_cap, const uint2* __restrict__ dup, float4* __restrict__ dupgrad) {
+  __shared__ float part[4][12];
+  const unsigned n_chunks = (unsigned)min(hdr[HDR_BIG_CHUNKS], (unsigned long long)chunk_cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned j = blockIdx.x; j < n_chunks; j += gridDim.x) {
+    const uint2 gc = big_chunks[j];
+    const uint2 dr = dup[gc.x];
+    const unsigned first = gc.y * BWD_CHUNK;
+    const unsigned n = min(BWD_CHUNK, dr.y - first);
+    const size_t d0 = (size_t)dr.x + first;
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = 0.f;
+    for (unsigned i = threadIdx.x; i < n; i += 256) {
+      const float4 x0 = dupgrad[(d0 + i) * 3], x1 = dupgrad[(d0 + i) * 3 + 1], x2 = dupgrad[(d0 + i) * 3 + 2];
+      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w;
+      v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+      v[8] += x2.x; v[9] += x2.y; v[10] += x2.z; v[11] += x2.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v[i] += __shfl_xor(v[i], d);
+    }
+    __syncthreads();   // every record of the chunk has been read (and `part` is free again)
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) part[wave][i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+      const float s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+      reinterpret_cast<float*>(dupgrad + d0 * 3)[threadIdx.x] = s;
+    }
+  }
+}
+
 // one thread per Gaussian. K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree:
 // compile-time so that the coefficient / gradient rows live in registers, not scratch.
 template <int K, int DEG>
@@ -384,7 +425,14 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   unsigned d0 = 0, cnt = 0;
   if (vis) { const uint2 dr = dup[g]; d0 = dr.x; cnt = dr.y; }
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-  if (cnt <= COOP) {
+  if (cnt > BWD_BIG) {   // pre-reduced by dupgrad_reduce_kernel: add the chunk heads (<= a few dozen)
+    for (unsigned d = d0; d < d0 + cnt; d += BWD_CHUNK) {
+      const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
+      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+    }
+  } else if (cnt <= COOP) {
     for (unsigned d = d0; d < d0 + cnt; ++d) {
       const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
       a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
@@ -392,7 +440,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
       a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
     }
   }
-  for (unsigned long long todo = __ballot(cnt > COOP); todo; todo &= todo - 1) {
+  for (unsigned long long todo = __ballot(cnt > COOP && cnt <= BWD_BIG); todo; todo &= todo - 1) {
     const int src = __builtin_ctzll(todo);
     const unsigned b0 = (unsigned)__shfl((int)d0, src), bn = (unsigned)__shfl((int)cnt, src);
     float v[12];
@@ -503,6 +551,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
+    hipLaunchKernelGGL(dupgrad_reduce_kernel, dim3(1024), dim3(256), 0, stream, tv.hdr, bv.big_chunks,
+                       (unsigned)big_chunk_capacity(dup_capacity), gv.dup, (float4*)dupgrad);
 #define SFGS_LAUNCH_PBWD(K, D)                                                                                          \
   hipLaunchKernelGGL((preprocess_bwd_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales, \
                      g->rotations, g->opacities, g->shs, radii, gv.dup, (const float4*)dupgrad, grads->means3D,        \

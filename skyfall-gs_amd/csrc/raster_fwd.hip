@@ -121,7 +121,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
-                  unsigned long long* __restrict__ hdr) {
+                  uint2* __restrict__ big_chunks, unsigned big_chunk_cap, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
   __shared__ unsigned long long s_base;
   const FrameParams f = load_frame(kf);
@@ -219,6 +219,13 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const bool fits = base + total <= dup_capacity;
   if (!fits && threadIdx.x == 0) hdr[HDR_OVERFLOW] = 1ull;
   if (g < N) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
+  if (fits && n_dup > BWD_BIG) {  // rare: list this Gaussian's records in chunks for the backward's parallel reduction
+    const unsigned nch = (n_dup + BWD_CHUNK - 1) / BWD_CHUNK;
+    const unsigned long long cb0 = atomicAdd(&hdr[HDR_BIG_CHUNKS], (unsigned long long)nch);
+    if (cb0 + nch <= big_chunk_cap)
+      for (unsigned c = 0; c < nch; ++c) big_chunks[cb0 + c] = make_uint2((unsigned)g, c);
+    else hdr[HDR_OVERFLOW] = 1ull;   // cannot happen while dup_capacity >= D (big_chunk_capacity's bound); kept for safety
+  }
   if (fits && n_dup && !big) {
     unsigned dup = (unsigned)(base + ex);
     int cx = cx0, cy = cy0;
@@ -923,7 +930,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   hipLaunchKernelGGL((preprocess_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,    \
                      g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,   \
                      bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,            \
-                     tv.block_dref, tv.hdr)
+                     tv.block_dref, bv.big_chunks, (unsigned)big_chunk_capacity(dup_capacity), tv.hdr)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
     }

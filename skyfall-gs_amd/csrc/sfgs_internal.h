@@ -112,7 +112,8 @@ enum HeaderSlot {
   HDR_SUBPIX_BOUND = 5,  // float bits of max |subpixel_offset| (0 when none)
   HDR_ITEM_ALLOC = 6,    // list-slot allocator of the fine-binning kernel
   HDR_MAX_COARSE = 7,    // fullest coarse bin (sizes coarse_capacity for the next frame)
-  HDR_LONG_COUNT = 8     // tiles whose list is too long for the register sort (> 512 entries)
+  HDR_LONG_COUNT = 8,    // tiles whose list is too long for the register sort (> 512 entries)
+  HDR_BIG_CHUNKS = 9     // entries of BinsView::big_chunks (1024-record chunks of Gaussians with > BWD_BIG duplicates)
 };
 
 struct GeomView {
@@ -169,14 +170,23 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   return t;
 }
 
+// A Gaussian that covers thousands of tiles owns thousands of per-duplicate gradient records: preprocess_bwd would sum
+// them with ONE wave while the rest of the chip idles (2 000 screen-filling splats: 11.7 ms). Such Gaussians (more than
+// BWD_BIG duplicates) are listed by the forward in 1024-record chunks; the backward first reduces every chunk to its
+// head record with one workgroup per chunk (dupgrad_reduce_kernel), preprocess_bwd then adds the few heads.
+constexpr unsigned BWD_BIG = 2048, BWD_CHUNK = 1024;
+static inline size_t big_chunk_capacity(int64_t D) { return (size_t)(D / 512 + 64); }
+
 struct BinsView {
   uint4* slabs;          // [NCB][coarse_capacity] coarse items (Gaussian id, depth bits, first dup index, 16-bit tile mask)
   uint4* items;          // [D] per-tile segments, unsorted: (Gaussian id, depth bits, dup index, 0)
   uint32_t* sorted_id;   // [D] per-tile lists of Gaussian ids, front to back
   uint32_t* sorted_dup;  // [D] the matching duplicate indices
+  uint2* big_chunks;     // [D / 512 + 64] (Gaussian id, chunk index) of the chunks described above
 };
 static inline size_t bins_bytes(int64_t D, int64_t NCB, int64_t coarse_cap) {
-  return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
+  return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256) +
+         align_up(big_chunk_capacity(D) * 8, 256);
 }
 static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coarse_cap) {
   BinsView b;
@@ -184,7 +194,8 @@ static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coa
   b.slabs = (uint4*)p; p += align_up((size_t)NCB * coarse_cap * 16, 256);
   b.items = (uint4*)p; p += align_up((size_t)D * 16, 256);
   b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
-  b.sorted_dup = (uint32_t*)p;
+  b.sorted_dup = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
+  b.big_chunks = (uint2*)p;
   return b;
 }
 

@@ -19,6 +19,9 @@ CASES = {
                                                      sh_degree=1)),
     "cfg2_like": dict(n=60000, W=480, H=270, kw=dict(zrange=(250., 350.), scale_range=(0.2, 2.4))),
     "big_splats": dict(n=400, W=256, H=192, kw=dict(zrange=(3., 6.), scale_range=(0.3, 2.0))),
+    # splats that cover thousands of 8x8 tiles each: the chunked parallel reduction of their gradient records
+    # (dupgrad_reduce_kernel, > 2048 duplicates per Gaussian) and the wave-cooperative binning walk
+    "screen_filling": dict(n=60, W=640, H=400, kw=dict(zrange=(3., 6.), scale_range=(0.5, 3.0), opacity_range=(0.01, 0.05))),
     # the headline scene generator at its full viewport, 1/10 of the Gaussians (the oracle needs ~1 s for it)
     "cfg2_200k_1080p": dict(n=200000, W=1920, H=1080, kw=dict()),
     "cfg4_like_1440p": dict(n=150000, W=2560, H=1440, kw=dict(zrange=(500., 700.))),
@@ -86,6 +89,8 @@ def test_forward_backward_parity(case):
     print(case, out["counters"], reps)
     want_list = {"lists_800": (513, 1024), "lists_2k": (1025, 2048), "lists_3k": (2049, 4096), "lists_6k": (4097, 8192),
                  "lists_10k": (8193, 1 << 20)}.get(case)
+    if case == "screen_filling":
+        assert out["counters"]["num_duplicates"] > 20 * 2048, out["counters"]   # many Gaussians above BWD_BIG duplicates
     if want_list:  # the case really exercises the sort path it is named after
         assert want_list[0] <= out["counters"]["max_tile_list"] <= want_list[1], out["counters"]
 
