@@ -341,7 +341,22 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
   const uint4* slab = slabs + (size_t)cb * coarse_capacity;
   if (tid < COARSE_TILES) cnt[tid] = 0;
   __syncthreads();
-  for (unsigned i = tid; i < n; i += 256) {
+  // the bin's coarse items are read ONCE, all loads of a thread in flight together (the kernel is latency-bound: one
+  // round of workgroups, each a chain of dependent global loads and LDS atomics); bins with more than 256 * FB_R items
+  // take the remainder from memory in both passes
+  constexpr int FB_R = 12;
+  uint4 reg[FB_R];
+#pragma unroll
+  for (int k = 0; k < FB_R; ++k) {
+    const unsigned i = tid + 256u * k;
+    reg[k] = i < n ? slab[i] : make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < FB_R; ++k) {
+    unsigned m = reg[k].w;
+    while (m) { const int b = __builtin_ctz(m); m &= m - 1; atomicAdd(&cnt[b], 1u); }
+  }
+  for (unsigned i = tid + 256u * FB_R; i < n; i += 256) {
     unsigned m = slab[i].w;
     while (m) { const int b = __builtin_ctz(m); m &= m - 1; atomicAdd(&cnt[b], 1u); }
   }
@@ -380,8 +395,7 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
   __syncthreads();
   const unsigned long long base = s_base;
   if (base == ~0ull) return;
-  for (unsigned i = tid; i < n; i += 256) {
-    const uint4 it = slab[i];
+  auto expand = [&](const uint4 it) {
     unsigned m = it.w, dup = it.z;
     while (m) {
       const int b = __builtin_ctz(m);
@@ -390,7 +404,10 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
       items[base + slot] = make_uint4(it.x, it.y, dup, 0u);
       ++dup;
     }
-  }
+  };
+#pragma unroll
+  for (int k = 0; k < FB_R; ++k) expand(reg[k]);
+  for (unsigned i = tid + 256u * FB_R; i < n; i += 256) expand(slab[i]);
 }
 
 // ------------------------------------------------------------------------------------------------

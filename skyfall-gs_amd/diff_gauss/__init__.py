@@ -44,6 +44,12 @@ class GaussianRasterizationSettings(NamedTuple):
     tile_rows: Optional[tuple] = None     # extension: (begin, end) 8-pixel tile rows to render (sfgs.shard)
 
 
+import threading
+
+# Wrapper state. The forward runs on the caller's thread, the backward on an autograd worker, and nothing stops two host
+# threads from rendering at once: every piece of state below is either immutable once published (the counters dict is
+# REPLACED, never mutated), keyed by (device, stream) / (device, viewport) with idempotent updates, or guarded by _lock.
+_lock = threading.Lock()
 _last_counters = {}
 _stats = {"full": False}
 _pinned = {}     # (device index, stream) -> (pinned host buffer the counters are read through, event)
@@ -78,7 +84,7 @@ def collect_full_counters(on=True):
 
 def last_counters():
     """Counters of the most recent forward on this process (duplicates, visible Gaussians, capacities ...)."""
-    return dict(_last_counters)
+    return dict(_last_counters)   # a snapshot of the dict published by the most recent forward
 
 
 def _f32c(t, name, shape_tail=None):
@@ -188,10 +194,12 @@ class _Rasterize(torch.autograd.Function):
                 # memory-safe).
                 tstream = torch.cuda.current_stream(dev)
                 pkey = (dev.index, tstream.cuda_stream)   # one buffer per (device, stream): frames on different
-                pinned = _pinned.get(pkey)                # streams / host threads never share a counter buffer
+                pkey = pkey + (threading.get_ident(),)    # ... nor do two host threads that share a stream
+                pinned = _pinned.get(pkey)
                 if pinned is None:
-                    pinned = _pinned[pkey] = (torch.empty(8, dtype=torch.int64).pin_memory(),
-                                              torch.cuda.Event(enable_timing=False, blocking=False))
+                    with _lock:
+                        pinned = _pinned.setdefault(pkey, (torch.empty(8, dtype=torch.int64).pin_memory(),
+                                                           torch.cuda.Event(enable_timing=False, blocking=False)))
                 pin, ev = pinned
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
@@ -214,11 +222,11 @@ class _Rasterize(torch.autograd.Function):
                 ccap = max(ccap, int(cmax * 1.25) + 256)
             _cap_hint[(dev.index, W, H)] = (max(slots(int(D * 1.25) + 1024), min(cap, slots(2 * D + 1024))),
                                     max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
-            _last_counters.clear()
-            _last_counters.update(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
+            global _last_counters
+            _last_counters = dict(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
                                   num_visible=int(cnt.num_visible), max_coarse_bin=cmax,
                                   max_tile_list=int(cnt.max_tile_list), N=N, W=W, H=H, dup_capacity=cap,
-                                  coarse_capacity=ccap)
+                                  coarse_capacity=ccap)     # published by reference assignment (atomic)
         # normals are not produced by this rasterizer (no consumer in the reference): a zero-stride view of one
         # zero, i.e. a read-only all-zeros [3,H,W] tensor that costs no memory and no kernel
         norm = _zero(dev).expand(3, H, W)
