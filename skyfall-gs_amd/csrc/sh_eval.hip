@@ -9,6 +9,49 @@
 
 namespace sfgs {
 
+// degree 4 exists only in the reference's Python eval_sh (utils/sh_utils.py:44-54,101-111; the rasterizer's in-kernel SH
+// path stops at degree 3 like its CUDA original): the nine extra basis polynomials and their partial derivatives with
+// x, y, z treated as free variables (what autograd of the reference's expression yields)
+constexpr float SH4_0 = 2.5033429417967046f, SH4_1 = -1.7701307697799304f, SH4_2 = 0.9461746957575601f,
+                SH4_3 = -0.6690465435572892f, SH4_4 = 0.10578554691520431f, SH4_5 = -0.6690465435572892f,
+                SH4_6 = 0.47308734787878004f, SH4_7 = -1.7701307697799304f, SH4_8 = 0.6258357354491761f;
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis_any(float x, float y, float z, float* Bk) {
+  sh_basis(DEG > 3 ? 3 : DEG, x, y, z, Bk);
+  if constexpr (DEG > 3) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    Bk[16] = SH4_0 * xy * (xx - yy);
+    Bk[17] = SH4_1 * yz * (3.f * xx - yy);
+    Bk[18] = SH4_2 * xy * (7.f * zz - 1.f);
+    Bk[19] = SH4_3 * yz * (7.f * zz - 3.f);
+    Bk[20] = SH4_4 * (zz * (35.f * zz - 30.f) + 3.f);
+    Bk[21] = SH4_5 * xz * (7.f * zz - 3.f);
+    Bk[22] = SH4_6 * (xx - yy) * (7.f * zz - 1.f);
+    Bk[23] = SH4_7 * xz * (xx - 3.f * yy);
+    Bk[24] = SH4_8 * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+  }
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grad_any(float x, float y, float z, float* dBx, float* dBy, float* dBz) {
+  sh_basis_grad(DEG > 3 ? 3 : DEG, x, y, z, dBx, dBy, dBz);
+  if constexpr (DEG > 3) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    dBx[16] = SH4_0 * y * (3.f * xx - yy); dBy[16] = SH4_0 * x * (xx - 3.f * yy); dBz[16] = 0.f;
+    dBx[17] = SH4_1 * 6.f * xy * z; dBy[17] = SH4_1 * 3.f * z * (xx - yy); dBz[17] = SH4_1 * y * (3.f * xx - yy);
+    dBx[18] = SH4_2 * y * (7.f * zz - 1.f); dBy[18] = SH4_2 * x * (7.f * zz - 1.f); dBz[18] = SH4_2 * 14.f * xy * z;
+    dBx[19] = 0.f; dBy[19] = SH4_3 * z * (7.f * zz - 3.f); dBz[19] = SH4_3 * y * (21.f * zz - 3.f);
+    dBx[20] = 0.f; dBy[20] = 0.f; dBz[20] = SH4_4 * z * (140.f * zz - 60.f);
+    dBx[21] = SH4_5 * z * (7.f * zz - 3.f); dBy[21] = 0.f; dBz[21] = SH4_5 * x * (21.f * zz - 3.f);
+    dBx[22] = SH4_6 * 2.f * x * (7.f * zz - 1.f); dBy[22] = SH4_6 * -2.f * y * (7.f * zz - 1.f);
+    dBz[22] = SH4_6 * 14.f * z * (xx - yy);
+    dBx[23] = SH4_7 * 3.f * z * (xx - yy); dBy[23] = SH4_7 * -6.f * xy * z; dBz[23] = SH4_7 * x * (xx - 3.f * yy);
+    dBx[24] = SH4_8 * 4.f * x * (xx - 3.f * yy); dBy[24] = SH4_8 * 4.f * y * (yy - 3.f * xx); dBz[24] = 0.f;
+    (void)yz; (void)xz;
+  }
+}
+
 template <int DEG>
 __global__ void __launch_bounds__(256)
 sh_eval_fwd_kernel(int N, int K, const float* __restrict__ sh, const float* __restrict__ dirs,
@@ -18,7 +61,7 @@ sh_eval_fwd_kernel(int N, int K, const float* __restrict__ sh, const float* __re
   constexpr int M = (DEG + 1) * (DEG + 1);
   float Bk[M];
   const float x = dirs[3 * (size_t)g], y = dirs[3 * (size_t)g + 1], z = dirs[3 * (size_t)g + 2];
-  sh_basis(DEG, x, y, z, Bk);
+  sh_basis_any<DEG>(x, y, z, Bk);
   const float* s = sh + (size_t)g * 3 * K;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -38,8 +81,8 @@ sh_eval_bwd_kernel(int N, int K, const float* __restrict__ sh, const float* __re
   constexpr int M = (DEG + 1) * (DEG + 1);
   float Bk[M], dBx[M], dBy[M], dBz[M];
   const float x = dirs[3 * (size_t)g], y = dirs[3 * (size_t)g + 1], z = dirs[3 * (size_t)g + 2];
-  sh_basis(DEG, x, y, z, Bk);
-  sh_basis_grad(DEG, x, y, z, dBx, dBy, dBz);
+  sh_basis_any<DEG>(x, y, z, Bk);
+  sh_basis_grad_any<DEG>(x, y, z, dBx, dBy, dBz);
   const float* s = sh + (size_t)g * 3 * K;
   float* gs = g_sh + (size_t)g * 3 * K;
   float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -63,7 +106,7 @@ using namespace sfgs;
 
 static int check_sh_args(int32_t N, int32_t deg, int32_t K) {
   SFGS_REQUIRE(N >= 0, SFGS_E_ARG, "negative Gaussian count");
-  SFGS_REQUIRE(deg >= 0 && deg <= 3, SFGS_E_UNSUPPORTED, "SH degree %d not in 0..3", deg);
+  SFGS_REQUIRE(deg >= 0 && deg <= 4, SFGS_E_UNSUPPORTED, "SH degree %d not in 0..4", deg);
   SFGS_REQUIRE(K >= (deg + 1) * (deg + 1), SFGS_E_ARG, "%d SH coefficients stored, degree %d needs %d", K, deg,
                (deg + 1) * (deg + 1));
   return SFGS_OK;
@@ -74,7 +117,8 @@ static int check_sh_args(int32_t N, int32_t deg, int32_t K) {
     case 0: hipLaunchKernelGGL(KERNEL<0>, dim3((N + 255) / 256), dim3(256), 0, stream, __VA_ARGS__); break;     \
     case 1: hipLaunchKernelGGL(KERNEL<1>, dim3((N + 255) / 256), dim3(256), 0, stream, __VA_ARGS__); break;     \
     case 2: hipLaunchKernelGGL(KERNEL<2>, dim3((N + 255) / 256), dim3(256), 0, stream, __VA_ARGS__); break;     \
-    default: hipLaunchKernelGGL(KERNEL<3>, dim3((N + 255) / 256), dim3(256), 0, stream, __VA_ARGS__); break;    \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3((N + 255) / 256), dim3(256), 0, stream, __VA_ARGS__); break;     \
+    default: hipLaunchKernelGGL(KERNEL<4>, dim3((N + 255) / 256), dim3(256), 0, stream, __VA_ARGS__); break;    \
   }
 
 extern "C" int sfgs_sh_eval_forward(int32_t N, int32_t deg, int32_t K, const float* sh, const float* dirs,

@@ -44,8 +44,6 @@ def eval_sh(deg, sh, dirs):
     """Same contract as the reference's eval_sh: sh [..., 3, K] (K >= (deg+1)^2), dirs [..., 3] -> [..., 3]."""
     if not (0 <= deg <= 4):
         raise AssertionError  # the reference asserts `deg <= 4 and deg >= 0`
-    if deg > 3:
-        raise NotImplementedError("fused eval_sh implements degrees 0-3 (the reference trains with sh_degree <= 3)")
     if sh.shape[-1] < (deg + 1) ** 2:
         raise AssertionError  # reference: `assert sh.shape[-1] >= coeff`
     if sh.shape[-2] != 3 or dirs.shape[-1] != 3 or sh.shape[:-2] != dirs.shape[:-1]:

@@ -63,6 +63,22 @@ def test_fused_eval_sh_matches_reference(deg):
 
 
 @pytest.mark.gpu
+def test_fused_eval_sh_degree_4_matches_reference():
+    """degree 4 exists only in the reference's Python eval_sh (utils/sh_utils.py:101-111); golden from the real function"""
+    import os
+    from sfgs.sh import eval_sh
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_sh4.npz"))
+    dev = "cuda:0"
+    sh = torch.tensor(z["sh"], device=dev, requires_grad=True)
+    dirs = torch.tensor(z["dirs"], device=dev, requires_grad=True)
+    out = eval_sh(4, sh, dirs)
+    (out * torch.tensor(z["w"], device=dev)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(sh.grad.cpu().numpy(), z["g_sh"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(dirs.grad.cpu().numpy(), z["g_dirs"], rtol=RTOL, atol=10 * ATOL)
+
+
+@pytest.mark.gpu
 def test_views_leading_dims_and_install():
     """render()'s `convert_SHs_python` path hands eval_sh a transposed (non-contiguous) view of get_features
     (gaussian_renderer/__init__.py:121-124); the appearance path a contiguous tensor with K > (active_deg+1)^2."""
