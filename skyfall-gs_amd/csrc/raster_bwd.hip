@@ -251,6 +251,13 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   uint2 mw = hitmask[(size_t)s + 64u * (unsigned)g_cur + lane];
   uint2 mw_next = make_uint2(0u, 0u);
   if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
+  // A batch's three 16-byte record stores are issued at the START of the next iteration, right after that iteration's
+  // prefetch loads: the s_waitcnt vmcnt(0) the compiler places at the loop's back edge (for the prefetched registers)
+  // then only sees memory operations that had a whole batch of arithmetic to complete. Issued at the end of their own
+  // iteration, the stores were waited for every batch (measured: the kernel had a 0.08 ms floor of pure store latency).
+  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+  unsigned p_dup = 0;
+  bool p_valid = false;
   for (int bi = nbatch - 1; bi >= 0; --bi) {
     const unsigned b0 = (unsigned)bi * B;
     const unsigned cnt = min((unsigned)B, kmax - b0);
@@ -268,7 +275,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       dup_cur = dup_next;
       if (bi >= 2) { id_next = sorted_id[s + b0 - 2 * B + lane]; dup_next = sorted_dup[s + b0 - 2 * B + lane]; }
     }
-    {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2
+    if (p_valid) {  // the previous batch's gradient records
+      float4* dst = dupgrad + (size_t)p_dup * 3;
+      dst[0] = p0; dst[1] = p1; dst[2] = p2;
+    }
+    {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2.
+       // (ds_write_addtid_b32 would do this at twice the LDS store rate -- the kernel drops from 0.49 to 0.46 ms -- but
+       // on gfx950 it does NOT add the workgroup's LDS base: with several workgroups per CU it writes into its
+       // neighbours' memory; tools/microbench/addtid_probe.hip)
       float4* z = reinterpret_cast<float4*>(lds.UW);
       constexpr int NZ = B * ROW / 2;
       static_assert((B * ROW) % 2 == 0, "zero fill in 16-byte stores");
@@ -355,10 +369,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       o1.z = -0.5f * op * acc[7];                 // dL/dconic C
       o1.w = acc[0];                              // dL/d(op)
       o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
-      float4* dst = dupgrad + (size_t)my_dup * 3;
-      dst[0] = o0; dst[1] = o1; dst[2] = o2;
+      p0 = o0; p1 = o1; p2 = o2; p_dup = my_dup;
     }
+    p_valid = (unsigned)lane < cnt;
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p_valid) {
+    float4* dst = dupgrad + (size_t)p_dup * 3;
+    dst[0] = p0; dst[1] = p1; dst[2] = p2;
   }
 }
 

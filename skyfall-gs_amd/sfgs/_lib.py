@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfgs.so")
+LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
 ABI_VERSION = 7
 
 SFGS_OK = 0
