@@ -53,6 +53,19 @@ __device__ __forceinline__ float row_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xf, 0xf, false));
 }
 
+// v_permlane32_swap (gfx950): a' = [a.lo, b.lo], b' = [a.hi, b.hi]  ->  a' + b' = a summed over the two half-waves in
+// lanes 0..31 and b summed over them in lanes 32..63
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// v_permlane16_swap: a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3] (rows of 16 lanes)  ->  a' + b' =
+// a.r0 + a.r1 | b.r0 + b.r1 | a.r2 + a.r3 | b.r2 + b.r3
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct Phase2Acc {
   float u, x, y, ax, ay, xx, xy, yy, r, g, b, d;
 };
@@ -238,12 +251,17 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   unsigned dup_cur = 0, id_next = 0, dup_next = 0;
   {
     const unsigned b0 = (unsigned)(nbatch - 1) * B;
+    // the duplicate index of entry ej is needed by all four lanes (ej, row) of the entry: each stores a quarter of
+    // the entry's gradient record (see the combine step)
+    if ((unsigned)ej < kmax - b0) dup_cur = sorted_dup[s + b0 + ej];
     if ((unsigned)lane < kmax - b0) {
       const unsigned id = sorted_id[s + b0 + lane];
-      dup_cur = sorted_dup[s + b0 + lane];
       n0 = rec[3 * (size_t)id]; n1 = rec[3 * (size_t)id + 1]; n2 = rec[3 * (size_t)id + 2];
     }
-    if (nbatch >= 2 && lane < B) { id_next = sorted_id[s + b0 - B + lane]; dup_next = sorted_dup[s + b0 - B + lane]; }
+    if (nbatch >= 2) {
+      dup_next = sorted_dup[s + b0 - B + ej];
+      if (lane < B) id_next = sorted_id[s + b0 - B + lane];
+    }
   }
   // hit-mask words of the tile's 64-entry groups (one uint2 per pixel and group), fetched one group ahead
   static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
@@ -255,7 +273,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   // prefetch loads: the s_waitcnt vmcnt(0) the compiler places at the loop's back edge (for the prefetched registers)
   // then only sees memory operations that had a whole batch of arithmetic to complete. Issued at the end of their own
   // iteration, the stores were waited for every batch (measured: the kernel had a 0.08 ms floor of pure store latency).
-  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+  float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats grp, 4 + grp, 8 + grp
   unsigned p_dup = 0;
   bool p_valid = false;
   for (int bi = nbatch - 1; bi >= 0; --bi) {
@@ -270,14 +288,17 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // this pixel's blended entries of the batch: bit j <=> entry b0 + j
     unsigned pm = (((bi & 2) ? mw.y : mw.x) >> (16 * (bi & 1))) & 0xffffu;
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
-    if (bi >= 1 && lane < B) {  // batches below the last one are always full
-      n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2];
+    if (bi >= 1) {  // batches below the last one are always full
+      if (lane < B) { n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2]; }
       dup_cur = dup_next;
-      if (bi >= 2) { id_next = sorted_id[s + b0 - 2 * B + lane]; dup_next = sorted_dup[s + b0 - 2 * B + lane]; }
+      if (bi >= 2) {
+        dup_next = sorted_dup[s + b0 - 2 * B + ej];
+        if (lane < B) id_next = sorted_id[s + b0 - 2 * B + lane];
+      }
     }
     if (p_valid) {  // the previous batch's gradient records
-      float4* dst = dupgrad + (size_t)p_dup * 3;
-      dst[0] = p0; dst[1] = p1; dst[2] = p2;
+      float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
+      dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
     }
     {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2.
        // (ds_write_addtid_b32 would do this at twice the LDS store rate -- the kernel drops from 0.49 to 0.46 ms -- but
@@ -350,33 +371,40 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #undef SFGS_P2
       }
     }
-    // combine the NGRP partial lanes of every entry (fixed order -> deterministic)
-    float acc[12] = {pa.u, pa.x, pa.y, pa.ax, pa.ay, pa.xx, pa.xy, pa.yy, pa.r, pa.g, pa.b, pa.d};
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-#pragma unroll
-      for (int d = B; d < 64; d <<= 1) acc[i] += __shfl_xor(acc[i], d);
-    }
-    if ((unsigned)lane < cnt) {
+    // Combine the four partial lanes (ej, row 0..3) of every entry in a fixed order (deterministic). The record's 12
+    // floats are linear in the sums, so every lane forms them from its PARTIAL sums first; then two rounds of the gfx950
+    // half-wave / row SWAPS reduce two (then four) values per instruction pair and leave float 4 k + row of the record
+    // in lane (ej, row) of register k: 9 v_permlane*_swap + 9 adds instead of 24 ds_bpermute + 24 adds, and each lane
+    // stores three floats (the deferred store needs 3 registers instead of 12).
+    {
       const float sxm = -op * ddelx_dx, sym = -op * ddely_dy;
-      float4 o0, o1, o2;
-      o0.x = sxm * (cA * acc[1] + cB * acc[2]);   // dL/dmean2D x (NDC units)
-      o0.y = sym * (cC * acc[2] + cB * acc[1]);   // dL/dmean2D y
-      o0.z = op * ddelx_dx * acc[3];              // sum |.| x
-      o0.w = op * ddely_dy * acc[4];              // sum |.| y
-      o1.x = -0.5f * op * acc[5];                 // dL/dconic A
-      o1.y = -op * acc[6];                        // dL/dconic B
-      o1.z = -0.5f * op * acc[7];                 // dL/dconic C
-      o1.w = acc[0];                              // dL/d(op)
-      o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
-      p0 = o0; p1 = o1; p2 = o2; p_dup = my_dup;
+      float O[12];
+      O[0] = sxm * (cA * pa.x + cB * pa.y);   // dL/dmean2D x (NDC units)
+      O[1] = sym * (cC * pa.y + cB * pa.x);   // dL/dmean2D y
+      O[2] = op * ddelx_dx * pa.ax;           // sum |.| x
+      O[3] = op * ddely_dy * pa.ay;           // sum |.| y
+      O[4] = -0.5f * op * pa.xx;              // dL/dconic A
+      O[5] = -op * pa.xy;                     // dL/dconic B
+      O[6] = -0.5f * op * pa.yy;              // dL/dconic C
+      O[7] = pa.u;                            // dL/d(op)
+      O[8] = pa.r; O[9] = pa.g; O[10] = pa.b; O[11] = pa.d;
+      float q[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        // halves: lanes 0..31 get O[4k] summed over (row r, row r + 2), lanes 32..63 get O[4k+2]; likewise O[4k+1] / O[4k+3]
+        const float s02 = swap32_add(O[4 * k], O[4 * k + 2]);
+        const float s13 = swap32_add(O[4 * k + 1], O[4 * k + 3]);
+        // rows: row 0 = O[4k], row 1 = O[4k+1], row 2 = O[4k+2], row 3 = O[4k+3], each summed over the four rows
+        q[k] = swap16_add(s02, s13);
+      }
+      pq0 = q[0]; pq1 = q[1]; pq2 = q[2]; p_dup = my_dup;
     }
-    p_valid = (unsigned)lane < cnt;
+    p_valid = (unsigned)ej < cnt;
     __builtin_amdgcn_wave_barrier();
   }
   if (p_valid) {
-    float4* dst = dupgrad + (size_t)p_dup * 3;
-    dst[0] = p0; dst[1] = p1; dst[2] = p2;
+    float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
+    dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
   }
 }
 

@@ -66,6 +66,25 @@ KERNEL(permlane32_swap, "v_permlane32_swap_b32 %0, %1")
 KERNEL(readlane_like_bpermute, "ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)")
 KERNEL(swizzle, "ds_swizzle_b32 %0, %0 offset:0x401f\n s_waitcnt lgkmcnt(0)")
 
+// packed-f32 forms (VOP3P): operands are 64-bit register pairs, 2 FMAs per lane and instruction
+#define PK_KERNEL(NAME, ASMSTR)                                                                       \
+  __global__ void __launch_bounds__(256, 4) k_##NAME(float* out, float a, float b, int iters) {      \
+    v2f x[8];                                                                                         \
+    for (int i = 0; i < 8; ++i) { x[i].x = threadIdx.x * 0.001f + i; x[i].y = x[i].x + 0.5f; }        \
+    const v2f a2 = {a, b}, b2 = {b, a};                                                               \
+    for (int it = 0; it < iters; ++it) {                                                              \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASMSTR : "+v"(x[i]) : "v"(a2), "v"(b2)); \
+    }                                                                                                 \
+    float s = 0;                                                                                      \
+    for (int i = 0; i < 8; ++i) s += x[i].x + x[i].y;                                                 \
+    out[blockIdx.x * 256 + threadIdx.x] = s;                                                          \
+  }
+PK_KERNEL(pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
+PK_KERNEL(pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+PK_KERNEL(pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+PK_KERNEL(pk_fma_opsel, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]")
+KERNEL(permlane16_swap, "v_permlane16_swap_b32 %0, %1")
+
 // LDS forms: 8 independent accesses per iteration, then one wait
 #define LDS_KERNEL(NAME, BODY)                                                                         \
   __global__ void __launch_bounds__(256, 4) k_##NAME(float* out, float a, float b, int iters) {       \
@@ -122,7 +141,7 @@ int main() {
   Entry tab[] = {E(fma, 8), E(fmac, 8), E(fmac_dpp_bcast, 8), E(fma_abs, 8), E(mul, 8), E(add, 8), E(sub_dpp, 8),
                  E(min_f32, 8), E(mov, 8), E(mad_u24, 8), E(lshl_add, 8), E(ffbh, 8), E(bfe, 8), E(min_u32, 8),
                  E(xor_b32, 8), E(lshlrev, 8), E(add_u32, 8), E(sub_u32, 8), E(and_b32, 8), E(or_b32, 8), E(and_or, 8), E(lshl_or, 8), E(max_f32, 8), E(med3_f32, 8), E(mul_u24, 8), E(mul_e64_neg, 8), E(sub_f32, 8), E(fma_sgpr_lit, 8), E(add_dpp_quad, 8), E(add_dpp_rowshr, 8), E(bcnt, 8), E(exp, 8), E(rcp, 8), E(cmp_vcc, 8), E(cndmask_vcc, 8), E(cmp_cndmask, 16),
-                 E(mov_dpp_quad, 8), E(permlane32_swap, 8), E(readlane_like_bpermute, 8), E(swizzle, 8),
+                 E(mov_dpp_quad, 8), E(permlane32_swap, 8), E(permlane16_swap, 8), E(pk_fma_f32, 8), E(pk_mul_f32, 8), E(pk_add_f32, 8), E(pk_fma_opsel, 8), E(readlane_like_bpermute, 8), E(swizzle, 8),
                  E(ds_read_b128_seq, 8), E(ds_read_b128_rec16, 8), E(ds_read_b64_row, 8), E(ds_read_b32_row, 8),
                  E(ds_write_b64_row, 8), E(ds_write_b32_row, 8), E(ds_write_b128_seq, 8)};
   const int nblk = 4096;  // 16 blocks per CU: every SIMD always has 4 resident waves
