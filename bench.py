@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--d2h-async", action="store_true", help="with --forward-only: download every frame through sfgs.video.FrameDownloader (pinned ring, side stream; informational)")
     ap.add_argument("--d2h-copy", action="store_true", help="with --forward-only: copy every frame to the host like render_video.py:181 (informational; never the headline value)")
     ap.add_argument("--sh-degree", type=int, default=-1, help=">= 0: colour path B (in-kernel SH of this degree) instead of colors_precomp")
+    ap.add_argument("--order", choices=["random", "morton"], default="random",
+                    help="storage order of the Gaussians: 'random' (the headline: worst case for the id -> record gathers) "
+                         "or 'morton' (sorted along a Z-curve of the ground position; informational)")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-only", action="store_true", help="run only the CPU-baseline legs and print them")
     args = ap.parse_args()
@@ -105,6 +108,10 @@ def main():
     W, H, N = args.width, args.height, args.n
     sh = args.sh_degree
     frame, g = scene(N, W, H, seed=rank) if sh < 0 else scene(N, W, H, seed=rank, mode="sh", sh_degree=sh)
+    if args.order == "morton":
+        from sfgs.synth import morton_order
+        perm = morton_order(g["means3D"])
+        g = {k: (v[perm].contiguous() if v is not None else None) for k, v in g.items()}
     gc, gd = upstream_grads(W, H, rank)
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"],

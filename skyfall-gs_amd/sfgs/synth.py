@@ -55,6 +55,18 @@ def scene(n, W, H, seed=0, zrange=(250.0, 350.0), scale_range=(0.05, 0.6), fovx_
     return frame, out
 
 
+def morton_order(means3D, bits=10):
+    """Permutation that sorts points along a Z-curve of their (x / z, y / z) direction, 2^bits cells per axis."""
+    d = (means3D[:, :2] / means3D[:, 2:3]).double()
+    lo, hi = d.min(0).values, d.max(0).values
+    q = ((d - lo) / (hi - lo).clamp_min(1e-30) * (2 ** bits - 1)).long().clamp(0, 2 ** bits - 1)
+    key = torch.zeros(means3D.shape[0], dtype=torch.int64)
+    for b in range(bits):
+        key |= ((q[:, 0] >> b) & 1) << (2 * b)
+        key |= ((q[:, 1] >> b) & 1) << (2 * b + 1)
+    return torch.argsort(key, stable=True)
+
+
 def upstream_grads(W, H, seed=0):
     """dL/dimage, dL/ddepth ~ N(0,1)/P."""
     gen = torch.Generator().manual_seed(1000 + seed)

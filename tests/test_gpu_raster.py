@@ -18,6 +18,9 @@ CASES = {
     "sh1_ragged": dict(n=5000, W=130, H=77, kw=dict(zrange=(2., 50.), scale_range=(0.01, 2.0), mode="sh",
                                                      sh_degree=1)),
     "cfg2_like": dict(n=60000, W=480, H=270, kw=dict(zrange=(250., 350.), scale_range=(0.2, 2.4))),
+    # the same Gaussians stored along a Z-curve of their screen position: lanes of a wave append to the SAME coarse bin
+    # (run-merged atomics in the binning emission)
+    "cfg2_like_zcurve": dict(n=60000, W=480, H=270, kw=dict(zrange=(250., 350.), scale_range=(0.2, 2.4)), zcurve=True),
     "big_splats": dict(n=400, W=256, H=192, kw=dict(zrange=(3., 6.), scale_range=(0.3, 2.0))),
     # splats that cover thousands of 8x8 tiles each: the chunked parallel reduction of their gradient records
     # (dupgrad_reduce_kernel, > 2048 duplicates per Gaussian) and the wave-cooperative binning walk
@@ -69,6 +72,10 @@ def run_hip(frame, g, gc=None, gd=None, backward=True, debug=True, depth_mode=0,
 def test_forward_backward_parity(case):
     c = CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=7, **c["kw"])
+    if c.get("zcurve"):
+        from sfgs.synth import morton_order
+        perm = morton_order(g["means3D"])
+        g = {k: (v[perm].contiguous() if v is not None else None) for k, v in g.items()}
     R = orc.OracleRender(frame, **g)
     gc, gd = upstream_grads(c["W"], c["H"], 0)
     gd = gd.clone()

@@ -51,7 +51,7 @@ for name, c in REGIMES.items():
                                 opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
         torch.autograd.backward([color, torch.nan_to_num(depth)], [gc, gd])
     collect_full_counters(True); step(); cnt = last_counters(); collect_full_counters(False)
-    for _ in range(3):
+    for _ in range(10):    # the caching allocator settles (the capacity hint of the previous regime shrinks over a few frames)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

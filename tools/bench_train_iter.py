@@ -29,7 +29,10 @@ bg = torch.zeros(3, device="cuda")
 hooks = [(prepass, loop.GaussianModel), (densify_stats, loop.GaussianModel), (adam, loop.GaussianModel),
          (compact, loop.GaussianModel), (sh, loop.renderer)]
 out = {"N": N, "W": W, "H": H}
+only = os.environ.get("ONLY", "")          # "fused" / "torch": run one variant (for rocprofv3 kernel statistics)
 for fused in (False, True):
+    if only and only != ("fused" if fused else "torch"):
+        continue
     if fused:
         for mod, target in hooks:
             mod.install(target)
@@ -59,5 +62,6 @@ for fused in (False, True):
             mod.uninstall(target)
     del model
     torch.cuda.empty_cache()
-out["speedup"] = round(out["torch_around_ms"] / out["fused_hooks_ms"], 2)
+if not only:
+    out["speedup"] = round(out["torch_around_ms"] / out["fused_hooks_ms"], 2)
 print(json.dumps(out))
