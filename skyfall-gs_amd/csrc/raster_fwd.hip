@@ -63,7 +63,8 @@ __device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, co
   return m;
 }
 
-constexpr int BIG_WALK = 6;  // coarse bins above which a splat's walk is done by the whole wave
+constexpr int BIG_WALK = 6;  // coarse bins above which a splat's walk is done by a whole wave (big_walk_kernel)
+constexpr int BIG_WALK_BLOCKS = 256;    // persistent grid of big_walk_kernel: 1 024 waves = 1 per SIMD (an empty list costs one short dispatch)
 static_assert(BIG_WALK <= 8, "the per-lane walk keeps one 16-bit mask per coarse bin in two 64-bit registers");
 
 struct WalkArgs { SplatRec r; BinRange br; float thr; int cx0, cx1, cy0, cy1; };
@@ -121,7 +122,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
-                  uint2* __restrict__ big_chunks, unsigned big_chunk_cap, unsigned long long* __restrict__ hdr) {
+                  uint4* __restrict__ big_list, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
   __shared__ unsigned long long s_base;
   const FrameParams f = load_frame(kf);
@@ -130,7 +131,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const int CX = (((f.W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
   unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
   unsigned long long mask_lo = 0ull, mask_hi = 0ull;  // 16-bit tile masks of the (<= BIG_WALK) coarse bins of the walk
-  bool big = false;                  // walk handled cooperatively by the wave
+  bool big = false;                  // walk handled cooperatively by the wave (BIG_WALK < coarse bins < 64)
+  bool huge = false;                 // >= 64 coarse bins: walked by big_walk_kernel
   const int lane = threadIdx.x & 63;
   SplatRec r;
   BinRange br;
@@ -167,8 +169,10 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       if (br.x1 > br.x0 && br.y1 > br.y0) {
         cx0 = br.x0 / COARSE; cx1 = (br.x1 - 1) / COARSE + 1;
         cy0 = br.y0 / COARSE; cy1 = (br.y1 - 1) / COARSE + 1;
-        big = (cx1 - cx0) * (cy1 - cy0) > BIG_WALK;
-        if (!big) {
+        const int ncb_ = (cx1 - cx0) * (cy1 - cy0);
+        huge = ncb_ >= 64;
+        big = ncb_ > BIG_WALK && !huge;
+        if (ncb_ <= BIG_WALK) {
           // ONE flat loop over the tiles of the walk range (a 4-deep coarse-bin x tile loop nest with per-lane
           // bounds costs as much in divergent loop control as the tile tests themselves); hits are ORed into the
           // 16-bit mask of their coarse bin, BIG_WALK (= 6) masks = 96 bits in two registers
@@ -187,28 +191,34 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       }
     }
   }
-  // Splats that reach many coarse bins (near or huge: up to the whole screen) are walked by the whole wave,
-  // one coarse bin per lane, instead of serially by their owner thread.
+  // Mid-size splats (more than BIG_WALK, fewer than 64 coarse bins) are walked by the whole wave, lane = tile, instead
+  // of serially by their owner thread.
   const unsigned long long big_lanes = __ballot(big);
   for (unsigned long long bl = big_lanes; bl; bl &= bl - 1) {
     const int L = __builtin_ctzll(bl);
     const WalkArgs a = broadcast_walk(r, br, thr, cx0, cx1, cy0, cy1, L);
-    const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
+    const int ncb = (a.cx1 - a.cx0) * (a.cy1 - a.cy0);
     unsigned total = 0;
-    if (ncb < 64) {  // mid-size splat: lane = tile keeps the wave full
-      for (int it = 0; it * 4 < ncb; ++it) {
-        int cb;
-        total += (unsigned)__popcll(walk_ballot4(a, it, lane, f.W, f.H, bound, &cb, CX));
-      }
-    } else {         // huge splat: lane = coarse bin (16 tile tests per lane and iteration, index math amortised)
-      for (int i0 = 0; i0 < ncb; i0 += 64) {
-        const int i = i0 + lane;
-        unsigned c = 0;
-        if (i < ncb) c = (unsigned)__popc(coarse_hits(a.r, a.thr, a.br, a.cx0 + i % nx, a.cy0 + i / nx, f.W, f.H, bound));
-        total += wave_sum_u32(c);
-      }
+    for (int it = 0; it * 4 < ncb; ++it) {
+      int cb;
+      total += (unsigned)__popcll(walk_ballot4(a, it, lane, f.W, f.H, bound, &cb, CX));
     }
     if (lane == L) n_dup = total;
+  }
+  // Huge splats (64 coarse bins and more, up to the whole screen) are not walked here: they go to the work list of
+  // big_walk_kernel, which spreads them over the whole chip one wave per splat (walked by the wave that owns them,
+  // 2 000 screen-filling splats kept 8 waves busy for 10 ms while the other 4 000 wave slots idled). That kernel also
+  // reserves their duplicate indices and writes their dup_out entry.
+  const unsigned long long huge_lanes = __ballot(huge);
+  if (huge_lanes) {
+    unsigned long long slot0 = 0ull;
+    if (lane == 0) slot0 = atomicAdd(&hdr[HDR_BIG_COUNT], (unsigned long long)__popcll(huge_lanes));
+    const unsigned s_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)slot0);
+    if (huge) {
+      const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(huge_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)huge_lanes, 0u));
+      big_list[s_lo + rk] = make_uint4((unsigned)g, (unsigned)br.x0 | ((unsigned)br.x1 << 16),
+                                       (unsigned)br.y0 | ((unsigned)br.y1 << 16), 0u);
+    }
   }
   // reserve duplicate indices: block scan + one returning atomic per block
   unsigned total;
@@ -218,14 +228,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const unsigned long long base = s_base;
   const bool fits = base + total <= dup_capacity;
   if (!fits && threadIdx.x == 0) hdr[HDR_OVERFLOW] = 1ull;
-  if (g < N) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
-  if (fits && n_dup > BWD_BIG) {  // rare: list this Gaussian's records in chunks for the backward's parallel reduction
-    const unsigned nch = (n_dup + BWD_CHUNK - 1) / BWD_CHUNK;
-    const unsigned long long cb0 = atomicAdd(&hdr[HDR_BIG_CHUNKS], (unsigned long long)nch);
-    if (cb0 + nch <= big_chunk_cap)
-      for (unsigned c = 0; c < nch; ++c) big_chunks[cb0 + c] = make_uint2((unsigned)g, c);
-    else hdr[HDR_OVERFLOW] = 1ull;   // cannot happen while dup_capacity >= D (big_chunk_capacity's bound); kept for safety
-  }
+  if (g < N && !huge) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
   {
     // Emission, one coarse bin of the walk per iteration and lane. Lanes that append to the SAME bin in the same
     // iteration -- the rule rather than the exception when the Gaussians are stored in a spatially coherent order
@@ -265,28 +268,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     const WalkArgs a = broadcast_walk(r, br, thr, cx0, cx1, cy0, cy1, L);
     const unsigned g_L = (unsigned)__shfl((int)g, L), depth_L = __shfl(depth_bits, L);
     unsigned dup = __shfl((unsigned)(base + ex), L);
-    const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
-    if (ncb >= 64) {
-      for (int i0 = 0; i0 < ncb; i0 += 64) {
-        const int i = i0 + lane;
-        unsigned m = 0;
-        int cb = 0;
-        if (i < ncb) {
-          const int cx = a.cx0 + i % nx, cy = a.cy0 + i / nx;
-          m = coarse_hits(a.r, a.thr, a.br, cx, cy, f.W, f.H, bound);
-          cb = cy * CX + cx;
-        }
-        const unsigned c = (unsigned)__popc(m);
-        const unsigned incl = wave_incl_scan_u32(c);
-        if (m) {
-          const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
-          if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + incl - c, m);
-          else hdr[HDR_OVERFLOW] = 1ull;
-        }
-        dup += __shfl(incl, 63);
-      }
-      continue;
-    }
+    const int ncb = (a.cx1 - a.cx0) * (a.cy1 - a.cy0);
     for (int it = 0; it * 4 < ncb; ++it) {
       int cb;
       const unsigned long long bal = walk_ballot4(a, it, lane, f.W, f.H, bound, &cb, CX);
@@ -306,6 +288,90 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   if (threadIdx.x == 0) block_nvis[blockIdx.x] = total;
   block_excl_scan_u32<PRE_BLOCK>(dref, &total, s_red);
   if (threadIdx.x == 0) block_dref[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b: the binning walk of the splats preprocess_kernel listed as huge (64 coarse bins and more), ONE WAVE PER SPLAT,
+// persistent waves over the work list. Two passes over the splat's coarse bins, lane = coarse bin: count the hit
+// tiles, reserve the duplicate indices (one atomic per splat), then emit one item per non-empty coarse bin.
+// (Mid-size splats stay with the wave that owns them: sent here too, every splat pays the latency chain list entry ->
+// record -> walk -> atomic -> stores on its own, and a pitched camera's 600 k mid-size splats took 1.2 ms instead of 0.45.)
+__global__ void __launch_bounds__(256)
+big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __restrict__ rec,
+                uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count, uint4* __restrict__ slabs,
+                unsigned coarse_capacity, unsigned long long dup_capacity, uint2* __restrict__ big_chunks,
+                unsigned big_chunk_cap, unsigned long long* __restrict__ hdr) {
+  const unsigned n_big = (unsigned)hdr[HDR_BIG_COUNT];
+  const int lane = threadIdx.x & 63;
+  const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+  const int W = kf.W, H = kf.H;
+  const int CX = (((W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
+  const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
+  for (unsigned i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_big; i += nwaves) {
+    const uint4 it = big_list[i];
+    const unsigned g = it.x;
+    const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
+    WalkArgs a;
+    a.r.mx = r0.x; a.r.my = r0.y; a.r.qa = r0.z; a.r.qb = r0.w; a.r.qc = r1.x; a.r.op = r1.y; a.r.depth = r1.z;
+    a.r.r = a.r.g = a.r.b = 0.f; a.r.ex = r2.z; a.r.ey = r2.w;
+    a.br.x0 = (int)(it.y & 0xffffu); a.br.x1 = (int)(it.y >> 16);
+    a.br.y0 = (int)(it.z & 0xffffu); a.br.y1 = (int)(it.z >> 16);
+    a.thr = alpha_threshold_log2(a.r.op);
+    a.cx0 = a.br.x0 / COARSE; a.cx1 = (a.br.x1 - 1) / COARSE + 1;
+    a.cy0 = a.br.y0 / COARSE; a.cy1 = (a.br.y1 - 1) / COARSE + 1;
+    const unsigned depth_bits = __float_as_uint(a.r.depth);
+    const int nx = a.cx1 - a.cx0, ncb = nx * (a.cy1 - a.cy0);
+    // pass 1: count
+    unsigned total = 0;   // lane = coarse bin (16 tile tests per lane and iteration, index math amortised)
+    for (int i0 = 0; i0 < ncb; i0 += 64) {
+      const int j = i0 + lane;
+      unsigned c = 0;
+      if (j < ncb) c = (unsigned)__popc(coarse_hits(a.r, a.thr, a.br, a.cx0 + j % nx, a.cy0 + j / nx, W, H, bound));
+      total += wave_sum_u32(c);
+    }
+    // reserve the duplicate indices
+    unsigned long long base = 0ull;
+    if (lane == 0 && total) base = atomicAdd(&hdr[HDR_D_EFF], (unsigned long long)total);
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    const bool fits = base + total <= dup_capacity;
+    if (lane == 0) {
+      dup_out[g] = make_uint2((unsigned)base, total);
+      if (!fits) hdr[HDR_OVERFLOW] = 1ull;
+    }
+    if (!fits || total == 0) continue;
+    if (total > BWD_BIG) {  // list this Gaussian's records in chunks for the backward's parallel reduction
+      const unsigned nch = (total + BWD_CHUNK - 1) / BWD_CHUNK;
+      unsigned long long cb0 = 0ull;
+      if (lane == 0) cb0 = atomicAdd(&hdr[HDR_BIG_CHUNKS], (unsigned long long)nch);
+      const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cb0);
+      if ((unsigned long long)c0 + nch <= big_chunk_cap) {
+        for (unsigned c = lane; c < nch; c += 64) big_chunks[c0 + c] = make_uint2(g, c);
+      } else if (lane == 0) {
+        hdr[HDR_OVERFLOW] = 1ull;   // cannot happen while dup_capacity >= D (big_chunk_capacity's bound); kept for safety
+      }
+    }
+    // pass 2: emit
+    unsigned dup = (unsigned)base;
+    for (int i0 = 0; i0 < ncb; i0 += 64) {
+      const int j = i0 + lane;
+      unsigned m = 0;
+      int cb = 0;
+      if (j < ncb) {
+        const int cx = a.cx0 + j % nx, cy = a.cy0 + j / nx;
+        m = coarse_hits(a.r, a.thr, a.br, cx, cy, W, H, bound);
+        cb = cy * CX + cx;
+      }
+      const unsigned c = (unsigned)__popc(m);
+      const unsigned incl = wave_incl_scan_u32(c);
+      if (m) {
+        const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+        if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g, depth_bits, dup + incl - c, m);
+        else hdr[HDR_OVERFLOW] = 1ull;
+      }
+      dup += __shfl(incl, 63);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -966,9 +1032,13 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   hipLaunchKernelGGL((preprocess_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,    \
                      g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,   \
                      bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,            \
-                     tv.block_dref, bv.big_chunks, (unsigned)big_chunk_capacity(dup_capacity), tv.hdr)
+                     tv.block_dref, gv.big_list, tv.hdr)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
+      // the big splats' walk: persistent waves over the work list (returns at once when the list is empty)
+      hipLaunchKernelGGL(big_walk_kernel, dim3(BIG_WALK_BLOCKS), dim3(256), 0, stream, kf, gv.big_list, gv.rec, gv.dup,
+                         tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity,
+                         bv.big_chunks, (unsigned)big_chunk_capacity(dup_capacity), tv.hdr);
     }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }

@@ -113,19 +113,25 @@ enum HeaderSlot {
   HDR_ITEM_ALLOC = 6,    // list-slot allocator of the fine-binning kernel
   HDR_MAX_COARSE = 7,    // fullest coarse bin (sizes coarse_capacity for the next frame)
   HDR_LONG_COUNT = 8,    // tiles whose list is too long for the register sort (> 512 entries)
-  HDR_BIG_CHUNKS = 9     // entries of BinsView::big_chunks (1024-record chunks of Gaussians with > BWD_BIG duplicates)
+  HDR_BIG_CHUNKS = 9,    // entries of BinsView::big_chunks (1024-record chunks of Gaussians with > BWD_BIG duplicates)
+  HDR_BIG_COUNT = 10     // entries of GeomView::big_list (splats whose binning walk is done by big_walk_kernel)
 };
 
 struct GeomView {
-  float4* rec;   // [N][3] float4 = SplatRec
-  uint2* dup;    // [N] (first duplicate index, duplicate count) of every Gaussian
+  float4* rec;      // [N][3] float4 = SplatRec
+  uint2* dup;       // [N] (first duplicate index, duplicate count) of every Gaussian
+  uint4* big_list;  // [N] work list of big_walk_kernel: (Gaussian id, tile range x0 | x1 << 16, y0 | y1 << 16, 0);
+                    //     HDR_BIG_COUNT entries, written only for splats that reach more than BIG_WALK coarse bins
 };
-static inline size_t geom_bytes(int64_t N) { return align_up((size_t)N * 48, 256) + align_up((size_t)N * 8, 256); }
+static inline size_t geom_bytes(int64_t N) {
+  return align_up((size_t)N * 48, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N * 16, 256);
+}
 static inline GeomView geom_view(void* base, int64_t N) {
   GeomView g;
   char* p = (char*)base;
   g.rec = (float4*)p; p += align_up((size_t)N * 48, 256);
-  g.dup = (uint2*)p;
+  g.dup = (uint2*)p; p += align_up((size_t)N * 8, 256);
+  g.big_list = (uint4*)p;
   return g;
 }
 

@@ -55,6 +55,32 @@ def scene(n, W, H, seed=0, zrange=(250.0, 350.0), scale_range=(0.05, 0.6), fovx_
     return frame, out
 
 
+def orbit_scene(n, W, H, elevation_deg, seed=0, radius=420.0, extent=170.0, height=25.0, scale_range=(0.05, 0.6),
+                fovx_deg=60.0, opacity_range=(0.05, 0.95), kernel_size=0.1):
+    """A city-like slab (x, y in [-extent, extent], z in [0, height], z up) seen from an orbit camera that looks at the
+    origin from `elevation_deg` above the horizon -- the pseudo-camera geometry of the reference's IDU stage
+    (train.py:364-420: elevations 85..45 degrees, 25 in one schedule). colors_precomp mode."""
+    gen = torch.Generator().manual_seed(seed)
+    fovx = math.radians(fovx_deg)
+    fovy = fovy_from_fovx(fovx, W, H)
+    xy = torch.empty(n, 2).uniform_(-extent, extent, generator=gen)
+    z = torch.empty(n, 1).uniform_(0.0, height, generator=gen)
+    lo, hi = math.log(scale_range[0]), math.log(scale_range[1])
+    out = dict(means3D=torch.cat([xy, z], 1).contiguous(),
+               scales=torch.exp(torch.empty(n, 3).uniform_(lo, hi, generator=gen)), rotations=_unit_quats(n, gen),
+               opacities=torch.empty(n, 1).uniform_(opacity_range[0], opacity_range[1], generator=gen),
+               colors_precomp=torch.rand(n, 3, generator=gen), shs=None)
+    e = math.radians(elevation_deg)
+    C = np.array([radius * math.cos(e), 0.0, radius * math.sin(e)])
+    f = -C / np.linalg.norm(C)                      # camera z: forward
+    r = np.cross(f, np.array([0.0, 0.0, 1.0]))
+    r = r / np.linalg.norm(r) if np.linalg.norm(r) > 1e-9 else np.array([0.0, 1.0, 0.0])   # camera x: right
+    d = np.cross(f, r)                              # camera y: down
+    R = np.stack([r, d, f], 1)                      # camera-to-world rotation (columns = camera axes)
+    t = -R.T @ C                                    # world-to-camera translation
+    return make_frame(R, t, fovx, fovy, W, H, kernel_size=kernel_size), out
+
+
 def morton_order(means3D, bits=10):
     """Permutation that sorts points along a Z-curve of their (x / z, y / z) direction, 2^bits cells per axis."""
     d = (means3D[:, :2] / means3D[:, 2:3]).double()

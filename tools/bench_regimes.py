@@ -13,11 +13,14 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "skyfall-gs_amd"))
 from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, collect_full_counters, last_counters  # noqa: E402
 from sfgs import _lib as L  # noqa: E402
-from sfgs.synth import scene, upstream_grads  # noqa: E402
+from sfgs.synth import orbit_scene, scene, upstream_grads  # noqa: E402
 
 REGIMES = {
     "headline_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw={}),
     "low_elevation_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw=dict(pitch_deg=45.0, zrange=(40.0, 400.0))),
+    # the IDU stage's orbit cameras over a city-like slab (train.py:364-420): elevation 45 and 25 degrees
+    "orbit_e45_2M_1080p": dict(n=2_000_000, W=1920, H=1080, orbit=45.0),
+    "orbit_e25_2M_1080p": dict(n=2_000_000, W=1920, H=1080, orbit=25.0),
     "near_big_splats_200k": dict(n=200_000, W=1920, H=1080, kw=dict(zrange=(3.0, 6.0), scale_range=(0.01, 0.3))),
     "screen_filling_2k": dict(n=2_000, W=1920, H=1080, kw=dict(zrange=(3.0, 6.0), scale_range=(0.5, 3.0), opacity_range=(0.01, 0.05))),
     "tiny_scene_1k": dict(n=1_000, W=1920, H=1080, kw={}),
@@ -32,7 +35,10 @@ only = sys.argv[1:]
 for name, c in REGIMES.items():
     if only and name not in only:
         continue
-    frame, g = scene(c["n"], c["W"], c["H"], seed=0, **c["kw"])
+    if "orbit" in c:
+        frame, g = orbit_scene(c["n"], c["W"], c["H"], c["orbit"], seed=0)
+    else:
+        frame, g = scene(c["n"], c["W"], c["H"], seed=0, **c["kw"])
     gc, gd = (t.to(dev) for t in upstream_grads(c["W"], c["H"], 0))
     sub = torch.zeros(c["H"], c["W"], 2) if c.get("zero_subpix") else frame.get("subpix")
     settings = GaussianRasterizationSettings(
