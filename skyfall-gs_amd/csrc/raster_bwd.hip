@@ -184,7 +184,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, const uint2* __restrict__ hitmask,
-                     float4* __restrict__ dupgrad, const unsigned long long* __restrict__ hdr) {
+                     const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad,
+                     const unsigned long long* __restrict__ hdr) {
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[4];
   const unsigned sb = xcd_remap(blockIdx.x, nblk);
@@ -227,16 +228,16 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-  unsigned kmax = last;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, d));
-  kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)kmax);
+  const unsigned kmax = tile_kmax[t];   // max of `last` over the tile's pixels (written by the forward; scalar load)
 
-  // list entries behind every pixel's last contributor receive zero gradient
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (unsigned k = kmax + lane; k < L; k += 64) {
-    float4* dst = dupgrad + (size_t)sorted_dup[s + k] * 3;
-    dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
+  // list entries behind every pixel's last contributor receive zero gradient -- unless dupgrad_prefill_kernel found so
+  // many of them in this frame that it zeroed the whole record array with streaming stores instead
+  if ((unsigned)hdr[HDR_PREFILLED] == 0u) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned k = kmax + lane; k < L; k += 64) {
+      float4* dst = dupgrad + (size_t)sorted_dup[s + k] * 3;
+      dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
+    }
   }
   if (kmax == 0) return;
 
@@ -406,6 +407,44 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
     dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
   }
+}
+
+// Dead list entries -- behind their tile's last contributor: opaque surfaces seen at a low angle leave a third to a
+// half of every list dead, near-camera overdraw 95 % -- still own a gradient record that preprocess_bwd adds up, so it
+// has to read zero. One scattered 48-byte store per dead entry costs ~38 ps (near-camera regime: 4.4 of 4.8 ms of
+// composite_bwd); zeroing the WHOLE array with streaming stores costs ~10 ps per entry, dead or alive. The training
+// forward leaves every tile's dead-entry count (tile_dead); this kernel sums them, fills when prefill_wanted() says
+// so, and publishes the decision in hdr[HDR_PREFILLED] for composite_bwd, which then skips its zero records.
+// (On the headline scene 0.1 % are dead: the kernel returns after the sum.)
+__global__ void __launch_bounds__(256)
+dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned long long n_dup,
+                       float4* __restrict__ dupgrad, unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned part[4];
+  // every workgroup sums the per-tile counts for itself (2 bytes per tile, 16-byte loads: 64 KB from L2 at 1080p)
+  unsigned dead = 0;   // <= 65535 * T8 < 2^32 up to 65 k tiles... accumulate in 64 bits across lanes below
+  unsigned long long dead64 = 0ull;
+  const uint4* v = reinterpret_cast<const uint4*>(tile_dead);
+  const int n8 = T8 / 8;
+  for (int i = threadIdx.x; i < n8; i += 256) {
+    const uint4 q = v[i];
+    dead += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16) + (q.z & 0xffffu) + (q.z >> 16) +
+            (q.w & 0xffffu) + (q.w >> 16);
+    if (dead > 0x7fffffffu) { dead64 += dead; dead = 0; }
+  }
+  for (int t = n8 * 8 + threadIdx.x; t < T8; t += 256) dead += tile_dead[t];
+  dead64 += dead;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) dead64 += (unsigned long long)__shfl_xor((long long)dead64, d);
+  // saturating 32-bit partials are enough for the decision
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (unsigned)min(dead64, 0xffffffffull >> 2);
+  __syncthreads();
+  const unsigned long long total = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+  const bool fill = prefill_wanted(total, n_dup);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HDR_PREFILLED] = fill ? 1ull : 0ull;
+  if (!fill) return;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t n4 = (size_t)n_dup * 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dupgrad[i] = zero4;
 }
 
 // Parallel pre-reduction of the records of Gaussians with more than BWD_BIG duplicates (sfgs_internal.h): one
@@ -586,14 +625,16 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
   const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity, coarse_bins(W, H), coarse_capacity);
-  const ImageView iv = image_view(const_cast<void*>(image), W, H);
+  const ImageView iv = image_view(const_cast<void*>(image), W, H, dup_capacity);
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
+    hipLaunchKernelGGL(dupgrad_prefill_kernel, dim3(512), dim3(256), 0, stream, TX8 * TY8, iv.tile_dead,
+                       (unsigned long long)num_duplicates, (float4*)dupgrad, tv.hdr);
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, iv.hitmask, (float4*)dupgrad, tv.hdr); }
+                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);

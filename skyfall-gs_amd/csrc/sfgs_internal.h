@@ -114,7 +114,9 @@ enum HeaderSlot {
   HDR_MAX_COARSE = 7,    // fullest coarse bin (sizes coarse_capacity for the next frame)
   HDR_LONG_COUNT = 8,    // tiles whose list is too long for the register sort (> 512 entries)
   HDR_BIG_CHUNKS = 9,    // entries of BinsView::big_chunks (1024-record chunks of Gaussians with > BWD_BIG duplicates)
-  HDR_BIG_COUNT = 10     // entries of GeomView::big_list (splats whose binning walk is done by big_walk_kernel)
+  HDR_BIG_COUNT = 10,    // entries of GeomView::big_list (splats whose binning walk is done by big_walk_kernel)
+  HDR_PREFILLED = 11     // backward: 1 when dupgrad_prefill_kernel zeroed the whole record array (composite_bwd then
+                         // skips the entries behind a tile's last contributor), else 0
 };
 
 struct GeomView {
@@ -213,18 +215,29 @@ struct ImageView {
   float* dacc;          // [P] un-normalised accumulated depth
   uint2* hitmask;       // [slot capacity] word (first slot of the tile + 64 b + lane) = which of the 64 entries of the
                         //   tile's b-th batch pixel `lane` BLENDED (bit j of .x: entry j, bit j of .y: entry 32 + j)
+  uint32_t* tile_kmax;  // [T8] list position (1-based) of the tile's LAST contributor = max of n_contrib over its pixels
+  uint16_t* tile_dead;  // [T8] min(65535, list entries behind the last contributor)
 };
 static inline size_t image_bytes(int W, int H, int64_t D) {
-  return 3 * align_up((size_t)W * H * 4, 256) + align_up((size_t)D * 8, 256);
+  return 3 * align_up((size_t)W * H * 4, 256) + align_up((size_t)D * 8, 256) +
+         align_up((size_t)((W + TILE_BIN - 1) / TILE_BIN) * ((H + TILE_BIN - 1) / TILE_BIN) * 4, 256) +
+         align_up((size_t)((W + TILE_BIN - 1) / TILE_BIN) * ((H + TILE_BIN - 1) / TILE_BIN) * 2 + 16, 256);
 }
-static inline ImageView image_view(void* base, int W, int H) {
+static inline ImageView image_view(void* base, int W, int H, int64_t D) {
   ImageView v;
   char* p = (char*)base;
   const size_t plane = align_up((size_t)W * H * 4, 256);
   v.n_contrib = (uint32_t*)p; v.final_T = (float*)(p + plane); v.dacc = (float*)(p + 2 * plane);
   v.hitmask = (uint2*)(p + 3 * plane);
+  v.tile_kmax = (uint32_t*)(p + 3 * plane + align_up((size_t)D * 8, 256));
+  v.tile_dead = (uint16_t*)((char*)v.tile_kmax +
+                            align_up((size_t)((W + TILE_BIN - 1) / TILE_BIN) * ((H + TILE_BIN - 1) / TILE_BIN) * 4, 256));
   return v;
 }
+
+// Backward: do the dead entries make up more than 30 % of the frame's duplicates? Then dupgrad_prefill_kernel zeroes
+// the whole record array with streaming stores and composite_bwd skips its per-entry zero records.
+__host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned long long n_dup) { return dead * 10ull > n_dup * 3ull; }
 
 constexpr int DUPGRAD_FLOATS = 12;  // 48 bytes per duplicate (Grad2D order), three 16-byte stores
 static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }

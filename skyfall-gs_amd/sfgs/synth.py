@@ -81,6 +81,52 @@ def orbit_scene(n, W, H, elevation_deg, seed=0, radius=420.0, extent=170.0, heig
     return make_frame(R, t, fovx, fovy, W, H, kernel_size=kernel_size), out
 
 
+def city_scene(n, W, H, elevation_deg, seed=0, radius=420.0, extent=170.0, n_buildings=300, splat=(0.25, 0.9),
+               opacity_range=(0.6, 0.99), fovx_deg=60.0, kernel_size=0.1):
+    """Opaque SURFACES instead of a transparent volume: a ground plane and `n_buildings` axis-aligned boxes (footprint
+    8..30 m, height 5..45 m), covered with flat, mostly opaque disks (thickness 2 cm, normal = surface normal) -- what a
+    trained urban scene looks like to the rasterizer: pixels saturate after a few splats and most of a tile's list lies
+    BEHIND the last contributor. Same orbit camera as orbit_scene."""
+    gen = torch.Generator().manual_seed(seed)
+    frame, _ = orbit_scene(1, W, H, elevation_deg, seed, radius, extent, fovx_deg=fovx_deg, kernel_size=kernel_size)
+    bx = torch.empty(n_buildings, 2).uniform_(-extent * 0.9, extent * 0.9, generator=gen)
+    bs = torch.empty(n_buildings, 2).uniform_(8.0, 30.0, generator=gen)
+    bh = torch.empty(n_buildings).uniform_(5.0, 45.0, generator=gen)
+    # surface areas: ground, then per building roof + 4 walls
+    areas = [torch.tensor([(2 * extent) ** 2])]
+    areas.append(torch.stack([bs[:, 0] * bs[:, 1], bs[:, 0] * bh, bs[:, 0] * bh, bs[:, 1] * bh, bs[:, 1] * bh], 1).reshape(-1))
+    areas = torch.cat(areas)
+    face = torch.multinomial(areas / areas.sum(), n, replacement=True, generator=gen)
+    u = torch.rand(n, 2, generator=gen)
+    pos = torch.zeros(n, 3)
+    normal_axis = torch.full((n,), 2, dtype=torch.long)      # ground / roofs: normal along z
+    g0 = face == 0
+    pos[g0, 0] = (u[g0, 0] * 2 - 1) * extent
+    pos[g0, 1] = (u[g0, 1] * 2 - 1) * extent
+    fb = (face - 1).clamp_min(0)
+    b, k = fb // 5, fb % 5
+    cx, cy, sx, sy, hh = bx[b, 0], bx[b, 1], bs[b, 0], bs[b, 1], bh[b]
+    roof = (~g0) & (k == 0)
+    pos[roof] = torch.stack([cx + (u[:, 0] - 0.5) * sx, cy + (u[:, 1] - 0.5) * sy, hh], 1)[roof]
+    for kk, (axis, sign) in enumerate([(1, -1.0), (1, 1.0), (0, -1.0), (0, 1.0)], start=1):
+        m = (~g0) & (k == kk)
+        if axis == 1:   # wall facing -y / +y: spans x and z
+            p = torch.stack([cx + (u[:, 0] - 0.5) * sx, cy + sign * 0.5 * sy, u[:, 1] * hh], 1)
+        else:           # wall facing -x / +x: spans y and z
+            p = torch.stack([cx + sign * 0.5 * sx, cy + (u[:, 0] - 0.5) * sy, u[:, 1] * hh], 1)
+        pos[m] = p[m]
+        normal_axis[m] = axis
+    lo, hi = math.log(splat[0]), math.log(splat[1])
+    scales = torch.exp(torch.empty(n, 3).uniform_(lo, hi, generator=gen))
+    scales[torch.arange(n), normal_axis] = 0.02              # flat along the surface normal (axis-aligned: identity rotation)
+    rots = torch.zeros(n, 4)
+    rots[:, 0] = 1.0
+    out = dict(means3D=pos.contiguous(), scales=scales, rotations=rots,
+               opacities=torch.empty(n, 1).uniform_(opacity_range[0], opacity_range[1], generator=gen),
+               colors_precomp=torch.rand(n, 3, generator=gen), shs=None)
+    return frame, out
+
+
 def morton_order(means3D, bits=10):
     """Permutation that sorts points along a Z-curve of their (x / z, y / z) direction, 2^bits cells per axis."""
     d = (means3D[:, :2] / means3D[:, 2:3]).double()

@@ -25,6 +25,8 @@ CASES = {
     # splats that cover thousands of 8x8 tiles each: the chunked parallel reduction of their gradient records
     # (dupgrad_reduce_kernel, > 2048 duplicates per Gaussian) and the wave-cooperative binning walk
     "screen_filling": dict(n=60, W=640, H=400, kw=dict(zrange=(3., 6.), scale_range=(0.5, 3.0), opacity_range=(0.01, 0.05))),
+    # more huge splats than big_walk_kernel has waves (1 024): its persistent loop takes a second round
+    "many_huge": dict(n=1500, W=512, H=384, kw=dict(zrange=(3., 6.), scale_range=(0.6, 3.0), opacity_range=(0.004, 0.02))),
     # the headline scene generator at its full viewport, 1/10 of the Gaussians (the oracle needs ~1 s for it)
     "cfg2_200k_1080p": dict(n=200000, W=1920, H=1080, kw=dict()),
     "cfg4_like_1440p": dict(n=150000, W=2560, H=1440, kw=dict(zrange=(500., 700.))),

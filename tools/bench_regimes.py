@@ -13,7 +13,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "skyfall-gs_amd"))
 from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, collect_full_counters, last_counters  # noqa: E402
 from sfgs import _lib as L  # noqa: E402
-from sfgs.synth import orbit_scene, scene, upstream_grads  # noqa: E402
+from sfgs.synth import city_scene, orbit_scene, scene, upstream_grads  # noqa: E402
 
 REGIMES = {
     "headline_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw={}),
@@ -21,6 +21,10 @@ REGIMES = {
     # the IDU stage's orbit cameras over a city-like slab (train.py:364-420): elevation 45 and 25 degrees
     "orbit_e45_2M_1080p": dict(n=2_000_000, W=1920, H=1080, orbit=45.0),
     "orbit_e25_2M_1080p": dict(n=2_000_000, W=1920, H=1080, orbit=25.0),
+    # opaque surfaces (ground + boxes covered with flat, mostly opaque disks): pixels saturate early, a large part of
+    # every tile list lies behind the last contributor
+    "city_e45_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=45.0),
+    "city_e25_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=25.0),
     "near_big_splats_200k": dict(n=200_000, W=1920, H=1080, kw=dict(zrange=(3.0, 6.0), scale_range=(0.01, 0.3))),
     "screen_filling_2k": dict(n=2_000, W=1920, H=1080, kw=dict(zrange=(3.0, 6.0), scale_range=(0.5, 3.0), opacity_range=(0.01, 0.05))),
     "tiny_scene_1k": dict(n=1_000, W=1920, H=1080, kw={}),
@@ -35,7 +39,9 @@ only = sys.argv[1:]
 for name, c in REGIMES.items():
     if only and name not in only:
         continue
-    if "orbit" in c:
+    if "city" in c:
+        frame, g = city_scene(c["n"], c["W"], c["H"], c["city"], seed=0)
+    elif "orbit" in c:
         frame, g = orbit_scene(c["n"], c["W"], c["H"], c["orbit"], seed=0)
     else:
         frame, g = scene(c["n"], c["W"], c["H"], seed=0, **c["kw"])
