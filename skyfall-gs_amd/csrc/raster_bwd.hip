@@ -169,8 +169,8 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
     const SplatEval e1 = eval_splat(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, sx, sy);
     const SplatEval e2 = eval_splat(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, sx, sy);
     float u1, w1, u2, w2;
-    pixel_bwd_scalars<HAS_BG>(ps, e1, a1.z, a1.w, a2.x, a2.y, u1, w1);
-    pixel_bwd_scalars<HAS_BG>(ps, e2, b1.z, b1.w, b2.x, b2.y, u2, w2);
+    pixel_bwd_scalars<HAS_BG>(ps, e1, a2.y, a1.z, a1.w, a2.x, u1, w1);
+    pixel_bwd_scalars<HAS_BG>(ps, e2, b2.y, b1.z, b1.w, b2.x, u2, w2);
     lds.UW[j1 * ROW + lane] = make_float2(u1, w1);
     lds.UW[j2 * ROW + lane] = make_float2(u2, w2);
   }

@@ -160,8 +160,10 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       }
       r = make_record(pr, opac[g], rgb);
       rec_out[3 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
-      rec_out[3 * (size_t)g + 1] = make_float4(r.qc, r.op, r.depth, r.r);
-      rec_out[3 * (size_t)g + 2] = make_float4(r.g, r.b, r.ex, r.ey);
+      // (r, g) and (b, depth) sit in aligned pairs: the compositing loops fetch them with one 16-byte and one 8-byte
+      // LDS read into the register pairs their packed multiply-adds take
+      rec_out[3 * (size_t)g + 1] = make_float4(r.qc, r.op, r.r, r.g);
+      rec_out[3 * (size_t)g + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
       depth_bits = __float_as_uint(r.depth);
       br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
       br.y0 = imax(br.y0, kf.band0); br.y1 = imax(br.y0, imin(br.y1, kf.band1));  // band rendering
@@ -312,7 +314,7 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
     const unsigned g = it.x;
     const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
     WalkArgs a;
-    a.r.mx = r0.x; a.r.my = r0.y; a.r.qa = r0.z; a.r.qb = r0.w; a.r.qc = r1.x; a.r.op = r1.y; a.r.depth = r1.z;
+    a.r.mx = r0.x; a.r.my = r0.y; a.r.qa = r0.z; a.r.qb = r0.w; a.r.qc = r1.x; a.r.op = r1.y; a.r.depth = r2.y;
     a.r.r = a.r.g = a.r.b = 0.f; a.r.ex = r2.z; a.r.ey = r2.w;
     a.br.x0 = (int)(it.y & 0xffffu); a.br.x1 = (int)(it.y >> 16);
     a.br.y0 = (int)(it.z & 0xffffu); a.br.y1 = (int)(it.z >> 16);
@@ -873,7 +875,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
             const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
             const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
             const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-            pixel_fwd_step(ps, ev, r1.z, r1.w, r2.x, r2.y, k0 + j);
+            pixel_fwd_step(ps, ev, r2.y, r1.z, r1.w, r2.x, k0 + j);
           }
         }
         if (__ballot(ps.T > 0.f) == 0ull) break;
@@ -911,7 +913,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
               const float4 r0 = st[j * 3], r1 = st[j * 3 + 1];
               const float2 r2 = *reinterpret_cast<const float2*>(&st[j * 3 + 2]);
               const SplatEval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, sx, sy);
-              pixel_fwd_step_mask(ps, ev, r1.z, r1.w, r2.x, r2.y, j, m);
+              pixel_fwd_step_mask(ps, ev, r2.y, r1.z, r1.w, r2.x, j, m);
             }
           }
           if (__ballot(ps.T > 0.f) == 0ull) { done = true; break; }

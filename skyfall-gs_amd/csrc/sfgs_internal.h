@@ -120,7 +120,7 @@ enum HeaderSlot {
 };
 
 struct GeomView {
-  float4* rec;      // [N][3] float4 = SplatRec
+  float4* rec;      // [N][3] float4: (mx, my, qa, qb) (qc, op, r, g) (b, depth, ex, ey) -- SplatRec with (r, g), (b, depth) paired
   uint2* dup;       // [N] (first duplicate index, duplicate count) of every Gaussian
   uint4* big_list;  // [N] work list of big_walk_kernel: (Gaussian id, tile range x0 | x1 << 16, y0 | y1 << 16, 0);
                     //     HDR_BIG_COUNT entries, written only for splats that reach more than BIG_WALK coarse bins
