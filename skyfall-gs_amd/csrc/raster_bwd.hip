@@ -305,12 +305,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
        // (ds_write_addtid_b32 would do this at twice the LDS store rate -- the kernel drops from 0.49 to 0.46 ms -- but
        // on gfx950 it does NOT add the workgroup's LDS base: with several workgroups per CU it writes into its
        // neighbours' memory; tools/microbench/addtid_probe.hip)
-      float4* z = reinterpret_cast<float4*>(lds.UW);
-      constexpr int NZ = B * ROW / 2;
-      static_assert((B * ROW) % 2 == 0, "zero fill in 16-byte stores");
+      float2* z = lds.UW;
+      constexpr int NZ = B * ROW;
 #pragma unroll
       for (int i = 0; i < (NZ + 63) / 64; ++i)
-        if (i * 64 + lane < NZ) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i * 64 + lane < NZ) z[i * 64 + lane] = make_float2(0.f, 0.f);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -129,6 +129,20 @@ LDS_KERNEL(ds_write_b128_seq, WR128(addr_seq, 0) WR128(addr_seq, 1024) WR128(add
            WR128(addr_seq, 4096) WR128(addr_seq, 5120) WR128(addr_seq, 6144) WR128(addr_seq, 7168)
            asm volatile("s_waitcnt lgkmcnt(0)");)
 
+#define WR2_64(A, O0, O1) asm volatile("ds_write2_b64 %0, %1, %1 offset0:" #O0 " offset1:" #O1 :: "v"(A), "v"(v2));
+LDS_KERNEL(ds_write2_b64_row, WR2_64(addr_row, 0, 65) WR2_64(addr_row, 130, 195) WR2_64(addr_row, 4, 69) WR2_64(addr_row, 134, 199)
+           WR2_64(addr_row, 8, 73) WR2_64(addr_row, 138, 203) WR2_64(addr_row, 12, 77) WR2_64(addr_row, 142, 207)
+           asm volatile("s_waitcnt lgkmcnt(0)");)
+#define WR64S(A, OFF) asm volatile("ds_write_b64 %0, %1 offset:" #OFF :: "v"(A), "v"(v2));
+LDS_KERNEL(ds_write_b64_seq, WR64S(addr_row, 0) WR64S(addr_row, 512) WR64S(addr_row, 1024) WR64S(addr_row, 1536)
+           WR64S(addr_row, 2048) WR64S(addr_row, 2560) WR64S(addr_row, 3072) WR64S(addr_row, 3584)
+           asm volatile("s_waitcnt lgkmcnt(0)");)
+typedef double v2d __attribute__((ext_vector_type(2)));
+#define RD2_64(A, O0, O1) asm volatile("ds_read2_b64 %0, %1 offset0:" #O0 " offset1:" #O1 : "=v"(v) : "v"(A));
+LDS_KERNEL(ds_read2_b64_row, RD2_64(addr_row, 0, 1) RD2_64(addr_row, 65, 66) RD2_64(addr_row, 130, 131) RD2_64(addr_row, 195, 196)
+           RD2_64(addr_row, 4, 5) RD2_64(addr_row, 69, 70) RD2_64(addr_row, 134, 135) RD2_64(addr_row, 199, 200)
+           asm volatile("s_waitcnt lgkmcnt(0)"); acc.x += v.x;)
+
 typedef void (*kern_t)(float*, float, float, int);
 struct Entry { const char* name; kern_t fn; int per_iter; };
 
@@ -143,7 +157,7 @@ int main() {
                  E(xor_b32, 8), E(lshlrev, 8), E(add_u32, 8), E(sub_u32, 8), E(and_b32, 8), E(or_b32, 8), E(and_or, 8), E(lshl_or, 8), E(max_f32, 8), E(med3_f32, 8), E(mul_u24, 8), E(mul_e64_neg, 8), E(sub_f32, 8), E(fma_sgpr_lit, 8), E(add_dpp_quad, 8), E(add_dpp_rowshr, 8), E(bcnt, 8), E(exp, 8), E(rcp, 8), E(cmp_vcc, 8), E(cndmask_vcc, 8), E(cmp_cndmask, 16),
                  E(mov_dpp_quad, 8), E(permlane32_swap, 8), E(permlane16_swap, 8), E(pk_fma_f32, 8), E(pk_mul_f32, 8), E(pk_add_f32, 8), E(pk_fma_opsel, 8), E(readlane_like_bpermute, 8), E(swizzle, 8),
                  E(ds_read_b128_seq, 8), E(ds_read_b128_rec16, 8), E(ds_read_b64_row, 8), E(ds_read_b32_row, 8),
-                 E(ds_write_b64_row, 8), E(ds_write_b32_row, 8), E(ds_write_b128_seq, 8)};
+                 E(ds_write_b64_row, 8), E(ds_write2_b64_row, 8), E(ds_write_b64_seq, 8), E(ds_read2_b64_row, 8), E(ds_write_b32_row, 8), E(ds_write_b128_seq, 8)};
   const int nblk = 4096;  // 16 blocks per CU: every SIMD always has 4 resident waves
   for (auto& t : tab) {
     float best = 1e9f;
