@@ -14,6 +14,9 @@
 // only where spelled fmaf, identically to raster_fwd.hip).
 #include <stdlib.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "sfgs_internal.h"
 
 namespace sfgs {
@@ -416,7 +419,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 // so, and publishes the decision in hdr[HDR_PREFILLED] for composite_bwd, which then skips its zero records.
 // (On the headline scene 0.1 % are dead: the kernel returns after the sum.)
 __global__ void __launch_bounds__(256)
-dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned long long n_dup,
+dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned long long n_dup, int mode,
                        float4* __restrict__ dupgrad, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned part[4];
   // every workgroup sums the per-tile counts for itself (2 bytes per tile, 16-byte loads: 64 KB from L2 at 1080p)
@@ -438,7 +441,7 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (unsigned)min(dead64, 0xffffffffull >> 2);
   __syncthreads();
   const unsigned long long total = (unsigned long long)part[0] + part[1] + part[2] + part[3];
-  const bool fill = prefill_wanted(total, n_dup);
+  const bool fill = mode == 1 ? true : mode == 2 ? false : prefill_wanted(total, n_dup);   // mode: test knob
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HDR_PREFILLED] = fill ? 1ull : 0ull;
   if (!fill) return;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -597,6 +600,14 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
 
 using namespace sfgs;
 
+// SFGS_PREFILL=always|never forces / forbids the dead-entry prefill (default: decided per frame on the device). Both
+// paths produce bit-identical gradients (tests/test_gpu_raster.py); the knob exists so that the tests can run each.
+static int prefill_mode() {
+  const char* e = getenv("SFGS_PREFILL");
+  if (!e) return 0;
+  return !strcmp(e, "always") ? 1 : !strcmp(e, "never") ? 2 : 0;
+}
+
 extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                                     const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
                                     int64_t coarse_capacity, int64_t num_duplicates, const void* image,
@@ -630,7 +641,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(dupgrad_prefill_kernel, dim3(512), dim3(256), 0, stream, TX8 * TY8, iv.tile_dead,
-                       (unsigned long long)num_duplicates, (float4*)dupgrad, tv.hdr);
+                       (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr);
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
                        dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr); }

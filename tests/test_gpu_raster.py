@@ -282,3 +282,22 @@ def test_random_configurations(i):
     for k in G:
         parity.assert_grad_close(k, out["grads"][k], G[k], l2=parity.GRAD_RTOL_L2 * scale * few * (3.0 if flipped else 1.0),
                                  mx=parity.GRAD_RTOL_MAX * scale * few * (6.0 if flipped else 1.0))
+
+
+def test_dead_entry_prefill_paths_bit_identical(monkeypatch):
+    """Entries behind a tile's last contributor get zero gradient records either one by one (composite_bwd) or from the
+    streaming prefill (dupgrad_prefill_kernel, chosen per frame on the device when > 30 % are dead). Both forced in
+    turn: every gradient must come out bit-identical, and identical to the automatic choice."""
+    frame, g = scene(400, 256, 192, seed=11, zrange=(3., 6.), scale_range=(0.3, 2.0))   # heavy overdraw: most entries dead
+    gc, gd = upstream_grads(256, 192, 3)
+    outs = {}
+    for mode in ("always", "never", ""):
+        if mode:
+            monkeypatch.setenv("SFGS_PREFILL", mode)
+        else:
+            monkeypatch.delenv("SFGS_PREFILL", raising=False)
+        outs[mode] = run_hip(frame, g, gc, gd)["grads"]
+    for k in outs["always"]:
+        np.testing.assert_array_equal(outs["always"][k], outs["never"][k], err_msg=k)
+        np.testing.assert_array_equal(outs["always"][k], outs[""][k], err_msg=k)
+    assert np.abs(outs["always"]["means3D"]).max() > 0
