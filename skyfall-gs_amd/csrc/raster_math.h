@@ -304,25 +304,40 @@ SFGS_HD float p2_at(const SplatRec& r, float dx, float dy) {
   return r.qa * dx * dx + r.qc * dy * dy + r.qb * dx * dy;
 }
 
-// sample rectangle [x0,x1] x [y0,y1] in pixel coordinates (already widened by the subpixel bound)
+// sample rectangle [x0,x1] x [y0,y1] in pixel coordinates (already widened by the subpixel bound): can alpha reach
+// 1/255 anywhere on it, i.e. is max p2 over the rectangle >= thr? p2 is a concave quadratic about the splat's centre,
+// so with the centre outside the rectangle the maximum lies on an edge that FACES the centre (from any other point of
+// the rectangle one can move towards the centre, uphill, and stay inside), and on an edge it is the 1-D stationary
+// point clamped to the edge. The nearer vertical and the nearer horizontal edge are therefore all that has to be
+// evaluated (an edge that does not face the centre only adds a smaller candidate): 2 clamped stationary points
+// instead of 4 corners + 4 edges -- the tile tests are a fifth of preprocess_kernel's instructions.
 SFGS_HD bool tile_can_contribute(const SplatRec& r, float thr, float x0, float x1, float y0, float y1) {
   const float dxl = r.mx - x1, dxh = r.mx - x0, dyl = r.my - y1, dyh = r.my - y0;
   if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;  // centre inside: p2 = 0
-  float best = fmaxf(fmaxf(p2_at(r, dxl, dyl), p2_at(r, dxl, dyh)), fmaxf(p2_at(r, dxh, dyl), p2_at(r, dxh, dyh)));
-  // stationary points of the four edges (only a maximum when the 1-D coefficient is negative)
-  if (r.qc < 0.f) {
-    const float inv = -0.5f / r.qc;
-    float dy = fminf(dyh, fmaxf(dyl, r.qb * dxl * inv));
-    best = fmaxf(best, p2_at(r, dxl, dy));
-    dy = fminf(dyh, fmaxf(dyl, r.qb * dxh * inv));
-    best = fmaxf(best, p2_at(r, dxh, dy));
-  }
-  if (r.qa < 0.f) {
-    const float inv = -0.5f / r.qa;
-    float dx = fminf(dxh, fmaxf(dxl, r.qb * dyl * inv));
-    best = fmaxf(best, p2_at(r, dx, dyl));
-    dx = fminf(dxh, fmaxf(dxl, r.qb * dyh * inv));
-    best = fmaxf(best, p2_at(r, dx, dyh));
+  float best;
+  if (r.qa < 0.f && r.qc < 0.f) {
+    const float dxv = fabsf(dxl) < fabsf(dxh) ? dxl : dxh;   // nearer vertical edge
+    const float dyv = fabsf(dyl) < fabsf(dyh) ? dyl : dyh;   // nearer horizontal edge
+    const float dy = fminf(dyh, fmaxf(dyl, r.qb * dxv * (-0.5f / r.qc)));
+    const float dx = fminf(dxh, fmaxf(dxl, r.qb * dyv * (-0.5f / r.qa)));
+    best = fmaxf(p2_at(r, dxv, dy), p2_at(r, dx, dyv));
+  } else {
+    // degenerate or NaN conic: all four corners and whatever edge maxima exist (NaN keeps the pair below)
+    best = fmaxf(fmaxf(p2_at(r, dxl, dyl), p2_at(r, dxl, dyh)), fmaxf(p2_at(r, dxh, dyl), p2_at(r, dxh, dyh)));
+    if (r.qc < 0.f) {
+      const float inv = -0.5f / r.qc;
+      float dy = fminf(dyh, fmaxf(dyl, r.qb * dxl * inv));
+      best = fmaxf(best, p2_at(r, dxl, dy));
+      dy = fminf(dyh, fmaxf(dyl, r.qb * dxh * inv));
+      best = fmaxf(best, p2_at(r, dxh, dy));
+    }
+    if (r.qa < 0.f) {
+      const float inv = -0.5f / r.qa;
+      float dx = fminf(dxh, fmaxf(dxl, r.qb * dyl * inv));
+      best = fmaxf(best, p2_at(r, dx, dyl));
+      dx = fminf(dxh, fmaxf(dxl, r.qb * dyh * inv));
+      best = fmaxf(best, p2_at(r, dx, dyh));
+    }
   }
   return !(best < thr);  // NaN keeps the pair
 }
