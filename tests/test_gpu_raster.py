@@ -301,3 +301,21 @@ def test_dead_entry_prefill_paths_bit_identical(monkeypatch):
         np.testing.assert_array_equal(outs["always"][k], outs["never"][k], err_msg=k)
         np.testing.assert_array_equal(outs["always"][k], outs[""][k], err_msg=k)
     assert np.abs(outs["always"]["means3D"]).max() > 0
+
+
+def test_storage_order_is_a_relabelling():
+    """Rendering a scene and the same scene with its Gaussians permuted (Z-curve order, sfgs.densify.zcurve_permutation)
+    gives the same image and, row for row, the same gradients: only exact depth ties are broken by index."""
+    from sfgs.densify import zcurve_permutation
+    frame, g = scene(30000, 320, 200, seed=5, zrange=(250., 350.), scale_range=(0.2, 2.4))
+    gc, gd = upstream_grads(320, 200, 2)
+    a = run_hip(frame, g, gc, gd)
+    perm = zcurve_permutation(g["means3D"])
+    gp = {k: (v[perm].contiguous() if v is not None else None) for k, v in g.items()}
+    b = run_hip(frame, gp, gc, gd)
+    np.testing.assert_array_equal(a["radii"][perm.numpy()], b["radii"])
+    np.testing.assert_allclose(a["color"], b["color"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.nan_to_num(a["depth"]), np.nan_to_num(b["depth"]), rtol=1e-5, atol=1e-5)
+    for k in a["grads"]:
+        ga, gb = a["grads"][k][perm.numpy()], b["grads"][k]
+        assert np.abs(ga - gb).max() <= 1e-5 * max(np.abs(ga).max(), 1e-30) + 1e-12, k

@@ -43,7 +43,7 @@ def _free_port():
 
 
 # ---- hooks on the reference's GaussianModel ---------------------------------------------------------------------------
-def install_hooks(gaussian_model_cls, fused=True, shared_mlp=True):
+def install_hooks(gaussian_model_cls, fused=True, shared_mlp=True, zcurve_order=False):
     """Patch the reference's GaussianModel class in place (idempotent). fused: the HIP drop-ins of INTEGRATION.md
     (pre-pass, 3D filter, densification statistics, Adam, prune compaction, densify_and_prune). shared_mlp: keep the appearance MLP in
     step across the processes of the torch.distributed group."""
@@ -51,8 +51,9 @@ def install_hooks(gaussian_model_cls, fused=True, shared_mlp=True):
         sys.path.insert(0, PKG)
     if fused:
         from sfgs import adam, compact, densify, densify_stats, filter3d, prepass
-        for mod in (prepass, filter3d, densify_stats, adam, compact, densify):
+        for mod in (prepass, filter3d, densify_stats, adam, compact):
             mod.install(gaussian_model_cls)
+        densify.install(gaussian_model_cls, zcurve_order=zcurve_order)   # optionally keeps the rows in Z-curve order
     if shared_mlp and not getattr(gaussian_model_cls, "_sfgs_shared_mlp", False):
         import torch.distributed as dist
         from sfgs.shard import SharedGradBucket
@@ -129,7 +130,8 @@ def worker(args, cmd):
             sys.modules["plyfile"] = m
     import importlib
     gm = importlib.import_module(args.model_module)
-    install_hooks(getattr(gm, args.model_class), fused=not args.no_fused, shared_mlp=not args.no_shared_mlp)
+    install_hooks(getattr(gm, args.model_class), fused=not args.no_fused, shared_mlp=not args.no_shared_mlp,
+                  zcurve_order=args.zcurve_order)
     scenes = [s for i, s in enumerate(args.scenes) if i % world == rank]
     rc = 0
     try:
@@ -162,6 +164,8 @@ def main():
     ap.add_argument("--gpu-ids", default="", help="comma-separated physical GPU ids (default 0..gpus-1)")
     ap.add_argument("--no-fused", action="store_true", help="do not install the fused HIP hooks on GaussianModel")
     ap.add_argument("--no-shared-mlp", action="store_true", help="independent scenes: no all-reduce of the appearance MLP")
+    ap.add_argument("--zcurve-order", action="store_true",
+                    help="re-sort the Gaussians along a Z-curve after every densify_and_prune (a relabelling; faster binning)")
     ap.add_argument("--no-plyfile-standin", action="store_true")
     ap.add_argument("--model-module", default="scene.gaussian_model")
     ap.add_argument("--model-class", default="GaussianModel")
