@@ -1,7 +1,7 @@
 """Oracle parity AT THE BENCHMARKED SIZES ("What's weak" item 2): the HIP path against the C oracle on
 the full BASELINE.json configurations -- cfg 2 (2 M Gaussians, 1920x1080: the bench.py headline), its low-elevation
-variant (long tile lists), cfg 4 (5 M, 2560x1440, dL/ddepth != 0: depth-regularised training) and the IDU render
-shape of cfg 3 (1024x1024). The oracle needs a few seconds per case on the GPU box's host cores.
+variant (long tile lists), cfg 4 (5 M, 2560x1440, dL/ddepth != 0: depth-regularised training), the IDU render
+shape of cfg 3 (1024x1024) and an opaque-surface city seen from an IDU orbit camera (saturating pixels, dead entries). The oracle needs a few seconds per case on the GPU box's host cores.
 
 Bars (SURVEY A.7 / BASELINE.json north_star):
   * radii, N_vis, D (sum of tiles_touched): bit-exact;
@@ -20,7 +20,7 @@ import torch
 
 import parity
 from oracle import oracle as orc
-from sfgs.synth import scene, upstream_grads
+from sfgs.synth import city_scene, scene, upstream_grads
 from test_gpu_raster import run_hip
 
 pytestmark = pytest.mark.gpu
@@ -30,6 +30,10 @@ CASES = {
     "cfg2_low_elevation_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw=dict(pitch_deg=45.0, zrange=(40.0, 400.0))),
     "cfg4_5M_1440p_depth": dict(n=5_000_000, W=2560, H=1440, kw=dict(zrange=(500.0, 700.0))),
     "cfg3_idu_2M_1024sq": dict(n=2_000_000, W=1024, H=1024, kw={}),
+    # opaque surfaces seen from an IDU orbit camera at 25 degrees elevation: pixels saturate after a few splats, lists of
+    # up to ~3 400 entries (every sort path), about half of the list entries behind their tile's last contributor (the
+    # dead-entry prefill of the backward)
+    "city_e25_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=25.0),
 }
 MAX_BORDERLINE_FRAC = 1e-4
 
@@ -49,7 +53,10 @@ def _record(entry):
 def test_full_size_oracle_parity(case):
     c = CASES[case]
     os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
-    frame, g = scene(c["n"], c["W"], c["H"], seed=0, **c["kw"])
+    if "city" in c:
+        frame, g = city_scene(c["n"], c["W"], c["H"], c["city"], seed=0)
+    else:
+        frame, g = scene(c["n"], c["W"], c["H"], seed=0, **c["kw"])
     R = orc.OracleRender(frame, **g)
     gc, gd = upstream_grads(c["W"], c["H"], 0)
     gd = gd.clone()
