@@ -501,13 +501,16 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
                       float* __restrict__ g_rots, float* __restrict__ g_opac, float* __restrict__ g_colors,
                       float* __restrict__ g_shs) {
+  constexpr int PB_CHUNK = 128;   // records per staging chunk and wave: 6 KB of LDS
+  static_assert((PB_CHUNK * 3) % 64 == 0, "whole load rounds");
+  __shared__ float4 pb_stage[PRE_BLOCK / 64][PB_CHUNK * 3];
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const bool valid = g < N;
   const int lane = threadIdx.x & 63;
   // ---- sum this Gaussian's per-duplicate records (fixed order -> deterministic) -----------------------------------
   // A splat that covers many tiles owns thousands of records: summing them in its own lane would leave the other 63
   // lanes idle for that long, so above COOP records the whole wave strides over them and reduces across lanes.
-  constexpr unsigned COOP = 16;
+  constexpr unsigned COOP = 32;
   const bool vis = valid && radii[g] > 0;
   unsigned d0 = 0, cnt = 0;
   if (vis) { const uint2 dr = dup[g]; d0 = dr.x; cnt = dr.y; }
@@ -519,12 +522,45 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
       a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
       a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
     }
-  } else if (cnt <= COOP) {
-    for (unsigned d = d0; d < d0 + cnt; ++d) {
-      const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
-      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+  }
+  // Gaussians with at most COOP records (almost all): the records of a wave's Gaussians are CONTIGUOUS (the forward
+  // reserves duplicate indices in thread order), so the wave streams them through LDS in chunks of PB_CHUNK records
+  // with full-line loads -- lane i fetches the i-th 16-byte piece -- and every lane then adds up its own records from
+  // LDS, in the same order as before (bit-identical sums). Read per lane straight from memory (64 different cache lines
+  // per load instruction) the summation was 0.085 of the kernel's 0.14 ms.
+  {
+    const bool small = cnt > 0 && cnt <= COOP;
+    const unsigned rb = small ? d0 : 0xffffffffu, re = small ? d0 + cnt : 0u;
+    unsigned w0 = rb, w1 = re;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      w0 = min(w0, (unsigned)__shfl_xor((int)w0, d));
+      w1 = max(w1, (unsigned)__shfl_xor((int)w1, d));
+    }
+    float4* stage = pb_stage[threadIdx.x >> 6];
+    for (unsigned c0 = w0; c0 < w1; c0 += PB_CHUNK) {   // w0 >= w1 when the wave has no such Gaussian
+      const unsigned c1 = min(c0 + PB_CHUNK, w1);
+      if (__ballot(small && rb < c1 && re > c0) == 0ull) continue;   // a stretch that belongs to bigger splats only
+      const unsigned n4 = (c1 - c0) * 3;
+#pragma unroll
+      for (int k = 0; k < PB_CHUNK * 3 / 64; ++k) {
+        const unsigned u = k * 64 + lane;
+        if (u < n4) stage[u] = dupgrad[(size_t)c0 * 3 + u];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (small) {
+        const unsigned lo = max(rb, c0), hi = min(re, c1);
+        for (unsigned d = lo; d < hi; ++d) {
+          const float4* q = stage + (size_t)(d - c0) * 3;
+          const float4 x0 = q[0], x1 = q[1], x2 = q[2];
+          a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+          a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+          a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
   for (unsigned long long todo = __ballot(cnt > COOP && cnt <= BWD_BIG); todo; todo &= todo - 1) {
