@@ -301,7 +301,8 @@ def main():
                                    f"kernel_size=0.1, seed=rank, one scene per GPU",
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
                        "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
-                       "collective_backend": backend if world > 1 else None},
+                       "collective_backend": backend if world > 1 else None,
+                       "prewarm_ms": args.prewarm_ms, "order": args.order},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
