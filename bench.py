@@ -50,10 +50,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--prewarm-ms", type=float, default=60.0,
-                    help="untimed steps for this long BEFORE the W warm-up steps: the device needs ~30 ms of sustained load "
-                         "to reach its sustained clock state (tools/diag_ramp.py: 1.35 -> 1.25 ms/step over the first 25 "
-                         "steps of a process, again after 2 s of idle); 0 disables")
+    ap.add_argument("--prewarm-steps", type=int, default=50,
+                    help="untimed steps BEFORE the W warm-up steps (the same count on every rank): the device needs ~30 ms of "
+                         "sustained load to reach its sustained clock state (tools/diag_ramp.py: 1.35 -> 1.25 ms/step over "
+                         "the first 25 steps of a process, again after 2 s of idle); 0 disables")
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -179,13 +179,9 @@ def main():
     collect_full_counters(False)
     # device clock ramp (power management, not this code: the same ramp follows every idle period): a training loop runs
     # at the sustained state, so bring the device there before the W warm-up and K timed steps
-    if args.prewarm_ms > 0:
-        torch.cuda.synchronize(dev)
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize(dev)
+    for _ in range(max(args.prewarm_steps, 0)):   # a fixed count: with N > 1 every step holds a collective
+        step()
+    torch.cuda.synchronize(dev)
     L.profile_select(None)
     n_prof = max(args.warmup - 1, 1) if args.warmup else 0   # the first step sizes the scratch (may re-plan): not timed
     for i in range(args.warmup):
@@ -302,7 +298,7 @@ def main():
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
                        "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
                        "collective_backend": backend if world > 1 else None,
-                       "prewarm_ms": args.prewarm_ms, "order": args.order},
+                       "prewarm_steps": args.prewarm_steps, "order": args.order},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
