@@ -187,7 +187,9 @@ int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* ge
  * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same capacities, image)
  * and radii unchanged. `dupgrad` is scratch: 48 bytes for each of the num_duplicates (Gaussian, tile) pairs the
  * plan counted (sfgs_raster_sizes(N, W, H, num_duplicates, ..).dupgrad_bytes). Every gradient tensor in `grads` is
- * fully overwritten. Deterministic (no float atomics). Asynchronous. */
+ * fully overwritten. Deterministic (no float atomics). Asynchronous. Writes one word of the `tiles` header (whether
+ * this frame's dead list entries were zero-filled in bulk; decided per frame on the device, environment variable
+ * SFGS_PREFILL=always|never forces either path for tests: the gradients are bit-identical). */
 int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                          const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
                          int64_t coarse_capacity, int64_t num_duplicates, const void* image, const float* dL_dcolor,
