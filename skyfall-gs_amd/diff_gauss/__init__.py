@@ -231,6 +231,9 @@ class _Rasterize(torch.autograd.Function):
         # zero, i.e. a read-only all-zeros [3,H,W] tensor that costs no memory and no kernel
         norm = _zero(dev).expand(3, H, W)
         ctx.mark_non_differentiable(radii, norm)
+        # an output the loss does not use (alpha, often depth) would otherwise reach backward() as a freshly filled zero
+        # image: the library takes NULL for those instead
+        ctx.set_materialize_grads(False)
         if need_bwd:
             ctx.settings, ctx.D, ctx.ccap, ctx.sh_coeffs, ctx.ndup = settings, cap, ccap, sh_coeffs, D
             ctx.keep = keep
