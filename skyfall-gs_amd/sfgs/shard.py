@@ -50,77 +50,204 @@ def scenes_for_rank(scenes, rank, world):
 
 
 class SharedGradBucket:
-    """Flat gradient bucket of the parameters that are shared between the per-rank scenes (the appearance
-    MLP). all_reduce_() averages their .grad across ranks with a single collective.
+    """Flat bucket of the parameters that are shared between the per-rank scenes (the appearance MLP) -- ONE logical
+    model and ONE logical Adam state, replicated on every rank that trains.
 
-    Scenes differ in length (iterations, early stops): the bucket carries one extra element, the number of ranks
-    still training. A rank whose training has ended keeps answering the collective with zeros (`drain()`, called by
-    the launcher at exit) until every rank has ended, and the training ranks average over the ACTIVE ranks only -- so
-    a short scene never blocks or dilutes the long ones."""
+    EVERY collective this class issues is the same one -- an all-reduce (sum) of the same flat buffer
 
-    def __init__(self, params):
+        [ gradients (n) | parameters (n) | Adam exp_avg (n) | Adam exp_avg_sq (n) | Adam step | number of ranks that train |
+          one flag per rank: "I am in training_setup" (world) ]
+
+    so that ranks in different phases can never pair mismatched collectives: a rank inside
+    optimizer.step() (`all_reduce_`), a rank (re)building its optimizer (`sync_setup`: train.py:95, restore() at
+    scene/gaussian_model.py:163, every IDU episode at train.py:633, or the next scene of a rank that trains several)
+    and a rank that has finished (`drain`) all answer one another's rounds:
+
+      * a training rank contributes its gradients, its parameters and Adam moments AS OF THE START of the round and
+        counts itself; it divides the gradient sum by the number of ranks that trained in that round -- a short scene
+        never blocks or dilutes the long ones -- and steps;
+      * a rank in setup contributes only its flag. It ADOPTS the training ranks' parameters and Adam state (their mean:
+        they are identical by construction; exact for 1, 2, 4, 8 contributors) and then applies the round's averaged
+        gradient with its own optimizer, i.e. performs the very step the training ranks perform: it leaves the round
+        bit-identical to them, although training_setup had just handed it a fresh Adam. If nobody trains yet (the common
+        start: all ranks set up together) the ranks of the round run one more all-reduce in which the LOWEST rank in
+        setup supplies its parameters -- "start from rank 0's initialisation" -- which is consistent because a round
+        without a training rank consists of setup and draining ranks only, and all of them see the same flags;
+      * a draining rank contributes zeros until a round has neither a training rank nor a rank in setup.
+
+    No host synchronisation on the training path (the divide happens on the device). A rank that is NOT issuing rounds
+    (loading its next scene, minutes of IDU refinement) holds the other ranks' optimizer steps: that is the price of
+    one shared model, and why the launcher leaves sharing off by default."""
+
+    def __init__(self, params, optimizer=None):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.optimizer = optimizer             # whose state[p] = {step, exp_avg, exp_avg_sq} is shared (torch.optim.Adam)
+        n = self.n = sum(p.numel() for p in self.params)
         ref = self.params[0] if self.params else torch.zeros(0)
-        self.flat = torch.zeros(n + 1, dtype=ref.dtype, device=ref.device)   # [..., active-rank count]
+        self.world = dist.get_world_size() if self._distributed() else 1
+        self.rank = dist.get_rank() if self._distributed() else 0
+        self.flat = torch.zeros(4 * n + 2 + self.world, dtype=ref.dtype, device=ref.device)
         self._work = None
         self.steps = 0
 
     def numel(self):
-        return self.flat.numel() - 1
+        return self.n
 
     @staticmethod
     def _distributed():
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    @staticmethod
+    def _pack(dst, tensors):
+        torch.cat([t.reshape(-1) for t in tensors], out=dst)
+
+    def _state(self, p):
+        st = self.optimizer.state.get(p) if self.optimizer is not None else None
+        return st if st else None
+
     def launch(self):
-        """Pack the grads and start the all-reduce (async). Call right after backward()."""
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
+        """Pack the gradients (and the shared state) and start the all-reduce (async). Call right after backward()."""
+        n = self.n
+        with torch.no_grad():
+            self.flat[2 * n:].zero_()
+            if all(p.grad is not None for p in self.params):
+                self._pack(self.flat[:n], [p.grad for p in self.params])
             else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        self.flat[off] = 1.0
+                off = 0
+                for p in self.params:
+                    k = p.numel()
+                    if p.grad is None:
+                        self.flat[off:off + k].zero_()
+                    else:
+                        self.flat[off:off + k].copy_(p.grad.reshape(-1))
+                    off += k
+            self._pack(self.flat[n:2 * n], [p.data for p in self.params])
+            states = [self._state(p) for p in self.params]
+            if states and all(st is not None and "exp_avg" in st for st in states):
+                self._pack(self.flat[2 * n:3 * n], [st["exp_avg"] for st in states])
+                self._pack(self.flat[3 * n:4 * n], [st["exp_avg_sq"] for st in states])
+                self.flat[4 * n] = float(states[0]["step"])
+            self.flat[4 * n + 1] = 1.0
         if self._distributed():
             self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
         return self
 
+    def _unpack_grads(self, scale=None):
+        n = self.n
+        with torch.no_grad():
+            if scale is None:
+                self.flat[:n].div_(self.flat[4 * n + 1].clamp(min=1.0))   # mean over the ranks that trained this round
+            off = 0
+            for p in self.params:
+                k = p.numel()
+                if p.grad is None:
+                    p.grad = self.flat[off:off + k].reshape(p.shape).clone()
+                else:
+                    p.grad.copy_(self.flat[off:off + k].reshape(p.shape))
+                off += k
+
     def wait(self):
-        """Finish the all-reduce and write the averaged grads back. Call before optimizer.step()."""
+        """Finish the all-reduce and write the averaged gradients back. Call before optimizer.step()."""
         if self._work is not None:
             self._work.wait()
             self._work = None
-        n_total = self.flat.numel() - 1
         if self._distributed():
-            self.flat[:n_total].div_(self.flat[n_total].clamp(min=1.0))   # mean over the ranks still training
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].reshape(p.shape).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].reshape(p.shape))
-            off += n
+            self._unpack_grads()
         self.steps += 1
 
     def all_reduce_(self):
         self.launch().wait()
 
+    def _passive_round(self, in_setup):
+        """One round as a rank that does not train. Returns (training ranks, Adam step sum, per-rank setup flags)."""
+        n = self.n
+        self.flat.zero_()
+        if in_setup:
+            self.flat[4 * n + 2 + self.rank] = 1.0
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        tail = self.flat[4 * n:].tolist()
+        return tail[1], tail[0], tail[2:]
+
+    def _seed_round(self, flags, mine):
+        """No rank trains: the lowest rank in setup supplies the parameters (all ranks of the round take part)."""
+        n = self.n
+        src = next(r for r, f in enumerate(flags) if f > 0)
+        buf = self.flat[:n]
+        buf.zero_()
+        if mine and self.rank == src:
+            with torch.no_grad():
+                self._pack(buf, [p.data for p in self.params])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return buf
+
+    def _adopt(self, buf, into):
+        off = 0
+        with torch.no_grad():
+            for p, t in zip(self.params, into):
+                k = p.numel()
+                t.copy_(buf[off:off + k].reshape(p.shape))
+                off += k
+
+    def sync_setup(self, step=None):
+        """Call from training_setup (any number of times, at any point of the other ranks' training) with the freshly
+        built optimizer's UNWRAPPED step function: the shared parameters and Adam state are replaced by the ones the
+        training ranks hold and the round's step is performed -- or, when nobody trains yet, the parameters become those
+        of the lowest rank that is setting up in the same round."""
+        if not self._distributed():
+            return
+        n = self.n
+        active, step_sum, flags = self._passive_round(in_setup=True)
+        if active == 0:
+            self._adopt(self._seed_round(flags, mine=True), [p.data for p in self.params])
+            return
+        inv = 1.0 / active
+        self._adopt(self.flat[n:2 * n] * inv, [p.data for p in self.params])
+        opt = self.optimizer
+        if opt is None or step is None:
+            return
+        nstep = round(step_sum * inv)
+        if nstep > 0:   # the training ranks have stepped before: take over their moments
+            for p in self.params:
+                st = opt.state[p]
+                if "exp_avg" not in st:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if torch.is_tensor(st["step"]):
+                    st["step"].fill_(float(nstep))
+                else:
+                    st["step"] = float(nstep)
+            self._adopt(self.flat[2 * n:3 * n] * inv, [opt.state[p]["exp_avg"] for p in self.params])
+            self._adopt(self.flat[3 * n:4 * n] * inv, [opt.state[p]["exp_avg_sq"] for p in self.params])
+        # the step the training ranks take in this round: only the shared parameters carry a gradient here
+        mine = set(id(p) for p in self.params)
+        stash = []
+        for g in opt.param_groups:
+            for p in g["params"]:
+                if id(p) not in mine and p.grad is not None:
+                    stash.append((p, p.grad))
+                    p.grad = None
+        self.flat[:n].mul_(inv)
+        self._unpack_grads(scale=inv)
+        step()
+        for p in self.params:
+            p.grad = None
+        for p, g in stash:
+            p.grad = g
+
     def drain(self):
-        """This rank's training is over: keep matching the other ranks' collectives with zeros until nobody trains.
-        Returns the number of rounds answered."""
+        """This rank's training is over: keep answering the other ranks' rounds with zeros until nobody trains or
+        sets up. Returns the number of rounds answered."""
         if not self._distributed():
             return 0
         rounds = 0
         while True:
-            self.flat.zero_()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            active, _, flags = self._passive_round(in_setup=False)
             rounds += 1
-            if float(self.flat[-1]) == 0.0:       # every rank is draining: all leave in the same round
-                return rounds
+            if active == 0 and not any(f > 0 for f in flags):
+                return rounds                     # every rank is draining: all leave in the same round
+            if active == 0:
+                self._seed_round(flags, mine=False)
 
 
 def band_rows(height, world, rank):

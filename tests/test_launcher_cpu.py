@@ -35,8 +35,8 @@ import numpy as np
 import torch
 from torch import nn
 import gm_shim
-scene, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-rank = {"A": 0, "B": 1}[scene]
+scene, plan, out = sys.argv[1], PLANS[sys.argv[2]], sys.argv[3]
+rank = {"A": 0, "B": 1, "C": 2}[scene]
 torch.manual_seed(100 + rank)          # DIFFERENT initial MLPs per scene: the launcher must broadcast rank 0's
 orig_to = nn.Module.to
 nn.Module.to = lambda self, *a, **k: self if (a and str(a[0]).startswith("cuda")) else orig_to(self, *a, **k)
@@ -52,16 +52,19 @@ args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, posit
     position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
     rotation_lr=0.001, embedding_lr=0.005, appearance_embedding_lr=0.001, appearance_embedding_regularization=0.01,
     appearance_mlp_lr=0.0005, idu_position_lr_max_steps=10000)
-m.training_setup(args, num_train_cameras=3, from_scratch=True)
 flat = lambda: torch.cat([p.detach().reshape(-1) for p in m.appearance_mlp.parameters()]).numpy().copy()
-hist = [flat()]
-for k in range(steps):
-    for i, p in enumerate(m.appearance_mlp.parameters()):
-        gg = torch.Generator().manual_seed(1000 * rank + 10 * k + i)
-        p.grad = torch.randn(*p.shape, generator=gg) * 1e-2
-    m.optimizer.step()
-    m.optimizer.zero_grad(set_to_none=True)
+hist, k = [], 0
+for ep, steps in enumerate(plan):      # a second entry = training_setup again (the next IDU episode: train.py:633)
+    m.training_setup(args, num_train_cameras=3, from_scratch=(ep == 0))
     hist.append(flat())
+    for _ in range(steps):
+        for i, p in enumerate(m.appearance_mlp.parameters()):
+            gg = torch.Generator().manual_seed(1000 * rank + 10 * k + i)
+            p.grad = torch.randn(*p.shape, generator=gg) * 1e-2
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+        hist.append(flat())
+        k += 1
 np.save(out, np.stack(hist))
 '''
 
@@ -76,10 +79,10 @@ def test_launcher_keeps_the_shared_mlp_in_step_and_lets_short_scenes_finish(tmp_
     env = dict(os.environ, SFGS_TEST_OUT=str(tmp_path))
     # per-scene arguments through the {scene} placeholder; step counts differ -> the short scene must not block the long one
     cmd = [sys.executable, os.path.join(ROOT, "tools", "launch_scenes.py"), "--reference", str(ref), "--gpus", "2",
-           "--scenes", "A", "B", "--no-fused", "--model-module", "gm_shim", "--",
+           "--scenes", "A", "B", "--no-fused", "--shared-mlp", "--model-module", "gm_shim", "--",
            "fake_train.py", "{scene}", "STEPS_{scene}", str(tmp_path / "{scene}.npy")]
     # STEPS_{scene} is resolved by a tiny wrapper: substitute before launching (the launcher only knows {scene})
-    (ref / "fake_train.py").write_text(textwrap.dedent(TRAIN).replace("int(sys.argv[2])", "{'STEPS_A': 3, 'STEPS_B': 6}[sys.argv[2]]"))
+    (ref / "fake_train.py").write_text("PLANS = {'STEPS_A': [3], 'STEPS_B': [6]}\n" + textwrap.dedent(TRAIN))
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     A, B = np.load(outs["A"]), np.load(outs["B"])
@@ -102,3 +105,49 @@ def test_launcher_keeps_the_shared_mlp_in_step_and_lets_short_scenes_finish(tmp_
     p.grad = (grads[0] + grads[1]) / 2
     opt.step()
     np.testing.assert_allclose(p.detach().numpy(), A[1], rtol=0, atol=1e-9)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (authoring container)")
+def test_three_scenes_on_two_ranks_with_a_repeated_training_setup(tmp_path):
+    """the reference calls training_setup repeatedly (train.py:95, restore(), every IDU episode) and a
+    rank may train several scenes. Rank 0 trains A (3 steps) then C (3 steps); rank 1 trains B: 4 steps, training_setup
+    again, 4 steps. Every collective is the same all-reduce, so the rounds pair in order:
+      1 A.setup / B.setup (rank 0 seeds) . 2-4 A, B step together . 5 C.setup / B step 4 . 6 C step 1 / B.setup
+      7-8 C, B step together . 9-10 rank 0 drains, B steps alone.
+    A rank that sets up while another trains adopts its parameters AND Adam state and performs that round's step."""
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    (ref / "gm_shim.py").write_text(SHIM.format(golden=os.path.join(ROOT, "tests", "golden"), ref=REF))
+    (ref / "fake_train.py").write_text("PLANS = {'A': [3], 'B': [4, 4], 'C': [3]}\n" + textwrap.dedent(TRAIN))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "launch_scenes.py"), "--reference", str(ref), "--gpus", "2",
+           "--scenes", "A", "B", "C", "--no-fused", "--shared-mlp", "--model-module", "gm_shim", "--",
+           "fake_train.py", "{scene}", "{scene}", str(tmp_path / "{scene}.npy")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    A, B, C = (np.load(str(tmp_path / f"{s}.npy")) for s in "ABC")
+    assert A.shape[0] == 4 and B.shape[0] == 10 and C.shape[0] == 4
+    for k in range(4):
+        np.testing.assert_array_equal(A[k], B[k], err_msg=f"A/B step {k}")
+    np.testing.assert_array_equal(C[0], B[4])      # C joined in the round of B's step 4: same parameters afterwards
+    np.testing.assert_array_equal(C[1], B[5])      # B's second training_setup adopted C's state and took C's step
+    np.testing.assert_array_equal(C[2], B[6])      # ... including the Adam moments: the following steps agree bit for bit
+    np.testing.assert_array_equal(C[3], B[7])
+    assert not np.array_equal(B[7], B[8]) and not np.array_equal(B[8], B[9])   # B finishes alone while rank 0 drains
+    assert r.stdout.count("answered") == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (authoring container)")
+def test_default_is_independent_scenes(tmp_path):
+    """Without --shared-mlp the scenes train independently, as the reference's farm does (scripts/run_jax.py:52-87):
+    no process group, different MLPs."""
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    (ref / "gm_shim.py").write_text(SHIM.format(golden=os.path.join(ROOT, "tests", "golden"), ref=REF))
+    (ref / "fake_train.py").write_text("PLANS = {'A': [2], 'B': [2]}\n" + textwrap.dedent(TRAIN))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "launch_scenes.py"), "--reference", str(ref), "--gpus", "2",
+           "--scenes", "A", "B", "--no-fused", "--model-module", "gm_shim", "--",
+           "fake_train.py", "{scene}", "{scene}", str(tmp_path / "{scene}.npy")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    A, B = (np.load(str(tmp_path / f"{s}.npy")) for s in "AB")
+    assert not np.array_equal(A[0], B[0]) and "answered" not in r.stdout

@@ -9,11 +9,14 @@ and shells out to `python train.py ...`) WITHOUT editing any reference file:
   * the worker puts this repo's drop-in packages (diff_gauss, fused_ssim, simple_knn) ahead of the reference on
     sys.path, installs the fused hooks on the reference's own GaussianModel class and runs the
     reference's train.py IN PROCESS (runpy) with the per-scene argument list;
-  * the parameters the scenes share -- the appearance MLP, 24 966 floats (scene/gaussian_model.py:52-58) -- are kept
-    in step across the processes: GaussianModel.training_setup (scene/gaussian_model.py:350-382) is wrapped to
-    broadcast rank 0's initial MLP and attach a sfgs.shard.SharedGradBucket, and optimizer.step() first averages the
-    MLP gradients with ONE flat all-reduce over RCCL / xGMI (backend "nccl"). Everything per-Gaussian stays local.
-    Scenes of different length are handled by the bucket's participation count (sfgs/shard.py).
+  * by default the scenes train independently, exactly like the reference's farm (no collective at all);
+  * with --shared-mlp the appearance MLP, 24 966 floats (scene/gaussian_model.py:52-58), is ONE model kept in step
+    across the processes: GaussianModel.training_setup (scene/gaussian_model.py:350-382) is wrapped to adopt the MLP
+    the training ranks hold (at the start: rank 0's initialisation) and to attach a sfgs.shard.SharedGradBucket, and
+    optimizer.step() first averages the MLP gradients with ONE flat all-reduce over RCCL / xGMI (backend "nccl").
+    Everything per-Gaussian stays local. Every collective is the same all-reduce of the same buffer, so repeated
+    training_setup calls (restore, IDU episodes), several scenes per rank and scenes of different length cannot pair
+    mismatched collectives (sfgs/shard.py).
 
 usage:
   python tools/launch_scenes.py --reference /path/to/Skyfall-GS --gpus 8 \\
@@ -43,10 +46,11 @@ def _free_port():
 
 
 # ---- hooks on the reference's GaussianModel ---------------------------------------------------------------------------
-def install_hooks(gaussian_model_cls, fused=True, shared_mlp=True, zcurve_order=False):
+def install_hooks(gaussian_model_cls, fused=True, shared_mlp=False, zcurve_order=False):
     """Patch the reference's GaussianModel class in place (idempotent). fused: the HIP drop-ins of INTEGRATION.md
-    (pre-pass, 3D filter, densification statistics, Adam, prune compaction, densify_and_prune). shared_mlp: keep the appearance MLP in
-    step across the processes of the torch.distributed group."""
+    (pre-pass, 3D filter, densification statistics, Adam, prune compaction, densify_and_prune). shared_mlp (opt-in: the
+    reference trains every scene independently, scripts/run_jax.py): keep the appearance MLP in step across the
+    processes of the torch.distributed group."""
     if PKG not in sys.path:
         sys.path.insert(0, PKG)
     if fused:
@@ -60,20 +64,21 @@ def install_hooks(gaussian_model_cls, fused=True, shared_mlp=True, zcurve_order=
         orig = gaussian_model_cls.training_setup
 
         def training_setup(self, *args, **kwargs):
+            # The reference calls training_setup repeatedly (train.py:95, restore() at scene/gaussian_model.py:163, every
+            # IDU episode at train.py:633) and a rank may train several scenes: every call is ONE round of the bucket's
+            # single-collective protocol (sfgs/shard.py), which ranks inside optimizer.step() or draining answer.
             out = orig(self, *args, **kwargs)
             mlp = getattr(self, "appearance_mlp", None)
             if mlp is None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
                 return out
-            params = list(mlp.parameters())
-            for p in params:                       # the shared parameters start from rank 0's initialisation
-                dist.broadcast(p.data, src=0)
-            bucket = SharedGradBucket(params)
+            bucket = SharedGradBucket(list(mlp.parameters()), self.optimizer)
+            step = self.optimizer.step
+            bucket.sync_setup(step)                # adopt the MLP + Adam state the training ranks hold (or the lowest rank's)
             self._sfgs_shared_bucket = bucket
             _BUCKETS.append(bucket)
-            step = self.optimizer.step
 
             def step_with_all_reduce(*a, **k):
-                bucket.all_reduce_()               # average the MLP gradients over the ranks still training
+                bucket.all_reduce_()               # average the MLP gradients over the ranks training in this round
                 return step(*a, **k)
             self.optimizer.step = step_with_all_reduce
             return out
@@ -110,8 +115,10 @@ def worker(args, cmd):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if PKG not in sys.path:
         sys.path.insert(0, PKG)                  # diff_gauss / fused_ssim / simple_knn resolve to the HIP drop-ins
-    if world > 1:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+    sharing = world > 1 and args.shared_mlp     # independent scenes (the default) need no process group at all
+    if sharing:
+        # "nccl" is RCCL on ROCm; SFGS_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+        backend = os.environ.get("SFGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
         # long timeout: a rank may sit in its IDU refinement (FlowEdit, minutes) while the others wait in the all-reduce
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=12), **kw)
@@ -130,7 +137,7 @@ def worker(args, cmd):
             sys.modules["plyfile"] = m
     import importlib
     gm = importlib.import_module(args.model_module)
-    install_hooks(getattr(gm, args.model_class), fused=not args.no_fused, shared_mlp=not args.no_shared_mlp,
+    install_hooks(getattr(gm, args.model_class), fused=not args.no_fused, shared_mlp=args.shared_mlp,
                   zcurve_order=args.zcurve_order)
     scenes = [s for i, s in enumerate(args.scenes) if i % world == rank]
     rc = 0
@@ -144,7 +151,7 @@ def worker(args, cmd):
     except SystemExit as e:
         rc = int(e.code or 0)
     finally:
-        if world > 1:
+        if sharing:
             rounds = drain()
             print(f"[launch_scenes rank {rank}] finished; answered {rounds} further all-reduce rounds", flush=True)
             dist.destroy_process_group()
@@ -163,7 +170,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=0, help="processes / GPUs to use (default: one per scene, at most the visible GPUs)")
     ap.add_argument("--gpu-ids", default="", help="comma-separated physical GPU ids (default 0..gpus-1)")
     ap.add_argument("--no-fused", action="store_true", help="do not install the fused HIP hooks on GaussianModel")
-    ap.add_argument("--no-shared-mlp", action="store_true", help="independent scenes: no all-reduce of the appearance MLP")
+    ap.add_argument("--shared-mlp", action="store_true",
+                    help="share ONE appearance MLP between the scenes (all-reduce of its 24 966 gradients per step over RCCL). "
+                         "Default: independent scenes, as the reference trains them. With sharing, a rank that is not "
+                         "stepping (loading its next scene, IDU refinement) holds the other ranks' optimizer steps")
     ap.add_argument("--zcurve-order", action="store_true",
                     help="re-sort the Gaussians along a Z-curve after every densify_and_prune (a relabelling; faster binning)")
     ap.add_argument("--no-plyfile-standin", action="store_true")
