@@ -323,7 +323,9 @@ int sfgs_compact_rows(const unsigned char* keep, int64_t N, const void* scratch,
  * sfgs_densify_gather: writes every dst tensor [totals[0] + totals[1] + 2 * totals[2] rows] in the reference's final
  * order [surviving originals | clones | first children | second children]; zero_new_rows: clones / children get zeros
  * (Adam moments). sfgs_densify_children then overwrites the child rows of xyz (parent + R(q) * sample) and of the raw
- * scaling (log(scaling / 1.6)); samples[2 * totals[4], 3] = std * z in the layout of the reference's `samples` (:666).
+ * scaling (log(scaling / 1.6)); samples[2 * totals[4], 3] = std * z in the layout of the reference's `samples` (:666),
+ * or -- unit_samples != 0 -- just z ~ N(0, 1), which the kernel multiplies by the parent's scaling itself (no mask
+ * gather on the host side).
  * sfgs_densify_masks: the decisions as byte masks (tests / diagnostics). */
 typedef struct SfgsDensifyTensor {
   const void* src;
@@ -345,8 +347,8 @@ int sfgs_densify_masks(int64_t N, const void* scratch, unsigned char* clone_out,
 int sfgs_densify_gather(int64_t N, const void* scratch, const int64_t totals[5], const SfgsDensifyTensor* tensors,
                         int32_t count, void* stream);
 int sfgs_densify_children(int64_t N, const void* scratch, const int64_t totals[5], const float* xyz,
-                          const float* rotation_raw, const float* scaling, const float* samples, float* xyz_out,
-                          float* scaling_raw_out, void* stream);
+                          const float* rotation_raw, const float* scaling, const float* samples, int32_t unit_samples,
+                          float* xyz_out, float* scaling_raw_out, void* stream);
 
 #ifdef __cplusplus
 }

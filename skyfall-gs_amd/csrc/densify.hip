@@ -150,8 +150,10 @@ densify_decide_kernel(long long N, const float* __restrict__ gnorm, const float*
     if constexpr (sizeof(OT) == 8) low = opacity[i] < min_opacity;
     else low = opacity[i] < (float)min_opacity;
     const bool prune_self = low || (use_big && smax > big_thr);               // :731-735 (max_radii2D was reset: never)
-    // children: scaling / (0.8 * 2) through the inverse activation and back (:672 then get_scaling)
-    const float cmax = expf(logf(smax / 1.6f));
+    // children: scaling / (0.8 * 2) through the inverse activation and back (:672 then get_scaling). On the GPU torch
+    // divides a tensor by a Python scalar by MULTIPLYING with the reciprocal formed in double (1 / 1.6 -> 0.625f); the
+    // CPU path divides -- 1 ulp apart for some inputs. This kernel replaces the GPU path.
+    const float cmax = expf(logf(smax * 0.625f));
     const bool prune_child = low || (use_big && cmax > big_thr);
     if (!split && !prune_self) c |= DN_KEEP_ORIG;
     if (clone && !prune_self) c |= DN_KEEP_CLONE;
@@ -253,11 +255,13 @@ densify_gather_kernel(const DensifyTable tab, long long N, const unsigned char* 
 }
 
 // child rows of xyz and raw scaling (:666-672): samples [2 * n_split_raw, 3] hold std * z for child k of the parent with
-// raw split rank r at row k * n_split_raw + r, exactly the layout of the reference's `samples`
+// raw split rank r at row k * n_split_raw + r, exactly the layout of the reference's `samples`; with unit_samples they
+// hold z alone and the parent's scaling is applied here
 __global__ void __launch_bounds__(DN_NT)
 densify_children_kernel(long long N, const unsigned char* __restrict__ code, const unsigned* __restrict__ idx,
                         const float* __restrict__ xyz, const float* __restrict__ rot_raw, const float* __restrict__ scaling,
-                        const float* __restrict__ samples, unsigned n_split_raw, unsigned n_orig, unsigned n_clone,
+                        const float* __restrict__ samples, int unit_samples, unsigned n_split_raw, unsigned n_orig,
+                        unsigned n_clone,
                         unsigned n_child, float* __restrict__ xyz_out, float* __restrict__ scaling_raw_out) {
   const long long i = (long long)blockIdx.x * DN_NT + threadIdx.x;
   if (i >= N || !(code[i] & DN_KEEP_CHILD)) return;
@@ -268,11 +272,13 @@ densify_children_kernel(long long N, const unsigned char* __restrict__ code, con
   quat_to_rot(q, R);
   const unsigned rr = idx[4 * i + 3], rk = idx[4 * i + 2];
   for (int child = 0; child < 2; ++child) {
-    const float* s = samples + 3 * ((size_t)child * n_split_raw + rr);
+    const float* sp = samples + 3 * ((size_t)child * n_split_raw + rr);
+    float s[3] = {sp[0], sp[1], sp[2]};
+    if (unit_samples) { for (int a = 0; a < 3; ++a) s[a] *= scaling[3 * i + a]; }   // torch.normal(0, std) = std * z
     const size_t row = (size_t)n_orig + n_clone + (size_t)child * n_child + rk;
     for (int a = 0; a < 3; ++a)
       xyz_out[3 * row + a] = R[3 * a] * s[0] + R[3 * a + 1] * s[1] + R[3 * a + 2] * s[2] + xyz[3 * i + a];
-    for (int a = 0; a < 3; ++a) scaling_raw_out[3 * row + a] = logf(scaling[3 * i + a] / 1.6f);
+    for (int a = 0; a < 3; ++a) scaling_raw_out[3 * row + a] = logf(scaling[3 * i + a] * 0.625f);
   }
 }
 
@@ -421,7 +427,7 @@ extern "C" int sfgs_densify_gather(int64_t N, const void* scratch, const int64_t
 
 extern "C" int sfgs_densify_children(int64_t N, const void* scratch, const int64_t totals[5], const float* xyz,
                                      const float* rotation_raw, const float* scaling, const float* samples,
-                                     float* xyz_out, float* scaling_raw_out, void* stream_) {
+                                     int32_t unit_samples, float* xyz_out, float* scaling_raw_out, void* stream_) {
   SFGS_REQUIRE(N >= 0 && totals, SFGS_E_ARG, "bad argument");
   if (N == 0 || totals[2] == 0) return SFGS_OK;
   SFGS_REQUIRE(scratch && xyz && rotation_raw && scaling && samples && xyz_out && scaling_raw_out, SFGS_E_ARG, "NULL argument");
@@ -429,7 +435,7 @@ extern "C" int sfgs_densify_children(int64_t N, const void* scratch, const int64
   const DensifyScratch s = dn_view(const_cast<void*>(scratch), N);
   { ProfScope ps_(KID_DENSIFY, stream);
     hipLaunchKernelGGL(densify_children_kernel, dim3((unsigned)dn_blocks(N)), dim3(DN_NT), 0, stream, (long long)N, s.code,
-                       s.idx, xyz, rotation_raw, scaling, samples, (unsigned)totals[4], (unsigned)totals[0],
+                       s.idx, xyz, rotation_raw, scaling, samples, (int)unit_samples, (unsigned)totals[4], (unsigned)totals[0],
                        (unsigned)totals[1], (unsigned)totals[2], xyz_out, scaling_raw_out); }
   SFGS_POST_LAUNCH("densify_children", stream, 0);
   return SFGS_OK;

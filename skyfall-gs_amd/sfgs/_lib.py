@@ -105,7 +105,7 @@ SYMBOLS = {
                                       C.c_float, _I32, _V, _SZ, C.POINTER(C.c_int64), _V]),
     "sfgs_densify_masks": (C.c_int, [_I64, _V, _V, _V, _V, _V]),
     "sfgs_densify_gather": (C.c_int, [_I64, _V, C.POINTER(C.c_int64), C.POINTER(SfgsDensifyTensor), _I32, _V]),
-    "sfgs_densify_children": (C.c_int, [_I64, _V, C.POINTER(C.c_int64), _V, _V, _V, _V, _V, _V, _V]),
+    "sfgs_densify_children": (C.c_int, [_I64, _V, C.POINTER(C.c_int64), _V, _V, _V, _V, C.c_int32, _V, _V, _V]),
     "sfgs_prepass_forward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V]),
     "sfgs_prepass_backward": (C.c_int, [_I32, _V, _V, _V, _V, _I32, _V, _V, _V, _V, _V, _V, _V]),
 }

@@ -144,19 +144,15 @@ def densify_and_prune(model, max_grad, min_opacity, extent, max_screen_size, sam
                 outs[job[1]["name"]] = dst
         # ---- the computed child rows: xyz = parent + R(q) * sample, raw scaling = log(scaling / 1.6) (:666-672) -------------
         if n_child > 0:
-            if samples is None:
-                stds = None  # std * z with z ~ N(0, 1): the kernel reads `samples` as the reference's torch.normal output
-                z = torch.randn(2 * raw_split, 3, device=dev)
-                split_mask = torch.empty(N, dtype=torch.uint8, device=dev)
-                L.check(lib.sfgs_densify_masks(N, L.ptr(scratch), None, L.ptr(split_mask), None, stream))
-                stds = scaling[split_mask.bool()].repeat(2, 1)
-                samples = z * stds
+            unit = samples is None
+            if unit:   # z ~ N(0, 1); the kernel applies the parent's scaling (torch.normal(0, std) = std * z): no mask gather
+                samples = torch.randn(2 * raw_split, 3, device=dev)
             samples = samples.to(dev, torch.float32).contiguous()
             if tuple(samples.shape) != (2 * raw_split, 3):
                 raise ValueError(f"samples must have shape ({2 * raw_split}, 3)")
             L.check(lib.sfgs_densify_children(N, L.ptr(scratch), totals, L.ptr(model._xyz.detach().contiguous()),
                                               L.ptr(model._rotation.detach().contiguous()), L.ptr(scaling), L.ptr(samples),
-                                              L.ptr(outs["xyz"]), L.ptr(outs["scaling"]), stream))
+                                              int(unit), L.ptr(outs["xyz"]), L.ptr(outs["scaling"]), stream))
     # ---- optimizer surgery exactly like cat_tensors_to_optimizer / _prune_optimizer (:564-624) ----------------------------
     optimizable, new_state = {}, {}
     for job, dst in jobs:
@@ -218,7 +214,9 @@ def reorder_zcurve(model, bits=10):
     but the waves of the binning kernel then append to the SAME coarse bin (one merged atomic, full-line slab stores:
     `preprocess` 0.23 -> 0.17 ms at 2 M Gaussians) and tiles gather neighbouring records. The
     reference's own order -- a gridded point cloud, children appended in parent order -- is partly coherent already;
-    install(..., zcurve_order=True) restores it at every densification. Returns the permutation."""
+    install(..., zcurve_order=True) restores it at every densification. Returns the permutation.
+    filter_3D is permuted only while it has one row per Gaussian; right after a densification it still has the OLD row
+    count and is left alone -- call compute_3D_filter afterwards, as train.py:330 does after every densify_and_prune."""
     perm = zcurve_permutation(model._xyz, bits)
     n = perm.numel()
     opt = model.optimizer
@@ -248,14 +246,18 @@ def reorder_zcurve(model, bits=10):
 
 
 _ORIG = {}
+_VARIANT = {}
 
 
 def install(gaussian_model_cls, zcurve_order=False):
     """zcurve_order=True: every densify_and_prune is followed by reorder_zcurve (row order then differs from the
     reference's [survivors | clones | children]; everything else is identical)."""
     if gaussian_model_cls in _ORIG:
-        return
+        if _VARIANT.get(gaussian_model_cls) == bool(zcurve_order):
+            return
+        uninstall(gaussian_model_cls)       # a different variant was installed: re-patch instead of ignoring the request
     _ORIG[gaussian_model_cls] = gaussian_model_cls.densify_and_prune
+    _VARIANT[gaussian_model_cls] = bool(zcurve_order)
     if zcurve_order:
         def densify_and_prune_zcurve(model, *args, **kwargs):
             out = densify_and_prune(model, *args, **kwargs)
@@ -269,3 +271,4 @@ def install(gaussian_model_cls, zcurve_order=False):
 def uninstall(gaussian_model_cls):
     if gaussian_model_cls in _ORIG:
         gaussian_model_cls.densify_and_prune = _ORIG.pop(gaussian_model_cls)
+        _VARIANT.pop(gaussian_model_cls, None)

@@ -80,6 +80,41 @@ def test_fused_densify_and_prune_matches_the_real_method():
     assert m._xyz.shape[0] == n_new
 
 
+def test_default_samples_path_equals_explicit_std_times_z():
+    """samples=None (what train.py gets): the kernel multiplies z ~ N(0, 1) by the parent's scaling itself (no host-side
+    mask gather). Same generator state -> same z -> the result equals the explicit samples = z * std path."""
+    from sfgs import densify
+    z = np.load(GOLD)
+    cfg = json.loads(str(z["config"]))
+    dev = torch.device("cuda:0")
+
+    class M(types.SimpleNamespace):
+        get_scaling = property(lambda self: torch.exp(self._scaling))
+        get_opacity = property(lambda self: torch.sigmoid(self._opacity))
+    outs = []
+    for explicit in (False, True):
+        m = M(**_model(z, dev).__dict__)
+        m.percent_dense = cfg["percent_dense"]
+        raw_split = int(z["ret"][1])
+        torch.manual_seed(77)
+        samples = None
+        if explicit:
+            zz = torch.randn(2 * raw_split, 3, device=dev)
+            import densify_rule
+            d = densify_rule.decisions(m.xyz_gradient_accum.cpu(), m.xyz_gradient_accum_abs.cpu(), m.denom.cpu(),
+                                       m.get_scaling.detach().cpu(), m.get_opacity.detach().cpu(), cfg["max_grad"],
+                                       cfg["min_opacity"], cfg["extent"], cfg["max_screen_size"], cfg["percent_dense"])
+            n0 = m._xyz.shape[0]
+            split = d["split"][:n0].to(dev)    # clones are never split in the same pass (their gradients are padded zeros)
+            assert int(split.sum()) == raw_split and not bool(d["split"][n0:].any())
+            samples = zz * m.get_scaling.detach()[split].repeat(2, 1)
+        ret = densify.densify_and_prune(m, cfg["max_grad"], cfg["min_opacity"], cfg["extent"], cfg["max_screen_size"],
+                                        samples=samples)
+        outs.append((ret, m._xyz.detach().clone(), m._scaling.detach().clone()))
+    assert tuple(outs[0][0]) == tuple(outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 @pytest.mark.parametrize("n,q", [(1, 0.3), (2, 0.5), (1000, 0.0), (1000, 1.0), (100003, 0.85), (2_000_000, 0.9137)])
 def test_quantile_matches_torch(n, q):
     from sfgs.densify import quantile_linear
