@@ -48,13 +48,15 @@ import threading
 
 # Wrapper state. The forward runs on the caller's thread, the backward on an autograd worker, and nothing stops two host
 # threads from rendering at once: every piece of state below is either immutable once published (the counters dict is
-# REPLACED, never mutated), keyed by (device, stream) / (device, viewport) with idempotent updates, or guarded by _lock.
-_lock = threading.Lock()
+# REPLACED, never mutated), keyed by device / (device, viewport) with idempotent updates, or thread-local.
 _last_counters = {}
 _stats = {"full": False}
-_pinned = {}     # (device index, stream) -> (pinned host buffer the counters are read through, event)
+_tls = threading.local()   # .pinned: (device index, stream) -> (pinned host buffer the counters are read through, event);
+                           # per host thread, dies with the thread
 _ncb_cache = {}  # (W, H) -> number of coarse bins
 _zeros = {}      # device index -> 1-element zero tensor
+_budget = {}     # device index -> scratch budget in bytes (half of the device memory)
+_cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin capacity) to plan with
 
 
 def _scratch_budget(dev):
@@ -64,15 +66,25 @@ def _scratch_budget(dev):
     return b
 
 
-_budget = {}
-
-
 def _zero(dev):
     z = _zeros.get(dev.index)
     if z is None:
         z = _zeros[dev.index] = torch.zeros(1, 1, 1, dtype=torch.float32, device=dev)
     return z
-_cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin capacity) to plan with
+
+
+def _pinned_counters(dev, stream):
+    """This thread's pinned counter buffer + event for (device, stream): frames on different streams or from different
+    host threads never share one."""
+    table = getattr(_tls, "pinned", None)
+    if table is None:
+        table = _tls.pinned = {}
+    key = (dev.index, stream.cuda_stream)
+    entry = table.get(key)
+    if entry is None:
+        entry = table[key] = (torch.empty(8, dtype=torch.int64).pin_memory(),
+                              torch.cuda.Event(enable_timing=False, blocking=False))
+    return entry
 
 
 def collect_full_counters(on=True):
@@ -94,15 +106,18 @@ def _f32c(t, name, shape_tail=None):
         raise TypeError(f"{name} must be a tensor")
     if t.dtype != torch.float32:
         raise ValueError(f"{name} must be float32, got {t.dtype}")
-    if not t.is_cuda:
-        raise ValueError(f"{name} must live on the GPU (got {t.device}); this rasterizer has no CPU path")
+    _backend.check_device(t, name)
     if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
         raise ValueError(f"{name}: expected shape [N,{','.join(map(str, shape_tail))}], got {tuple(t.shape)}")
     return t.contiguous()
 
 
-def _frame(settings, dev, sh_coeffs, keep):
+def _settings_tensors(settings, dev):
+    """Validation of the settings tuple (above the backend seam): returns the contiguous float32 tensors
+    (subpixel_offset or None, bg, viewmatrix, projmatrix, campos)."""
     H, W = int(settings.image_height), int(settings.image_width)
+    if H <= 0 or W <= 0:
+        raise ValueError(f"image size must be positive, got {W}x{H}")
     sub = settings.subpixel_offset
     if sub is not None:
         if tuple(sub.shape) != (H, W, 2):
@@ -117,6 +132,12 @@ def _frame(settings, dev, sh_coeffs, keep):
     for t in (sub, bg, view, proj, campos):
         if t is not None and t.device != dev:
             raise ValueError("all rasterizer inputs must be on the same device")
+    return sub, bg, view, proj, campos
+
+
+def _frame(settings, dev, sh_coeffs, keep):
+    H, W = int(settings.image_height), int(settings.image_width)
+    sub, bg, view, proj, campos = _settings_tensors(settings, dev)
     keep.extend([sub, bg, view, proj, campos])
     rows = getattr(settings, "tile_rows", None) or (0, 0)
     return L.SfgsFrame(C_sizeof(L.SfgsFrame), H, W, float(settings.tanfovx), float(settings.tanfovy),
@@ -193,14 +214,7 @@ class _Rasterize(torch.autograd.Function):
                 # stream. Both stages are redone in the rare case a capacity was exceeded (an overflowing plan is
                 # memory-safe).
                 tstream = torch.cuda.current_stream(dev)
-                pkey = (dev.index, tstream.cuda_stream)   # one buffer per (device, stream): frames on different
-                pkey = pkey + (threading.get_ident(),)    # ... nor do two host threads that share a stream
-                pinned = _pinned.get(pkey)
-                if pinned is None:
-                    with _lock:
-                        pinned = _pinned.setdefault(pkey, (torch.empty(8, dtype=torch.int64).pin_memory(),
-                                                           torch.cuda.Event(enable_timing=False, blocking=False)))
-                pin, ev = pinned
+                pin, ev = _pinned_counters(dev, tstream)
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
                                                      bins.numel(), cap, ccap, L.C.c_void_p(pin.data_ptr()), stream))
@@ -284,8 +298,27 @@ class _Rasterize(torch.autograd.Function):
         return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None
 
 
+class _HipBackend:
+    """The product's only backend: libsfgs.so on the GPU. The argument-validation layer (GaussianRasterizer.forward,
+    _f32c) sits above this seam; tests/ may swap `_backend` for a checker-backed double to drive the reference's real
+    render() glue through that layer on a GPU-less host -- nothing in this package ever does."""
+    name = "hip"
+
+    @staticmethod
+    def check_device(t, name):
+        if not t.is_cuda:
+            raise ValueError(f"{name} must live on the GPU (got {t.device}); this rasterizer has no CPU path")
+
+    @staticmethod
+    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings):
+        return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
+
+
+_backend = _HipBackend
+
+
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings):
-    return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
+    return _backend.rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
 
 
 class GaussianRasterizer(nn.Module):
@@ -326,6 +359,7 @@ class GaussianRasterizer(nn.Module):
         for name, t in (("scales", scales), ("rotations", rotations), ("colors_precomp", colors_precomp), ("shs", shs)):
             if t is not None and (t.shape[0] != N or t.device != means3D.device):
                 raise ValueError(f"{name}: first dimension / device must match means3D")
+        _settings_tensors(self.raster_settings, means3D.device)   # shapes / dtypes / devices of the 14-field tuple
         color, depth, norm, alpha, radii = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
                                                                rotations, self.raster_settings)
         return color, depth, norm, alpha, radii, None
