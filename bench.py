@@ -54,9 +54,9 @@ def main():
                     help="untimed steps BEFORE the W warm-up steps (the same count on every rank): the device needs ~30 ms of "
                          "sustained load to reach its sustained clock state (tools/diag_ramp.py: 1.35 -> 1.25 ms/step over "
                          "the first 25 steps of a process, again after 2 s of idle); 0 disables")
-    ap.add_argument("--n", type=int, default=2_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="0 = skip the CPU-baseline leg; otherwise it runs on the workload's own N (a bounded tile sample, ~30-60 s)")
     ap.add_argument("--forward-only", action="store_true", help="report render FPS instead of train-step Gaussians/s")
     ap.add_argument("--d2h-async", action="store_true", help="with --forward-only: download every frame through sfgs.video.FrameDownloader (pinned ring, side stream; informational)")
@@ -65,9 +65,25 @@ def main():
     ap.add_argument("--order", choices=["random", "morton"], default="random",
                     help="storage order of the Gaussians: 'random' (the headline: worst case for the id -> record gathers) "
                          "or 'morton' (sorted along a Z-curve of the ground position; informational)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+                    help="SURVEY 8d workloads with their exact geometry. cfg2 (the headline, BASELINE.json configs[1]): 2 M, "
+                         "1920x1080, z ~ U(250, 350). cfg3 (configs[2], the IDU loop's rasterizer share): 108 forward-only "
+                         "renders at 1024x1024 (train.py:360-525) followed by the timed fwd+bwd steps at 1024x1024, both rates "
+                         "in the one JSON line. cfg4 (configs[3]): 5 M, 2560x1440, z ~ U(500, 700), dL/ddepth != 0. "
+                         "--n / --width / --height override the config's size")
+    ap.add_argument("--zrange", type=float, nargs=2, default=None, metavar=("ZMIN", "ZMAX"),
+                    help="view depth range of the synthetic scene (default: the config's)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: initialise torch.distributed over RCCL (backend nccl, world size 1) and run the "
+                         "24 966-float device all-reduce every step, as the N > 1 runs do")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-only", action="store_true", help="run only the CPU-baseline legs and print them")
     args = ap.parse_args()
+    CFG = {"cfg2": dict(n=2_000_000, width=1920, height=1080, zrange=(250.0, 350.0), configs_index=1),
+           "cfg3": dict(n=2_000_000, width=1024, height=1024, zrange=(250.0, 350.0), configs_index=2),
+           "cfg4": dict(n=5_000_000, width=2560, height=1440, zrange=(500.0, 700.0), configs_index=3)}[args.config]
+    args.n, args.width, args.height = args.n or CFG["n"], args.width or CFG["width"], args.height or CFG["height"]
+    zrange = tuple(args.zrange) if args.zrange else CFG["zrange"]
     if args.cpu_leg:
         return cpu_leg(args.cpu_leg, args.n, args.width, args.height)
     if args.cpu_only:
@@ -98,9 +114,15 @@ def main():
     dev = torch.device("cuda", local_dev)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            s_.close()
         kw = {"device_id": dev} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
@@ -111,7 +133,8 @@ def main():
 
     W, H, N = args.width, args.height, args.n
     sh = args.sh_degree
-    frame, g = scene(N, W, H, seed=rank) if sh < 0 else scene(N, W, H, seed=rank, mode="sh", sh_degree=sh)
+    frame, g = (scene(N, W, H, seed=rank, zrange=zrange) if sh < 0 else
+                scene(N, W, H, seed=rank, zrange=zrange, mode="sh", sh_degree=sh))
     if args.order == "morton":
         from sfgs.synth import morton_order
         perm = morton_order(g["means3D"])
@@ -133,8 +156,8 @@ def main():
         from sfgs.video import FrameDownloader
         downloader = FrameDownloader(depth=3, device=dev)
 
-    def step():
-        if args.forward_only:
+    def step(forward_only=args.forward_only):
+        if forward_only:
             with torch.no_grad():
                 out = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=t["colors_precomp"],
                            opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
@@ -182,6 +205,22 @@ def main():
     for _ in range(max(args.prewarm_steps, 0)):   # a fixed count: with N > 1 every step holds a collective
         step()
     torch.cuda.synchronize(dev)
+    idu = None
+    if args.config == "cfg3" and not args.forward_only:
+        # the IDU episode's render phase (train.py:360-525: 108 pseudo-camera renders under no_grad), then the training steps
+        n_idu = 108
+        for _ in range(5):
+            step(True)
+        fence()
+        ti = time.perf_counter()
+        for _ in range(n_idu):
+            step(True)
+        fence()
+        dt_idu = time.perf_counter() - ti
+        idu = {"renders": n_idu, "ms_per_render": round(dt_idu / n_idu * 1e3, 4), "frames_per_s": round(n_idu / dt_idu, 1),
+               "what": "108 forward-only 1024x1024 renders (no_grad, no D2H copy) before the timed fwd+bwd steps"}
+        for _ in range(10):
+            step()
     L.profile_select(None)
     n_prof = max(args.warmup - 1, 1) if args.warmup else 0   # the first step sizes the scratch (may re-plan): not timed
     for i in range(args.warmup):
@@ -245,7 +284,8 @@ def main():
         unit, value = "frames/s", world / (ms_step * 1e-3)
     else:
         B_step = 128 * N + 184 * Nvis + 124 * D_ref + 64 * P
-        metric, unit = "train-step Gaussians/s (fwd+bwd raster) @1080p", "Gaussians/s"
+        metric = "train-step Gaussians/s (fwd+bwd raster) @%s" % ("1080p" if (W, H) == (1920, 1080) else f"{W}x{H}")
+        unit = "Gaussians/s"
         value = world * N / (ms_step * 1e-3)
 
     # per-kernel view (rank 0's launches): dominant kernel from the timed region, the split from the warm-up steps
@@ -284,7 +324,7 @@ def main():
                      "gpu_busy_ms_per_step": round(sum(v["ms_per_step"] for v in per_kernel.values()), 4)}
 
     cpu_baseline = None
-    if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only:
+    if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only and args.config == "cfg2":
         cpu_baseline = run_cpu_baseline(N, W, H)
 
     if rank == 0:
@@ -292,17 +332,21 @@ def main():
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic cfg-2 scene, N={N} Gaussians/GPU, {W}x{H}, "
+            "config": {"workload": f"configs[{CFG['configs_index']}]: synthetic {args.config} scene (SURVEY 8d), N={N} Gaussians/GPU, "
+                                   f"{W}x{H}, z ~ U({zrange[0]:g}, {zrange[1]:g}), "
                                    f"{'colors_precomp' if sh < 0 else 'SH degree %d in-kernel' % sh}, "
-                                   f"kernel_size=0.1, seed=rank, one scene per GPU",
+                                   f"kernel_size=0.1, dL/dimage and dL/ddepth ~ N(0,1)/P, seed=rank, one scene per GPU",
+                       "name": args.config, "zrange": list(zrange),
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
                        "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
-                       "collective_backend": backend if world > 1 else None,
+                       "collective_backend": backend if dist is not None else None,
                        "prewarm_steps": args.prewarm_steps, "order": args.order},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
         }
+        if idu is not None:
+            out["idu_render_phase"] = idu
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -79,7 +79,9 @@ class SharedGradBucket:
     (loading its next scene, minutes of IDU refinement) holds the other ranks' optimizer steps: that is the price of
     one shared model, and why the launcher leaves sharing off by default."""
 
-    def __init__(self, params, optimizer=None):
+    def __init__(self, params, optimizer=None, single_rank_collectives=False):
+        # single_rank_collectives: issue the collectives even in a group of ONE rank (diagnostics / the RCCL smoke test)
+        self._single = bool(single_rank_collectives)
         self.params = [p for p in params if p.requires_grad]
         self.optimizer = optimizer             # whose state[p] = {step, exp_avg, exp_avg_sq} is shared (torch.optim.Adam)
         n = self.n = sum(p.numel() for p in self.params)
@@ -93,9 +95,9 @@ class SharedGradBucket:
     def numel(self):
         return self.n
 
-    @staticmethod
-    def _distributed():
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    def _distributed(self):
+        return (dist.is_available() and dist.is_initialized() and
+                (dist.get_world_size() > 1 or getattr(self, "_single", False)))
 
     @staticmethod
     def _pack(dst, tensors):
