@@ -212,8 +212,10 @@ int sfgs_ssim_backward(const float* img1, const float* img2, int32_t B, int32_t 
                        void* stream);
 
 /* simple_knn distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other
- * points (index-excluded; fewer than 3 others: mean over those that exist). Exact. scratch:
- * sfgs_knn_scratch_bytes(N) bytes (currently 0; may be NULL). */
+ * points (index-excluded; fewer than 3 others: mean over those that exist). Exact for every input (brute force up to
+ * 32 768 points; above, a Z-curve counting sort with box-pruned search -- the layout of the reference's simple-knn).
+ * scratch: sfgs_knn_scratch_bytes(N) bytes, 256-byte aligned (0 / NULL for small N). Non-finite points get 0 and are
+ * nobody's neighbour. */
 size_t sfgs_knn_scratch_bytes(int32_t N);
 int sfgs_knn_dist2(const float* xyz, int32_t N, float* out, void* scratch, size_t scratch_bytes,
                    void* stream);

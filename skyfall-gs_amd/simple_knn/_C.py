@@ -1,5 +1,6 @@
 """simple_knn._C.distCUDA2(points[N,3] float32 GPU) -> [N] float32: mean squared distance to the three
-nearest other points (reference call site scene/gaussian_model.py:324). Kernel: csrc/knn.hip."""
+nearest other points (reference call site scene/gaussian_model.py:324). Kernels: csrc/knn.hip (exact; brute force for
+small clouds, Z-curve counting sort + box-pruned search above 32 768 points)."""
 import torch
 
 from sfgs import _lib as L
@@ -17,7 +18,9 @@ def distCUDA2(points):
     N = int(pts.shape[0])
     dev = pts.device
     out = torch.empty(N, dtype=torch.float32, device=dev)
+    nbytes = int(lib.sfgs_knn_scratch_bytes(N))     # 0 for small clouds (brute force); the spatial path sorts into scratch
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     with torch.cuda.device(dev):
         stream = L.C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        L.check(lib.sfgs_knn_dist2(L.ptr(pts), N, L.ptr(out), None, 0, stream))
+        L.check(lib.sfgs_knn_dist2(L.ptr(pts), N, L.ptr(out), L.ptr(scratch), nbytes, stream))
     return out
