@@ -19,6 +19,16 @@
 
 #include "sfgs_internal.h"
 
+// Ablation builds (tools/ablate_bwd.sh; never the shipped library): -DSFGS_BWD_ABLATE=<bits> removes one part of
+// composite_bwd so that its cost INSIDE the kernel (with the overlap the other waves provide) can be read off a timing:
+//   1 no zero fill of UW   2 no phase 1 (no pixel has a blended entry)   4 no phase-2 slot loop   8 no record stores
+//  16 no record gathers (every batch reuses the first one's records)
+// -DSFGS_BWD_SPARSE_CLEAR: experiment -- UW is zeroed once; after phase 2 every pixel lane clears the slots it wrote
+// (its own blended entries) instead of the wave zero-filling all 16 x 65 pairs per batch.
+#ifndef SFGS_BWD_ABLATE
+#define SFGS_BWD_ABLATE 0
+#endif
+
 namespace sfgs {
 
 // Compositing backward. Workgroup = 4 independent waves = 2x2 tiles of 8x8 pixels (as the forward).
@@ -238,8 +248,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   if ((unsigned)hdr[HDR_PREFILLED] == 0u) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (unsigned k = kmax + lane; k < L; k += 64) {
-      float4* dst = dupgrad + (size_t)sorted_dup[s + k] * 3;
-      dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
+      float4* dst = dupgrad + (size_t)sorted_dup[s + k] * DG_F4;
+#pragma unroll
+      for (int q = 0; q < DG_F4; ++q) dst[q] = zero4;
     }
   }
   if (kmax == 0) return;
@@ -252,7 +263,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   // Software pipeline over the batches (back to front): the dependent id -> record gathers of the NEXT batch are in
   // flight while this one is processed, the ids of the one after are fetched alongside (as in the forward).
   float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
-  unsigned dup_cur = 0, id_next = 0, dup_next = 0;
+  unsigned dup_cur = 0, id_next = 0;
   {
     const unsigned b0 = (unsigned)(nbatch - 1) * B;
     // the duplicate index of entry ej is needed by all four lanes (ej, row) of the entry: each stores a quarter of
@@ -260,10 +271,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     if ((unsigned)ej < kmax - b0) dup_cur = sorted_dup[s + b0 + ej];
     if ((unsigned)lane < kmax - b0) {
       const unsigned id = sorted_id[s + b0 + lane];
-      n0 = rec[3 * (size_t)id]; n1 = rec[3 * (size_t)id + 1]; n2 = rec[3 * (size_t)id + 2];
+      n0 = rec[REC_F4 * (size_t)id]; n1 = rec[REC_F4 * (size_t)id + 1]; n2 = rec[REC_F4 * (size_t)id + 2];
     }
     if (nbatch >= 2) {
-      dup_next = sorted_dup[s + b0 - B + ej];
       if (lane < B) id_next = sorted_id[s + b0 - B + lane];
     }
   }
@@ -277,6 +287,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   // prefetch loads: the s_waitcnt vmcnt(0) the compiler places at the loop's back edge (for the prefetched registers)
   // then only sees memory operations that had a whole batch of arithmetic to complete. Issued at the end of their own
   // iteration, the stores were waited for every batch (measured: the kernel had a 0.08 ms floor of pure store latency).
+#if defined(SFGS_BWD_SPARSE_CLEAR)
+  for (int i = lane; i < B * ROW; i += 64) lds.UW[i] = make_float2(0.f, 0.f);
+#endif
   float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats grp, 4 + grp, 8 + grp
   unsigned p_dup = 0;
   bool p_valid = false;
@@ -291,19 +304,33 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     }
     // this pixel's blended entries of the batch: bit j <=> entry b0 + j
     unsigned pm = (((bi & 2) ? mw.y : mw.x) >> (16 * (bi & 1))) & 0xffffu;
+    if (SFGS_BWD_ABLATE & 2) pm = 0u;
+#if defined(SFGS_BWD_SPARSE_CLEAR)
+    const unsigned pm_batch = pm;
+#endif
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
     if (bi >= 1) {  // batches below the last one are always full
-      if (lane < B) { n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2]; }
-      dup_cur = dup_next;
+      if (!(SFGS_BWD_ABLATE & 16))
+      if (lane < B) { n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2]; }
+      // the duplicate indices of the NEXT batch (needed only when its records are stored): loaded one batch ahead into
+      // the register whose old value was copied (my_dup) at the top of this iteration. A two-deep rotation
+      // (cur <- next <- load) made the compiler copy the freshly loaded value right away: an s_waitcnt vmcnt(0) directly
+      // behind the record gathers, i.e. every wave sat out the full gather latency once per batch.
+      dup_cur = sorted_dup[s + b0 - B + ej];
       if (bi >= 2) {
-        dup_next = sorted_dup[s + b0 - 2 * B + ej];
         if (lane < B) id_next = sorted_id[s + b0 - 2 * B + lane];
       }
     }
-    if (p_valid) {  // the previous batch's gradient records
-      float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
-      dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
+    if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {  // the previous batch's gradient records
+      if constexpr (DG_F4 == 4) {   // one 16-byte quarter per lane: the entry's four lanes fill a 64-byte sector
+        dupgrad[(size_t)p_dup * 4 + grp] = make_float4(pq0, pq1, pq2, 0.f);
+      } else {
+        float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
+        dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
+      }
     }
+#if !defined(SFGS_BWD_SPARSE_CLEAR)
+    if (!(SFGS_BWD_ABLATE & 1))
     {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2.
        // (ds_write_addtid_b32 would do this at twice the LDS store rate -- the kernel drops from 0.49 to 0.46 ms -- but
        // on gfx950 it does NOT add the workgroup's LDS base: with several workgroups per CU it writes into its
@@ -314,6 +341,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       for (int i = 0; i < (NZ + 63) / 64; ++i)
         if (i * 64 + lane < NZ) z[i * 64 + lane] = make_float2(0.f, 0.f);
     }
+#endif
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 1: lane = pixel, each lane walks its own blended entries back to front -------------------------
@@ -352,10 +380,15 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   { const float2 uw##A = UWrow[A], uw##Bq = UWrow[Bq], uw##C = UWrow[C], uw##D = UWrow[D];       \
     SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D); }                                           \
   asm volatile("" ::: "memory");
+        if (SFGS_BWD_ABLATE & 4) {
+          const float2 uw = UWrow[0];
+          pg = {uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y};
+        } else {
         SFGS_P2x4(0, 1, 2, 3)
         SFGS_P2x4(4, 5, 6, 7)
         SFGS_P2x4(8, 9, 10, 11)
         SFGS_P2x4(12, 13, 14, 15)
+        }
 #undef SFGS_P2x4
 #undef SFGS_P2
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
@@ -374,6 +407,24 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #undef SFGS_P2
       }
     }
+#if defined(SFGS_BWD_SPARSE_CLEAR)
+    {  // every lane has read its phase-2 slots (in-order LDS); clear the slots THIS pixel wrote
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      unsigned pc = pm_batch;
+      while (__ballot(pc != 0u) != 0ull) {
+        unsigned fb;
+        asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pc));
+        const unsigned j1 = min(fb ^ 31u, (unsigned)B);
+        pc = __builtin_amdgcn_ubfe(pc, 0u, j1);
+        asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pc));
+        const unsigned j2 = min(fb ^ 31u, (unsigned)B);
+        pc = __builtin_amdgcn_ubfe(pc, 0u, j2);
+        lds.UW[j1 * ROW + lane] = make_float2(0.f, 0.f);
+        lds.UW[j2 * ROW + lane] = make_float2(0.f, 0.f);
+      }
+    }
+#endif
     // Combine the four partial lanes (ej, row 0..3) of every entry in a fixed order (deterministic). The record's 12
     // floats are linear in the sums, so every lane forms them from its PARTIAL sums first; then two rounds of the gfx950
     // half-wave / row SWAPS reduce two (then four) values per instruction pair and leave float 4 k + row of the record
@@ -405,9 +456,13 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     p_valid = (unsigned)ej < cnt;
     __builtin_amdgcn_wave_barrier();
   }
-  if (p_valid) {
-    float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
-    dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
+  if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {
+    if constexpr (DG_F4 == 4) {
+      dupgrad[(size_t)p_dup * 4 + grp] = make_float4(pq0, pq1, pq2, 0.f);
+    } else {
+      float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
+      dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
+    }
   }
 }
 
@@ -445,7 +500,7 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HDR_PREFILLED] = fill ? 1ull : 0ull;
   if (!fill) return;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const size_t n4 = (size_t)n_dup * 3;
+  const size_t n4 = (size_t)n_dup * DG_F4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dupgrad[i] = zero4;
 }
 
@@ -454,7 +509,8 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
 __global__ void __launch_bounds__(256)
 dupgrad_reduce_kernel(const unsigned long long* __restrict__ hdr, const uint2* __restrict__ big_chunks,
                       unsigned chunk_cap, const uint2* __restrict__ dup, float4* __restrict__ dupgrad) {
-  __shared__ float part[4][12];
+  constexpr int NF = DUPGRAD_FLOATS;   // every float of the record is summed in place (padding floats are zeros)
+  __shared__ float part[4][NF];
   const unsigned n_chunks = (unsigned)min(hdr[HDR_BIG_CHUNKS], (unsigned long long)chunk_cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (unsigned j = blockIdx.x; j < n_chunks; j += gridDim.x) {
@@ -463,32 +519,55 @@ dupgrad_reduce_kernel(const unsigned long long* __restrict__ hdr, const uint2* _
     const unsigned first = gc.y * BWD_CHUNK;
     const unsigned n = min(BWD_CHUNK, dr.y - first);
     const size_t d0 = (size_t)dr.x + first;
-    float v[12];
+    float v[NF];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] = 0.f;
+    for (int i = 0; i < NF; ++i) v[i] = 0.f;
     for (unsigned i = threadIdx.x; i < n; i += 256) {
-      const float4 x0 = dupgrad[(d0 + i) * 3], x1 = dupgrad[(d0 + i) * 3 + 1], x2 = dupgrad[(d0 + i) * 3 + 2];
-      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w;
-      v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
-      v[8] += x2.x; v[9] += x2.y; v[10] += x2.z; v[11] += x2.w;
+#pragma unroll
+      for (int q = 0; q < DG_F4; ++q) {
+        const float4 x = dupgrad[(d0 + i) * DG_F4 + q];
+        v[4 * q] += x.x; v[4 * q + 1] += x.y; v[4 * q + 2] += x.z; v[4 * q + 3] += x.w;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < NF; ++i) {
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) v[i] += __shfl_xor(v[i], d);
     }
     __syncthreads();   // every record of the chunk has been read (and `part` is free again)
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) part[wave][i] = v[i];
+      for (int i = 0; i < NF; ++i) part[wave][i] = v[i];
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
+    if (threadIdx.x < NF) {
       const float s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-      reinterpret_cast<float*>(dupgrad + d0 * 3)[threadIdx.x] = s;
+      reinterpret_cast<float*>(dupgrad + d0 * DG_F4)[threadIdx.x] = s;
     }
   }
 }
+
+// accumulators of one Gaussian's record sum: DG_F4 float4s, added componentwise in record layout
+struct DupAcc {
+  float4 q[DG_F4];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < DG_F4; ++i) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void add(const float4* __restrict__ r) {
+#pragma unroll
+    for (int i = 0; i < DG_F4; ++i) {
+      const float4 x = r[i];
+      q[i].x += x.x; q[i].y += x.y; q[i].z += x.z;
+      if (DG_F4 == 3) q[i].w += x.w;      // the fourth float of a 64-byte record's quarters is padding
+    }
+  }
+  // float f of the record in Grad2D order (gmx gmy absx absy | gA gB gC gop | r g b depth)
+  __device__ __forceinline__ float get(int f) const {
+    if constexpr (DG_F4 == 3) { const float4 v = q[f >> 2]; const int c = f & 3; return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+    else { const float4 v = q[f & 3]; const int c = f >> 2; return c == 0 ? v.x : c == 1 ? v.y : v.z; }   // float 4 k + r at quarter r, slot k
+  }
+};
 
 // one thread per Gaussian. K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree:
 // compile-time so that the coefficient / gradient rows live in registers, not scratch.
@@ -502,8 +581,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
                       float* __restrict__ g_rots, float* __restrict__ g_opac, float* __restrict__ g_colors,
                       float* __restrict__ g_shs) {
   constexpr int PB_CHUNK = 128;   // records per staging chunk and wave: 6 KB of LDS
-  static_assert((PB_CHUNK * 3) % 64 == 0, "whole load rounds");
-  __shared__ float4 pb_stage[PRE_BLOCK / 64][PB_CHUNK * 3];
+  static_assert((PB_CHUNK * DG_F4) % 64 == 0, "whole load rounds");
+  __shared__ float4 pb_stage[PRE_BLOCK / 64][PB_CHUNK * DG_F4];
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const bool valid = g < N;
   const int lane = threadIdx.x & 63;
@@ -514,14 +593,10 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   const bool vis = valid && radii[g] > 0;
   unsigned d0 = 0, cnt = 0;
   if (vis) { const uint2 dr = dup[g]; d0 = dr.x; cnt = dr.y; }
-  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+  DupAcc acc;
+  acc.zero();
   if (cnt > BWD_BIG) {   // pre-reduced by dupgrad_reduce_kernel: add the chunk heads (<= a few dozen)
-    for (unsigned d = d0; d < d0 + cnt; d += BWD_CHUNK) {
-      const float4 x0 = dupgrad[(size_t)d * 3], x1 = dupgrad[(size_t)d * 3 + 1], x2 = dupgrad[(size_t)d * 3 + 2];
-      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
-    }
+    for (unsigned d = d0; d < d0 + cnt; d += BWD_CHUNK) acc.add(dupgrad + (size_t)d * DG_F4);
   }
   // Gaussians with at most COOP records (almost all): the records of a wave's Gaussians are CONTIGUOUS (the forward
   // reserves duplicate indices in thread order), so the wave streams them through LDS in chunks of PB_CHUNK records
@@ -541,23 +616,17 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     for (unsigned c0 = w0; c0 < w1; c0 += PB_CHUNK) {   // w0 >= w1 when the wave has no such Gaussian
       const unsigned c1 = min(c0 + PB_CHUNK, w1);
       if (__ballot(small && rb < c1 && re > c0) == 0ull) continue;   // a stretch that belongs to bigger splats only
-      const unsigned n4 = (c1 - c0) * 3;
+      const unsigned n4 = (c1 - c0) * DG_F4;
 #pragma unroll
-      for (int k = 0; k < PB_CHUNK * 3 / 64; ++k) {
+      for (int k = 0; k < PB_CHUNK * DG_F4 / 64; ++k) {
         const unsigned u = k * 64 + lane;
-        if (u < n4) stage[u] = dupgrad[(size_t)c0 * 3 + u];
+        if (u < n4) stage[u] = dupgrad[(size_t)c0 * DG_F4 + u];
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (small) {
         const unsigned lo = max(rb, c0), hi = min(re, c1);
-        for (unsigned d = lo; d < hi; ++d) {
-          const float4* q = stage + (size_t)(d - c0) * 3;
-          const float4 x0 = q[0], x1 = q[1], x2 = q[2];
-          a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-          a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-          a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
-        }
+        for (unsigned d = lo; d < hi; ++d) acc.add(stage + (size_t)(d - c0) * DG_F4);
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -566,25 +635,18 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   for (unsigned long long todo = __ballot(cnt > COOP && cnt <= BWD_BIG); todo; todo &= todo - 1) {
     const int src = __builtin_ctzll(todo);
     const unsigned b0 = (unsigned)__shfl((int)d0, src), bn = (unsigned)__shfl((int)cnt, src);
-    float v[12];
+    DupAcc w;
+    w.zero();
+    for (unsigned i = lane; i < bn; i += 64) w.add(dupgrad + (size_t)(b0 + i) * DG_F4);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] = 0.f;
-    for (unsigned i = lane; i < bn; i += 64) {
-      const size_t d = (size_t)(b0 + i) * 3;
-      const float4 x0 = dupgrad[d], x1 = dupgrad[d + 1], x2 = dupgrad[d + 2];
-      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w;
-      v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
-      v[8] += x2.x; v[9] += x2.y; v[10] += x2.z; v[11] += x2.w;
-    }
+    for (int i = 0; i < DG_F4; ++i) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) v[i] += __shfl_xor(v[i], d);
+      for (int d = 32; d >= 1; d >>= 1) {
+        w.q[i].x += __shfl_xor(w.q[i].x, d); w.q[i].y += __shfl_xor(w.q[i].y, d); w.q[i].z += __shfl_xor(w.q[i].z, d);
+        if (DG_F4 == 3) w.q[i].w += __shfl_xor(w.q[i].w, d);
+      }
     }
-    if (lane == src) {
-      a0 = make_float4(v[0], v[1], v[2], v[3]); a1 = make_float4(v[4], v[5], v[6], v[7]);
-      a2 = make_float4(v[8], v[9], v[10], v[11]);
-    }
+    if (lane == src) acc = w;
   }
   if (!valid) return;
   FrameParams f = load_frame(kf);
@@ -601,9 +663,9 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   for (int i = 0; i < ROW; ++i) gshl[i] = 0.f;
   if (vis) {
     Grad2D A;
-    A.gmx = a0.x; A.gmy = a0.y; A.absx = a0.z; A.absy = a0.w;
-    A.gA = a1.x; A.gB = a1.y; A.gC = a1.z; A.gop = a1.w;
-    A.grgb[0] = a2.x; A.grgb[1] = a2.y; A.grgb[2] = a2.z; A.gdepth = a2.w;
+    A.gmx = acc.get(0); A.gmy = acc.get(1); A.absx = acc.get(2); A.absy = acc.get(3);
+    A.gA = acc.get(4); A.gB = acc.get(5); A.gC = acc.get(6); A.gop = acc.get(7);
+    A.grgb[0] = acc.get(8); A.grgb[1] = acc.get(9); A.grgb[2] = acc.get(10); A.gdepth = acc.get(11);
     const float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
     const float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
     const float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);

@@ -159,11 +159,11 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len);
       }
       r = make_record(pr, opac[g], rgb);
-      rec_out[3 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
+      rec_out[REC_F4 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
       // (r, g) and (b, depth) sit in aligned pairs: the compositing loops fetch them with one 16-byte and one 8-byte
       // LDS read into the register pairs their packed multiply-adds take
-      rec_out[3 * (size_t)g + 1] = make_float4(r.qc, r.op, r.r, r.g);
-      rec_out[3 * (size_t)g + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
+      rec_out[REC_F4 * (size_t)g + 1] = make_float4(r.qc, r.op, r.r, r.g);
+      rec_out[REC_F4 * (size_t)g + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
       depth_bits = __float_as_uint(r.depth);
       br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
       br.y0 = imax(br.y0, kf.band0); br.y1 = imax(br.y0, imin(br.y1, kf.band1));  // band rendering
@@ -312,7 +312,7 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
   for (unsigned i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_big; i += nwaves) {
     const uint4 it = big_list[i];
     const unsigned g = it.x;
-    const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
+    const float4 r0 = rec[REC_F4 * (size_t)g], r1 = rec[REC_F4 * (size_t)g + 1], r2 = rec[REC_F4 * (size_t)g + 2];
     WalkArgs a;
     a.r.mx = r0.x; a.r.my = r0.y; a.r.qa = r0.z; a.r.qb = r0.w; a.r.qc = r1.x; a.r.op = r1.y; a.r.depth = r2.y;
     a.r.r = a.r.g = a.r.b = 0.f; a.r.ex = r2.z; a.r.ey = r2.w;
@@ -819,7 +819,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   unsigned id_next = 0;
   if (s + lane < e) {
     const unsigned id = sorted_id[s + lane];
-    n0 = rec[3 * (size_t)id]; n1 = rec[3 * (size_t)id + 1]; n2 = rec[3 * (size_t)id + 2];
+    n0 = rec[REC_F4 * (size_t)id]; n1 = rec[REC_F4 * (size_t)id + 1]; n2 = rec[REC_F4 * (size_t)id + 2];
   }
   if (s + 64 + lane < e) id_next = sorted_id[s + 64 + lane];
   for (unsigned b = s; b < e; b += 64) {
@@ -828,7 +828,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     st[lane * 3] = n0; st[lane * 3 + 1] = n1; st[lane * 3 + 2] = n2;
     const float stage_my = n0.y, stage_ey = n2.w;
     if (b + 64 + lane < e) {  // prefetch: records of the next batch, ids of the one after
-      n0 = rec[3 * (size_t)id_next]; n1 = rec[3 * (size_t)id_next + 1]; n2 = rec[3 * (size_t)id_next + 2];
+      n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2];
     }
     if (b + 128 + lane < e) id_next = sorted_id[b + 128 + lane];
     __builtin_amdgcn_wave_barrier();

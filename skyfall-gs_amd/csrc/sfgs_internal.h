@@ -119,19 +119,26 @@ enum HeaderSlot {
                          // skips the entries behind a tile's last contributor), else 0
 };
 
+// float4s per compositing record in global memory: 3 = packed 48-byte records; 4 = 64-byte stride (the fourth is never
+// touched): every id -> record gather then falls into ONE 64-byte sector instead of 1.5 on average
+#ifndef SFGS_REC_F4
+#define SFGS_REC_F4 3
+#endif
+constexpr int REC_F4 = SFGS_REC_F4;
+
 struct GeomView {
-  float4* rec;      // [N][3] float4: (mx, my, qa, qb) (qc, op, r, g) (b, depth, ex, ey) -- SplatRec with (r, g), (b, depth) paired
+  float4* rec;      // [N][REC_F4] float4: (mx, my, qa, qb) (qc, op, r, g) (b, depth, ex, ey) -- SplatRec with (r, g), (b, depth) paired
   uint2* dup;       // [N] (first duplicate index, duplicate count) of every Gaussian
   uint4* big_list;  // [N] work list of big_walk_kernel: (Gaussian id, tile range x0 | x1 << 16, y0 | y1 << 16, 0);
                     //     HDR_BIG_COUNT entries, written only for splats that reach more than BIG_WALK coarse bins
 };
 static inline size_t geom_bytes(int64_t N) {
-  return align_up((size_t)N * 48, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N * 16, 256);
+  return align_up((size_t)N * 16 * REC_F4, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N * 16, 256);
 }
 static inline GeomView geom_view(void* base, int64_t N) {
   GeomView g;
   char* p = (char*)base;
-  g.rec = (float4*)p; p += align_up((size_t)N * 48, 256);
+  g.rec = (float4*)p; p += align_up((size_t)N * 16 * REC_F4, 256);
   g.dup = (uint2*)p; p += align_up((size_t)N * 8, 256);
   g.big_list = (uint4*)p;
   return g;
@@ -239,7 +246,14 @@ static inline ImageView image_view(void* base, int W, int H, int64_t D) {
 // the whole record array with streaming stores and composite_bwd skips its per-entry zero records.
 __host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned long long n_dup) { return dead * 10ull > n_dup * 3ull; }
 
-constexpr int DUPGRAD_FLOATS = 12;  // 48 bytes per duplicate (Grad2D order), three 16-byte stores
+// per-duplicate gradient record. SFGS_DUPGRAD_F4 = 3: 48 bytes, floats in Grad2D order. 4: 64 bytes, float 3 k + r of the
+// record at position 4 r + k (every fourth float is padding): lane (entry, row r) of composite_bwd then owns one whole
+// 16-byte quarter and the four lanes of an entry write a full 64-byte sector with ONE store instruction
+#ifndef SFGS_DUPGRAD_F4
+#define SFGS_DUPGRAD_F4 3
+#endif
+constexpr int DG_F4 = SFGS_DUPGRAD_F4;
+constexpr int DUPGRAD_FLOATS = 4 * DG_F4;
 static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
 
 // ---- XCD-aware block remap (bijective; guide T1) -------------------------------------------------

@@ -73,6 +73,16 @@ def _zero(dev):
     return z
 
 
+def _dupgrad_record_bytes(lib):
+    """bytes of one per-duplicate gradient record, as the library lays them out (asked once through the C ABI)."""
+    b = _stats.get("dupgrad_record_bytes")
+    if b is None:
+        sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
+        L.check(lib.sfgs_raster_sizes(1, 8, 8, 1024, 256, L.C.byref(sizes)))
+        b = _stats["dupgrad_record_bytes"] = int(sizes.dupgrad_bytes) // 1024
+    return b
+
+
 def _pinned_counters(dev, stream):
     """This thread's pinned counter buffer + event for (device, stream): frames on different streams or from different
     host threads never share one."""
@@ -288,7 +298,8 @@ class _Rasterize(torch.autograd.Function):
             g_shs = take(3 * K, (N, K, 3)) if ctx.has_shs else None
             grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
                                         L.ptr(g_scales), L.ptr(g_rot), L.ptr(g_opac), L.ptr(g_col), L.ptr(g_shs))
-            dupgrad = torch.empty(max((ctx.ndup * 48 + 255) // 256 * 256, 1), dtype=torch.uint8, device=dev)
+            dupgrad = torch.empty(max((ctx.ndup * _dupgrad_record_bytes(lib) + 255) // 256 * 256, 1), dtype=torch.uint8,
+                                  device=dev)
             gc = None if g_color is None else g_color.contiguous().float()
             gd = None if g_depth is None else g_depth.contiguous().float()
             ga = None if g_alpha is None else g_alpha.contiguous().float()
