@@ -167,7 +167,8 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
   constexpr int ROW = BwdLds<B>::ROW;
   // two entries per iteration: their record reads, exponentials and reciprocals are independent and overlap; only the
   // short transmittance / "colour behind" recurrences chain them
-  while (__ballot(pm != 0u) != 0ull) {
+  // do-while: the caller only enters with at least one blended entry in the wave (a batch without any skips the phase)
+  do {
     unsigned fb;
     asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));            // 0xffffffff for pm == 0
     const unsigned j1 = min(fb ^ 31u, (unsigned)B);            // -> B (the dummy entry) for pm == 0
@@ -186,7 +187,7 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
     pixel_bwd_scalars<HAS_BG>(ps, e2, b2.y, b1.z, b1.w, b2.x, u2, w2);
     lds.UW[j1 * ROW + lane] = make_float2(u1, w1);
     lds.UW[j2 * ROW + lane] = make_float2(u2, w2);
-  }
+  } while (__ballot(pm != 0u) != 0ull);
 }
 
 template <int B>
@@ -349,8 +350,10 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // so 1 / (1 - alpha) = 1 and w = 0 leave Tr untouched; the lazily applied "colour behind" update runs once and is
     // then a no-op because last_alpha becomes 0; its (u, w) goes to the dummy row). No exec masking, no state copies:
     // the loop body is one straight basic block.
-    if (has_bg) phase1_walk<B, true>(lds, ps, pm, sx, sy, lane);
-    else phase1_walk<B, false>(lds, ps, pm, sx, sy, lane);
+    if (__ballot(pm != 0u) != 0ull) {
+      if (has_bg) phase1_walk<B, true>(lds, ps, pm, sx, sy, lane);
+      else phase1_walk<B, false>(lds, ps, pm, sx, sy, lane);
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
@@ -376,20 +379,33 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         // straight line, four pixels per LDS round trip (the asm fences keep the compiler from hoisting all sixteen
         // 8-byte loads above the arithmetic, which would cost ~30 VGPRs and the fourth wave per SIMD)
 #define SFGS_P2(I) phase2_grid_step<I>(pg, uw##I.x, uw##I.y, ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
-#define SFGS_P2x4(A, Bq, C, D)                                                                  \
-  { const float2 uw##A = UWrow[A], uw##Bq = UWrow[Bq], uw##C = UWrow[C], uw##D = UWrow[D];       \
-    SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D); }                                           \
-  asm volatile("" ::: "memory");
+#define SFGS_P2_LOAD(A, Bq, C, D) const float2 uw##A = UWrow[A], uw##Bq = UWrow[Bq], uw##C = UWrow[C], uw##D = UWrow[D];
+#define SFGS_P2_DO(A, Bq, C, D) SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D);
+#define SFGS_P2_FENCE asm volatile("" ::: "memory");
         if (SFGS_BWD_ABLATE & 4) {
           const float2 uw = UWrow[0];
           pg = {uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y};
         } else {
-        SFGS_P2x4(0, 1, 2, 3)
-        SFGS_P2x4(4, 5, 6, 7)
-        SFGS_P2x4(8, 9, 10, 11)
-        SFGS_P2x4(12, 13, 14, 15)
+          // software-pipelined by hand: the next four pairs are in flight while four are consumed (8 more live registers;
+          // the kernel's occupancy is set by its LDS, 4 waves per SIMD = 128 VGPRs each). The fences pin the order: left
+          // alone the compiler issues every group's loads right in front of their first use.
+          SFGS_P2_LOAD(0, 1, 2, 3)
+          SFGS_P2_LOAD(4, 5, 6, 7)
+          SFGS_P2_FENCE
+          SFGS_P2_DO(0, 1, 2, 3)
+          SFGS_P2_FENCE
+          SFGS_P2_LOAD(8, 9, 10, 11)
+          SFGS_P2_FENCE
+          SFGS_P2_DO(4, 5, 6, 7)
+          SFGS_P2_FENCE
+          SFGS_P2_LOAD(12, 13, 14, 15)
+          SFGS_P2_FENCE
+          SFGS_P2_DO(8, 9, 10, 11)
+          SFGS_P2_DO(12, 13, 14, 15)
         }
-#undef SFGS_P2x4
+#undef SFGS_P2_LOAD
+#undef SFGS_P2_DO
+#undef SFGS_P2_FENCE
 #undef SFGS_P2
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
       } else {
