@@ -31,6 +31,11 @@ def kernel_stats(path):
 
 TRAFFIC = {}
 SQ = {}   # kernel -> {counter: average per launch}
+ALL_KERNELS = False   # --all-kernels: also kernels outside namespace sfgs (the microbenchmarks of the SQ calibration)
+# Calibration of the SQ-derived ratios: the raw formulas below are scaled so that a kernel that
+# saturates a pipe reads 1.00 -- tools/calibrate_sq.sh runs tools/microbench/issue_bench (pure v_fma_f32 / pure ds_read_b64
+# loops at 4 waves per SIMD) under the same PMC passes and writes these factors to profiles/r3_sq_calibration.json.
+CAL = {"valu_util": 1.0, "lds_busy": 1.0}
 
 
 def pmc_stats(path):
@@ -46,7 +51,7 @@ def pmc_stats(path):
         print(f"{short(n):44s} {cn:12s} {c:6d} {v:14.1f} {b:14.0f} {corr:14.0f} {d/1e3:9.2f}")
         if is_sz and "sfgs" in n:
             TRAFFIC.setdefault(short(n), {})[cn] = corr
-        if cn.startswith("SQ_") and "sfgs" in n:
+        if cn.startswith("SQ_") and ("sfgs" in n or ALL_KERNELS):
             e = SQ.setdefault(short(n), {})
             e[cn] = v
             e.setdefault("avg_us", d / 1e3)
@@ -56,7 +61,9 @@ def pmc_stats(path):
 def sq_derived():
     """One number each per kernel from the SQ passes (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* /
     SQ_ACTIVE_INST_* count quad-cycles summed over waves; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES):
-      valu_util      = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   share of SIMD issue time doing VALU
+      valu_util      = CAL x SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   share of SIMD issue time doing VALU
+      lds_busy       = CAL x SQ_ACTIVE_INST_LDS x 4 / (SQ_BUSY_CU_CYCLES x 4)         share of the CU's LDS pipe time
+                       (CAL: --cal profiles/r3_sq_calibration.json, from the saturating microbenchmarks; 1.0 = uncalibrated)
       valu_of_wave   = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES                      share of a wave's lifetime issuing VALU
       wait_any       = SQ_WAIT_ANY / SQ_WAVE_CYCLES                              parked on s_waitcnt / barrier
       wait_inst      = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                         issue stalls (pipe busy)
@@ -66,7 +73,7 @@ def sq_derived():
       valu_per_wave  = SQ_INSTS_VALU / SQ_WAVES"""
     out = {}
     print("# derived SQ metrics (per kernel, averages per launch)")
-    hdr = ["kernel", "avg_us", "occup/SIMD", "VALU util", "VALU/wave-life", "wait_any", "wait_inst", "lds_stall",
+    hdr = ["kernel", "avg_us", "occup/SIMD", "VALU util", "LDS busy", "VALU/wave-life", "wait_any", "wait_inst", "lds_stall",
            "lds_conflict", "VALU/wave", "LDS/wave", "SALU/wave"]
     print(" ".join(f"{h:>14s}" if i else f"{h:32s}" for i, h in enumerate(hdr)))
     for k, c in SQ.items():
@@ -74,14 +81,18 @@ def sq_derived():
         wc, bcu = g("SQ_WAVE_CYCLES"), g("SQ_BUSY_CU_CYCLES")
         waves = g("SQ_WAVES")
         d = dict(avg_us=c.get("avg_us"), occupancy_waves_per_simd=wc * 4 / (bcu * 4) if bcu == bcu else float("nan"),
-                 valu_util=g("SQ_ACTIVE_INST_VALU") * 4 / (bcu * 4), valu_of_wave=g("SQ_ACTIVE_INST_VALU") / wc,
+                 valu_util=CAL["valu_util"] * g("SQ_ACTIVE_INST_VALU") * 4 / (bcu * 4),
+                 valu_util_raw=g("SQ_ACTIVE_INST_VALU") * 4 / (bcu * 4),
+                 lds_busy=CAL["lds_busy"] * g("SQ_ACTIVE_INST_LDS") * 4 / (bcu * 4),
+                 lds_busy_raw=g("SQ_ACTIVE_INST_LDS") * 4 / (bcu * 4),
+                 valu_of_wave=g("SQ_ACTIVE_INST_VALU") / wc,
                  wait_any=g("SQ_WAIT_ANY") / wc, wait_inst=g("SQ_WAIT_INST_ANY") / wc,
                  lds_stall=g("SQ_WAIT_INST_LDS") / wc,
                  lds_conflict=g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else float("nan"),
                  valu_per_wave=g("SQ_INSTS_VALU") / waves, lds_per_wave=g("SQ_INSTS_LDS") / waves,
                  salu_per_wave=g("SQ_INSTS_SALU") / waves, raw=c)
         out[k] = d
-        vals = [d["avg_us"], d["occupancy_waves_per_simd"], d["valu_util"], d["valu_of_wave"], d["wait_any"],
+        vals = [d["avg_us"], d["occupancy_waves_per_simd"], d["valu_util"], d["lds_busy"], d["valu_of_wave"], d["wait_any"],
                 d["wait_inst"], d["lds_stall"], d["lds_conflict"], d["valu_per_wave"], d["lds_per_wave"], d["salu_per_wave"]]
         print(f"{k:32s} " + " ".join(f"{v:14.3f}" if v is not None else f"{'':14s}" for v in vals))
     print()
@@ -90,6 +101,14 @@ def sq_derived():
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if "--all-kernels" in args:
+        ALL_KERNELS = True
+        args.remove("--all-kernels")
+    if "--cal" in args:
+        i = args.index("--cal")
+        import json as _json
+        CAL.update(_json.load(open(args[i + 1]))["factors"])
+        args = args[:i] + args[i + 2:]
     sq_json = None
     if "--sq-json" in args:
         i = args.index("--sq-json")
