@@ -211,6 +211,28 @@ int sfgs_ssim_backward(const float* img1, const float* img2, int32_t B, int32_t 
                        int32_t W, const void* scratch, const float* dL_dmean, float* dL_dimg1,
                        void* stream);
 
+/* Joint render with the Gaussians sharded over ranks (SURVEY 8e "all-gather the preprocessed 2D records"; the reference
+ * has no multi-scene render). Every rank runs sfgs_raster_forward_plan on ITS Gaussians for the whole frame, then:
+ *   sfgs_raster_plan_export  copies the plan's per-Gaussian compositing records rec_out[N][12 floats], the per-coarse-bin
+ *                            item counts count_out[coarse_bins] and the items items_out[coarse_bins][export_capacity]
+ *                            (16 bytes each) into caller-owned device buffers with FIXED strides, ready for an
+ *                            all-gather (export_capacity >= the fullest coarse bin of any rank: all-reduce MAX of
+ *                            SfgsRasterCounters.max_coarse_bin);
+ *   sfgs_raster_plan_merge   builds ONE plan (geom / tiles / bins blobs sized by sfgs_raster_sizes for the total N, the
+ *                            summed duplicate count and coarse_capacity >= parts x export_capacity) from the gathered
+ *                            parts; Gaussian ids become positions in the concatenation (part order), so the per-tile
+ *                            order -- ascending (depth bits, id) -- is the single-process one and
+ *                            sfgs_raster_forward_render (num_duplicates = -1, any tile-row band) produces the same pixels
+ *                            bit for bit. Forward only: a merged plan carries no duplicate indices for a backward.
+ * Up to 16 parts. Asynchronous on `stream`. */
+int sfgs_raster_plan_export(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles, const void* bins,
+                            int64_t dup_capacity, int64_t coarse_capacity, int64_t export_capacity, float* rec_out,
+                            uint32_t* count_out, void* items_out, void* stream);
+int sfgs_raster_plan_merge(const SfgsFrame* frame, int32_t parts, const int32_t* part_N, const float* const* part_rec,
+                           const uint32_t* const* part_count, const void* const* part_items, int64_t export_capacity,
+                           void* geom, size_t geom_bytes, void* tiles, size_t tiles_bytes, void* bins, size_t bins_bytes,
+                           int64_t dup_capacity, int64_t coarse_capacity, void* stream);
+
 /* simple_knn distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other
  * points (index-excluded; fewer than 3 others: mean over those that exist). Exact for every input (brute force up to
  * 32 768 points; above, a Z-curve counting sort with box-pruned search -- the layout of the reference's simple-knn).

@@ -1063,6 +1063,131 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   return SFGS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Joint render with the GAUSSIANS sharded over ranks: every rank plans its own Gaussians, EXPORTS the plan's
+// per-Gaussian records and per-coarse-bin items in a layout that can be all-gathered (fixed strides), and MERGES the
+// gathered parts into one plan whose Gaussian ids are the positions in the concatenated set -- the render stage then
+// bins, sorts (by depth bits, then id: the single-process order) and composites this rank's band.
+constexpr int MERGE_MAX_PARTS = 16;
+struct MergeParts {
+  const float4* rec[MERGE_MAX_PARTS];
+  const uint32_t* count[MERGE_MAX_PARTS];
+  const uint4* items[MERGE_MAX_PARTS];
+  unsigned base[MERGE_MAX_PARTS + 1];   // first merged id of every part
+  int parts;
+};
+
+__global__ void __launch_bounds__(256)
+plan_export_kernel(int N, int NCB, const float4* __restrict__ rec, const uint32_t* __restrict__ coarse_count,
+                   const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned export_capacity,
+                   float4* __restrict__ rec_out, uint32_t* __restrict__ count_out, uint4* __restrict__ items_out) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+  for (size_t i = t; i < (size_t)N * 3; i += nthreads) rec_out[i] = rec[(i / 3) * REC_F4 + i % 3];
+  for (size_t cb = t; cb < (size_t)NCB; cb += nthreads)
+    count_out[cb] = min(min(coarse_count[cb * CC_STRIDE], coarse_capacity), export_capacity);
+  for (size_t i = t; i < (size_t)NCB * export_capacity; i += nthreads) {
+    const size_t cb = i / export_capacity, k = i % export_capacity;
+    if (k < min(coarse_count[cb * CC_STRIDE], coarse_capacity)) items_out[i] = slabs[cb * coarse_capacity + k];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+plan_merge_rec_kernel(MergeParts mp, float4* __restrict__ rec) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+  for (int p = 0; p < mp.parts; ++p) {
+    const size_t n = (size_t)(mp.base[p + 1] - mp.base[p]) * 3;
+    for (size_t i = t; i < n; i += nthreads) rec[((size_t)mp.base[p] + i / 3) * REC_F4 + i % 3] = mp.rec[p][i];
+  }
+}
+
+// one workgroup per coarse bin: the parts' items one after the other (part order = id order), ids re-based
+__global__ void __launch_bounds__(256)
+plan_merge_items_kernel(MergeParts mp, unsigned export_capacity, unsigned coarse_capacity,
+                        uint32_t* __restrict__ coarse_count, uint4* __restrict__ slabs, unsigned long long* __restrict__ hdr) {
+  const size_t cb = blockIdx.x;
+  unsigned off = 0;
+  for (int p = 0; p < mp.parts; ++p) {
+    const unsigned n = min(mp.count[p][cb], export_capacity);
+    for (unsigned k = threadIdx.x; k < n; k += 256) {
+      uint4 it = mp.items[p][cb * export_capacity + k];
+      it.x += mp.base[p];
+      it.z = 0u;            // duplicate indices belong to the backward: a merged plan is rendered, not differentiated
+      if (off + k < coarse_capacity) slabs[cb * coarse_capacity + off + k] = it;
+    }
+    off += n;
+  }
+  if (threadIdx.x == 0) {
+    coarse_count[cb * CC_STRIDE] = off;
+    if (off > coarse_capacity) hdr[HDR_OVERFLOW] = 1ull;
+  }
+}
+
+extern "C" int sfgs_raster_plan_export(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles,
+                                       const void* bins, int64_t dup_capacity, int64_t coarse_capacity,
+                                       int64_t export_capacity, float* rec_out, uint32_t* count_out, void* items_out,
+                                       void* stream_) {
+  if (int rc = check_frame(frame)) return rc;
+  SFGS_REQUIRE(N >= 0 && geom && tiles && bins && count_out && items_out && (N == 0 || rec_out), SFGS_E_ARG, "NULL argument");
+  SFGS_REQUIRE(export_capacity > 0 && export_capacity < (1ll << 31) && coarse_capacity >= 0, SFGS_E_ARG, "bad capacity");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int W = frame->image_width, H = frame->image_height;
+  const int64_t NCB = coarse_bins(W, H);
+  const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
+  const GeomView gv = geom_view(const_cast<void*>(geom), N);
+  const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity, NCB, coarse_capacity);
+  hipLaunchKernelGGL(plan_export_kernel, dim3(2048), dim3(256), 0, stream, (int)N, (int)NCB, gv.rec, tv.coarse_count,
+                     bv.slabs, (unsigned)coarse_capacity, (unsigned)export_capacity, (float4*)rec_out, count_out,
+                     (uint4*)items_out);
+  SFGS_POST_LAUNCH("plan_export", stream, frame->debug);
+  return SFGS_OK;
+}
+
+extern "C" int sfgs_raster_plan_merge(const SfgsFrame* frame, int32_t parts, const int32_t* part_N,
+                                      const float* const* part_rec, const uint32_t* const* part_count,
+                                      const void* const* part_items, int64_t export_capacity, void* geom, size_t geom_sz,
+                                      void* tiles, size_t tiles_sz, void* bins, size_t bins_sz, int64_t dup_capacity,
+                                      int64_t coarse_capacity, void* stream_) {
+  if (int rc = check_frame(frame)) return rc;
+  SFGS_REQUIRE(parts >= 1 && parts <= MERGE_MAX_PARTS, SFGS_E_ARG, "1..%d parts", MERGE_MAX_PARTS);
+  SFGS_REQUIRE(part_N && part_rec && part_count && part_items && geom && tiles && bins, SFGS_E_ARG, "NULL argument");
+  SFGS_REQUIRE(export_capacity > 0 && export_capacity < (1ll << 31), SFGS_E_ARG, "bad export_capacity");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int W = frame->image_width, H = frame->image_height;
+  const int64_t NCB = coarse_bins(W, H);
+  MergeParts mp;
+  int64_t N = 0;
+  for (int p = 0; p < parts; ++p) {
+    SFGS_REQUIRE(part_N[p] >= 0 && part_count[p] && part_items[p] && (part_N[p] == 0 || part_rec[p]), SFGS_E_ARG, "bad part %d", p);
+    mp.rec[p] = (const float4*)part_rec[p]; mp.count[p] = part_count[p]; mp.items[p] = (const uint4*)part_items[p];
+    mp.base[p] = (unsigned)N;
+    N += part_N[p];
+  }
+  mp.base[parts] = (unsigned)N;
+  mp.parts = parts;
+  SFGS_REQUIRE(N < (1ll << 31), SFGS_E_ARG, "too many Gaussians");
+  size_t tb = 0;
+  const TilesView tv = tiles_view(tiles, W, H, N, &tb);
+  SFGS_REQUIRE(tiles_sz >= tb, SFGS_E_CAPACITY, "tiles blob: %zu bytes given, %zu needed", tiles_sz, tb);
+  SFGS_REQUIRE(geom_sz >= geom_bytes(N), SFGS_E_CAPACITY, "geom blob: %zu bytes given, %zu needed", geom_sz, geom_bytes(N));
+  SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0 && coarse_capacity < (1ll << 31),
+               SFGS_E_ARG, "bad dup_capacity / coarse_capacity");
+  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
+               "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
+  const GeomView gv = geom_view(geom, N);
+  const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
+  SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
+  if (frame->subpixel_offset) {
+    const int64_t n = (int64_t)W * H * 2;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 512));
+    hipLaunchKernelGGL(subpix_bound_kernel, dim3(blocks), dim3(256), 0, stream, frame->subpixel_offset, n, tv.hdr);
+  }
+  if (N > 0) hipLaunchKernelGGL(plan_merge_rec_kernel, dim3(2048), dim3(256), 0, stream, mp, gv.rec);
+  hipLaunchKernelGGL(plan_merge_items_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, mp, (unsigned)export_capacity,
+                     (unsigned)coarse_capacity, tv.coarse_count, bv.slabs, tv.hdr);
+  SFGS_POST_LAUNCH("plan_merge", stream, frame->debug);
+  return SFGS_OK;
+}
+
 static void unpack_counters(const unsigned long long* h, SfgsRasterCounters* out) {
   out->num_duplicates = (int64_t)h[HDR_D_EFF];
   out->num_duplicates_ref = (int64_t)h[HDR_D_REF];

@@ -82,6 +82,10 @@ SYMBOLS = {
     "sfgs_raster_read_counters_pinned": (C.c_int, [_V, _V, C.POINTER(SfgsRasterCounters), _V]),
     "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _I64, _I64, _V, _V, _V,
                                               _V, _SZ, _V]),
+    "sfgs_raster_plan_export": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _I64, _I64, _I64, _V, _V, _V, _V]),
+    "sfgs_raster_plan_merge": (C.c_int, [C.POINTER(SfgsFrame), _I32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I64, _V, _SZ, _V, _SZ, _V, _SZ,
+                                          _I64, _I64, _V]),
     "sfgs_raster_backward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _V, _V, _I64, _I64, _I64, _V,
                                         _V, _V, _V, _V, _SZ, C.POINTER(SfgsGaussianGrads), _V]),
     "sfgs_ssim_scratch_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32]),

@@ -287,15 +287,159 @@ def gather_bands(image, height, rank=None, world=None):
     return out.to(image.device) if staged else out
 
 
-def render_joint(rasterizer_cls, settings, inputs, height):
-    """Band-sharded joint render: every rank calls this with the same merged Gaussian set; returns the full
-    (color, depth, alpha). `settings` is a diff_gauss.GaussianRasterizationSettings."""
+def render_joint(rasterizer_cls, settings, inputs, height, shard_gaussians=False):
+    """Band-sharded joint render; returns the full (color, depth, alpha) on every rank. `settings` is a
+    diff_gauss.GaussianRasterizationSettings.
+      shard_gaussians=False: every rank calls this with the SAME merged Gaussian set (the fused PLY replicated once at
+        load) and projects / bins all of it for its band.
+      shard_gaussians=True: `inputs` are THIS RANK'S Gaussians only (rank r holds scene r; the merged set is the
+        concatenation in rank order). Every rank projects and coarse-bins its own Gaussians, the ranks all-gather the
+        48-byte compositing records and the coarse items (sfgs_raster_plan_export), merge them (sfgs_raster_plan_merge) and
+        bin / sort / composite their band. Same pixels, bit for bit. Per frame and rank this moves 48 B x N_total +
+        16 B x (coarse bins x fullest bin) x world over the interconnect in exchange for 1/world of the projection work:
+        worth it when the Gaussians are NOT replicated (each rank only has its own scene in memory)."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     t0, t1, _, _ = band_rows(height, world, rank)
     s = settings._replace(tile_rows=(t0, t1))
     with torch.no_grad():
-        color, depth, _, alpha, _, _ = rasterizer_cls(raster_settings=s)(**inputs)
+        if shard_gaussians:
+            color, depth, alpha = render_merged_parts(_gather_parts(plan_export(settings, inputs)), s)
+        else:
+            color, depth, _, alpha, _, _ = rasterizer_cls(raster_settings=s)(**inputs)
     packed = torch.cat([color, depth, alpha], 0)
     full = gather_bands(packed, height)
     return full[:3], full[3:4], full[4:5]
+
+
+# ---- Gaussian-sharded joint render: plan locally, exchange, merge, render the band --------------------------------------
+def plan_export(settings, inputs, export_capacity=None):
+    """Plan THIS rank's Gaussians for the whole frame and export the plan (device tensors with fixed strides):
+    dict(N, D, rec[N,12] f32, count[NCB] i32, items[NCB, C, 4] i32, C, max_coarse)."""
+    import diff_gauss as dg
+    from sfgs import _lib as L
+    lib = L.load()
+    means3D = dg._f32c(inputs["means3D"], "means3D")
+    dev = means3D.device
+    N = int(means3D.shape[0])
+    scales = dg._f32c(inputs["scales"], "scales", (3,))
+    rotations = dg._f32c(inputs["rotations"], "rotations", (4,))
+    opacities = dg._f32c(inputs["opacities"], "opacities").reshape(N, 1)
+    colors = dg._f32c(inputs.get("colors_precomp"), "colors_precomp", (3,))
+    shs = dg._f32c(inputs.get("shs"), "shs")
+    if (shs is None) == (colors is None):
+        raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+    H, W = int(settings.image_height), int(settings.image_width)
+    full = settings._replace(tile_rows=None)      # the plan covers the whole frame: every band needs these items
+    keep = []
+    with torch.cuda.device(dev):
+        frame = dg._frame(full, dev, 0 if shs is None else int(shs.shape[1]), keep)
+        stream = dg._stream(dev)
+        gs = L.SfgsGaussians(dg.C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                             L.ptr(opacities), L.ptr(colors), L.ptr(shs))
+        sizes = L.SfgsRasterSizes(dg.C_sizeof(L.SfgsRasterSizes))
+        L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
+        ncb = max(int(sizes.coarse_bins), 1)
+        cap = int(lib.sfgs_raster_slot_capacity(W, H, 4 * N))
+        ccap = max(8 * N // ncb, 256)
+        radii = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        while True:
+            L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
+            geom = torch.empty(max(int(sizes.geom_bytes), 256), dtype=torch.uint8, device=dev)
+            tiles = torch.empty(int(sizes.tiles_bytes), dtype=torch.uint8, device=dev)
+            bins = torch.empty(max(int(sizes.bins_bytes), 256), dtype=torch.uint8, device=dev)
+            L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom), geom.numel(),
+                                                 L.ptr(tiles), tiles.numel(), L.ptr(bins), bins.numel(), cap, ccap, None,
+                                                 stream))
+            cnt = L.SfgsRasterCounters()
+            L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))
+            D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
+            if not cnt.overflow and int(lib.sfgs_raster_slot_capacity(W, H, D)) <= cap and cmax <= ccap:
+                break
+            cap = max(cap, int(lib.sfgs_raster_slot_capacity(W, H, int(D * 1.25) + 1024)))
+            ccap = max(ccap, int(cmax * 1.25) + 256)
+        if export_capacity is None:
+            export_capacity = _agree_max(max(cmax, 1), dev)
+        C = int(export_capacity)
+        if C < cmax:
+            raise ValueError(f"export_capacity {C} is below this rank's fullest coarse bin ({cmax})")
+        rec = torch.empty(N, 12, dtype=torch.float32, device=dev)
+        count = torch.empty(ncb, dtype=torch.int32, device=dev)
+        items = torch.empty(ncb, C, 4, dtype=torch.int32, device=dev)
+        L.check(lib.sfgs_raster_plan_export(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins), cap, ccap, C,
+                                            L.ptr(rec), L.ptr(count), L.ptr(items), stream))
+    return dict(N=N, D=D, rec=rec, count=count, items=items, C=C, max_coarse=cmax)
+
+
+def _agree_max(v, dev):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(v)
+    t = torch.tensor([int(v)], dtype=torch.int64, device=dev if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def _gather_parts(part):
+    """All-gather the exported plans (rank order). RCCL moves device tensors directly; gloo stages through the host."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [part]
+    world = dist.get_world_size()
+    dev = part["rec"].device
+    staged = dist.get_backend() == "gloo"
+    meta = torch.tensor([part["N"], part["D"]], dtype=torch.int64, device="cpu" if staged else dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    Ns, Ds = [int(m[0]) for m in metas], [int(m[1]) for m in metas]
+    nmax = max(max(Ns), 1)
+    rec = torch.zeros(nmax, 12, dtype=torch.float32, device=dev)
+    rec[:part["N"]] = part["rec"]
+    out = []
+    src = {k: (v.cpu() if staged else v) for k, v in dict(rec=rec, count=part["count"], items=part["items"]).items()}
+    gathered = {}
+    for k, v in src.items():
+        bufs = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(bufs, v.contiguous())
+        gathered[k] = [b.to(dev) for b in bufs] if staged else bufs
+    for r in range(world):
+        out.append(dict(N=Ns[r], D=Ds[r], rec=gathered["rec"][r][:Ns[r]].contiguous(), count=gathered["count"][r],
+                        items=gathered["items"][r], C=part["C"]))
+    return out
+
+
+def render_merged_parts(parts, settings):
+    """Merge exported plans (part order = Gaussian order of the concatenated set) and render `settings`' frame / band.
+    Returns (color, depth, alpha)."""
+    import diff_gauss as dg
+    from sfgs import _lib as L
+    lib = L.load()
+    dev = parts[0]["count"].device
+    H, W = int(settings.image_height), int(settings.image_width)
+    C = int(parts[0]["C"])
+    N = sum(p["N"] for p in parts)
+    D = sum(p["D"] for p in parts)
+    P = len(parts)
+    keep = []
+    with torch.cuda.device(dev):
+        frame = dg._frame(settings._replace(sh_degree=0), dev, 0, keep)   # colours are already in the records
+        stream = dg._stream(dev)
+        sizes = L.SfgsRasterSizes(dg.C_sizeof(L.SfgsRasterSizes))
+        cap = int(lib.sfgs_raster_slot_capacity(W, H, D))
+        ccap = P * C
+        L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
+        geom = torch.empty(max(int(sizes.geom_bytes), 256), dtype=torch.uint8, device=dev)
+        tiles = torch.empty(int(sizes.tiles_bytes), dtype=torch.uint8, device=dev)
+        bins = torch.empty(max(int(sizes.bins_bytes), 256), dtype=torch.uint8, device=dev)
+        arr = lambda ptrs: (L.C.c_void_p * P)(*ptrs)
+        L.check(lib.sfgs_raster_plan_merge(L.C.byref(frame), P, (L.C.c_int32 * P)(*[p["N"] for p in parts]),
+                                           arr([p["rec"].data_ptr() for p in parts]),
+                                           arr([p["count"].data_ptr() for p in parts]),
+                                           arr([p["items"].data_ptr() for p in parts]), C, L.ptr(geom), geom.numel(),
+                                           L.ptr(tiles), tiles.numel(), L.ptr(bins), bins.numel(), cap, ccap, stream))
+        outs = (torch.zeros if getattr(settings, "tile_rows", None) else torch.empty)(5, H, W, dtype=torch.float32, device=dev)
+        L.check(lib.sfgs_raster_forward_render(L.C.byref(frame), N, L.ptr(geom), L.ptr(tiles), L.ptr(bins), bins.numel(), cap,
+                                               ccap, -1, L.ptr(outs[0:3]), L.ptr(outs[3:4]), L.ptr(outs[4:5]), None, 0, stream))
+        cnt = L.SfgsRasterCounters()
+        L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))
+        if cnt.overflow:
+            raise RuntimeError("merged plan overflowed its blobs (export_capacity below a rank's fullest coarse bin?)")
+    return outs[0:3], outs[3:4], outs[4:5]
