@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 7
+#define SFGS_ABI_VERSION 8
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -72,7 +72,28 @@ typedef struct SfgsFrame {
   const float* viewmatrix;       /* device [16]                                                  */
   const float* projmatrix;       /* device [16]                                                  */
   const float* campos;           /* device [3]                                                   */
+  uint32_t launch_hints;         /* SFGS_HINT_* bits, 0 = none (see below)                       */
+  void* feedback;                /* optional: 64 bytes of DEVICE memory, caller-owned and persistent across the frames of
+                                    one stream (zero it once). The render / backward stages leave the frame's late
+                                    statistics there -- they only exist once those stages have run -- and the NEXT
+                                    sfgs_raster_forward_plan reports them (SfgsRasterCounters.prev_*): the feedback the
+                                    launch hints are chosen from.                                                */
 } SfgsFrame;
+
+/* Launch hints. A frame's optional kernels -- the huge-splat walk, the three long-list sorts, the backward's dead-entry
+ * prefill and chunk pre-reduction -- each cost ~5 us of queue time even when they find nothing to do, and whether they
+ * have work is only known on the device. The caller may assert what it learnt from the previous frames:
+ *   NO_HUGE_SPLATS  plan: do not launch the huge-splat walk. If SfgsRasterCounters.num_huge_splats comes back != 0 the
+ *                   frame was binned WITHOUT those splats: redo plan + render without the hint.
+ *   FEW_LONG_LISTS  render: ONE catch-all kernel sorts every list longer than 512 entries instead of three size-class
+ *                   kernels. Always correct; slower when many lists are long.
+ *   NO_PREFILL      backward: do not launch the dead-entry prefill kernel (its decision then reads "no"). Always correct.
+ *   NO_BIG_CHUNKS   backward: do not launch the chunk pre-reduction. Only valid when THIS frame's plan reported
+ *                   num_big_chunks == 0. */
+#define SFGS_HINT_NO_HUGE_SPLATS 1u
+#define SFGS_HINT_FEW_LONG_LISTS 2u
+#define SFGS_HINT_NO_PREFILL 4u
+#define SFGS_HINT_NO_BIG_CHUNKS 8u
 
 /* Per-Gaussian inputs = keyword arguments of GaussianRasterizer.__call__
  * (gaussian_renderer/__init__.py:132-140). All float32, contiguous, device memory.
@@ -123,6 +144,12 @@ typedef struct SfgsRasterCounters {
   int64_t overflow;            /* != 0: dup_capacity or coarse_capacity was too small: redo the plan with
                                   dup_capacity >= num_duplicates and coarse_capacity >= max_coarse_bin     */
   int64_t max_coarse_bin;      /* items in the fullest 32x32-pixel coarse bin                               */
+  int64_t num_huge_splats;     /* splats reaching >= 64 coarse bins (their walk is a kernel of its own)        */
+  int64_t num_big_chunks;      /* 1024-record chunks of Gaussians with > 2048 duplicates (backward pre-reduction) */
+  int64_t prev_valid;          /* != 0: the prev_* fields below were read from SfgsFrame.feedback              */
+  int64_t prev_long_tiles;     /* previous frame: tiles with lists longer than 512 entries                     */
+  int64_t prev_max_tile_list;  /* previous frame: longest list                                                 */
+  int64_t prev_prefilled;      /* previous frame's backward: the prefill kernel ran and chose to fill          */
 } SfgsRasterCounters;
 
 int sfgs_abi_version(void);
@@ -151,7 +178,7 @@ int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates);
  * to that bin's slab in `bins` (coarse_capacity items per bin; dup_capacity duplicate indices).
  * Neither count is known beforehand: if the counters report overflow, call again with a bins blob
  * sized for counters.num_duplicates / counters.max_coarse_bin. Asynchronous on `stream`.
- * counters_pinned_host (optional): 64 bytes of PINNED host memory (hipHostMalloc / torch pin_memory) that the
+ * counters_pinned_host_128 (optional): 128 bytes of PINNED host memory (hipHostMalloc / torch pin_memory) that the
  * plan's last kernel fills with the frame's counters. Record an event right after this call, enqueue
  * sfgs_raster_forward_render, THEN wait for the event and sfgs_raster_counters_decode the buffer: the capacity
  * check overlaps with the render stage instead of draining the stream (max_tile_list is produced by the render
@@ -159,8 +186,8 @@ int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates);
 int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii,
                              void* geom, size_t geom_bytes, void* tiles, size_t tiles_bytes,
                              void* bins, size_t bins_bytes, int64_t dup_capacity,
-                             int64_t coarse_capacity, void* counters_pinned_host, void* stream);
-int sfgs_raster_counters_decode(const void* host_64, SfgsRasterCounters* out); /* host only, no GPU work */
+                             int64_t coarse_capacity, void* counters_pinned_host_128, void* stream);
+int sfgs_raster_counters_decode(const void* host_128, SfgsRasterCounters* out); /* host only, no GPU work */
 
 /* Copies the plan counters to the host. SYNCHRONISES `stream` (the one host sync of the forward,
  * as in the reference, where the duplicate total sizes the sort buffers). */

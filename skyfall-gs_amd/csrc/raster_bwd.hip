@@ -491,7 +491,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 // (On the headline scene 0.1 % are dead: the kernel returns after the sum.)
 __global__ void __launch_bounds__(256)
 dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned long long n_dup, int mode,
-                       float4* __restrict__ dupgrad, unsigned long long* __restrict__ hdr) {
+                       float4* __restrict__ dupgrad, unsigned long long* __restrict__ hdr,
+                       unsigned long long* __restrict__ feedback) {
   __shared__ unsigned part[4];
   // every workgroup sums the per-tile counts for itself (2 bytes per tile, 16-byte loads: 64 KB from L2 at 1080p)
   unsigned dead = 0;   // <= 65535 * T8 < 2^32 up to 65 k tiles... accumulate in 64 bits across lanes below
@@ -513,7 +514,10 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
   __syncthreads();
   const unsigned long long total = (unsigned long long)part[0] + part[1] + part[2] + part[3];
   const bool fill = mode == 1 ? true : mode == 2 ? false : prefill_wanted(total, n_dup);   // mode: test knob
-  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HDR_PREFILLED] = fill ? 1ull : 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[HDR_PREFILLED] = fill ? 1ull : 0ull;
+    if (feedback) feedback[FB_PREFILLED] = fill ? 1ull : 0ull;   // for the next frame's plan (SfgsFrame.feedback)
+  }
   if (!fill) return;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t n4 = (size_t)n_dup * DG_F4;
@@ -754,14 +758,18 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
+    // (without the prefill kernel its decision word keeps the plan's zero: composite_bwd writes the zero records itself)
+    if (!(frame->launch_hints & SFGS_HINT_NO_PREFILL))
     hipLaunchKernelGGL(dupgrad_prefill_kernel, dim3(512), dim3(256), 0, stream, TX8 * TY8, iv.tile_dead,
-                       (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr);
+                       (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
+                       (unsigned long long*)frame->feedback);
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
                        dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
+    if (!(frame->launch_hints & SFGS_HINT_NO_BIG_CHUNKS))   // the caller read num_big_chunks == 0 from this frame's plan
     hipLaunchKernelGGL(dupgrad_reduce_kernel, dim3(1024), dim3(256), 0, stream, tv.hdr, bv.big_chunks,
                        (unsigned)big_chunk_capacity(dup_capacity), gv.dup, (float4*)dupgrad);
 #define SFGS_LAUNCH_PBWD(K, D)                                                                                          \

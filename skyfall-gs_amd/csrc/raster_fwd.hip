@@ -382,7 +382,7 @@ constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
 plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                  const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
-                 unsigned long long* __restrict__ host_out) {
+                 const unsigned long long* __restrict__ feedback, unsigned long long* __restrict__ host_out) {
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
   unsigned long long nvis = 0, dref = 0, cmax = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
@@ -409,6 +409,15 @@ plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, con
   if (threadIdx.x == 0 && host_out) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) host_out[i] = hdr[i];
+    // words 8..15: this frame's optional-work counts, and the late statistics of the PREVIOUS frame (its render /
+    // backward stages completed before this kernel started: same stream) -- what the caller picks launch hints from
+    host_out[8] = hdr[HDR_BIG_COUNT];
+    host_out[9] = hdr[HDR_BIG_CHUNKS];
+    host_out[10] = feedback ? feedback[FB_VALID] : 0ull;
+    host_out[11] = feedback ? feedback[FB_LONG_TILES] : 0ull;
+    host_out[12] = feedback ? feedback[FB_MAX_LIST] : 0ull;
+    host_out[13] = feedback ? feedback[FB_PREFILLED] : 0ull;
+    host_out[14] = 0ull; host_out[15] = 0ull;
   }
 }
 
@@ -604,7 +613,13 @@ __device__ __forceinline__ void sort_tile_in_registers(unsigned s, int L, int la
 
 __global__ void __launch_bounds__(256)
 sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4* __restrict__ items,
-                      uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup) {
+                      uint32_t* __restrict__ sorted_id, uint32_t* __restrict__ sorted_dup,
+                      const unsigned long long* __restrict__ hdr, unsigned long long* __restrict__ feedback) {
+  if (feedback && blockIdx.x == 0 && threadIdx.x == 0) {   // the list statistics are final (fine_bin has run): leave
+    feedback[FB_VALID] = 1ull;                              // them for the next frame's plan (SfgsFrame.feedback)
+    feedback[FB_LONG_TILES] = hdr[HDR_LONG_COUNT];
+    feedback[FB_MAX_LIST] = hdr[HDR_MAX_LIST];
+  }
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= T8) return;
   const uint2 tr = tile_range[t];
@@ -1049,7 +1064,9 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                      tv.block_dref, gv.big_list, tv.hdr)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
-      // the big splats' walk: persistent waves over the work list (returns at once when the list is empty)
+      // the big splats' walk: persistent waves over the work list (returns at once when the list is empty; not launched
+      // at all when the caller asserts there are none -- it checks counters.num_huge_splats afterwards)
+      if (!(frame->launch_hints & SFGS_HINT_NO_HUGE_SPLATS))
       hipLaunchKernelGGL(big_walk_kernel, dim3(BIG_WALK_BLOCKS), dim3(256), 0, stream, kf, gv.big_list, gv.rec, gv.dup,
                          tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity,
                          bv.big_chunks, (unsigned)big_chunk_capacity(dup_capacity), tv.hdr);
@@ -1058,7 +1075,9 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
-                       tv.block_dref, tv.hdr, (unsigned long long*)counters_pinned_host); }
+                       tv.block_dref, tv.hdr,
+                       (const unsigned long long*)frame->feedback,
+                       (unsigned long long*)counters_pinned_host); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;
 }
@@ -1195,19 +1214,32 @@ static void unpack_counters(const unsigned long long* h, SfgsRasterCounters* out
   out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
   out->overflow = (int64_t)h[HDR_OVERFLOW];
   out->max_coarse_bin = (int64_t)h[HDR_MAX_COARSE];
+  out->num_huge_splats = (int64_t)h[HDR_BIG_COUNT];
+  out->num_big_chunks = (int64_t)h[HDR_BIG_CHUNKS];
+  out->prev_valid = out->prev_long_tiles = out->prev_max_tile_list = out->prev_prefilled = 0;
 }
 
-extern "C" int sfgs_raster_counters_decode(const void* host_64, SfgsRasterCounters* out) {
-  SFGS_REQUIRE(host_64 && out, SFGS_E_ARG, "NULL argument");
-  unpack_counters((const unsigned long long*)host_64, out);
+extern "C" int sfgs_raster_counters_decode(const void* host_128, SfgsRasterCounters* out) {
+  SFGS_REQUIRE(host_128 && out, SFGS_E_ARG, "NULL argument");
+  // words 0..7 = the first header words; 8..13 as plan_scan_kernel lays them out
+  const unsigned long long* h = (const unsigned long long*)host_128;
+  unsigned long long hdr[HDR_WORDS] = {0};
+  for (int i = 0; i < 8; ++i) hdr[i] = h[i];
+  hdr[HDR_BIG_COUNT] = h[8];
+  hdr[HDR_BIG_CHUNKS] = h[9];
+  unpack_counters(hdr, out);
+  out->prev_valid = (int64_t)h[10];
+  out->prev_long_tiles = (int64_t)h[11];
+  out->prev_max_tile_list = (int64_t)h[12];
+  out->prev_prefilled = (int64_t)h[13];
   return SFGS_OK;
 }
 
 extern "C" int sfgs_raster_read_counters(const void* tiles, SfgsRasterCounters* out, void* stream_) {
   SFGS_REQUIRE(tiles && out, SFGS_E_ARG, "NULL argument");
   hipStream_t stream = (hipStream_t)stream_;
-  unsigned long long h[8];
-  SFGS_CHECK_HIP(hipMemcpyAsync(h, tiles, sizeof(h), hipMemcpyDeviceToHost, stream));
+  unsigned long long h[HDR_WORDS] = {0};
+  SFGS_CHECK_HIP(hipMemcpyAsync(h, tiles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
   SFGS_CHECK_HIP(hipStreamSynchronize(stream));
   unpack_counters(h, out);
   return SFGS_OK;
@@ -1219,7 +1251,9 @@ extern "C" int sfgs_raster_read_counters_pinned(const void* tiles, void* pinned_
   hipStream_t stream = (hipStream_t)stream_;
   SFGS_CHECK_HIP(hipMemcpyAsync(pinned_host_64, tiles, 64, hipMemcpyDeviceToHost, stream));
   SFGS_CHECK_HIP(hipStreamSynchronize(stream));
-  unpack_counters((const unsigned long long*)pinned_host_64, out);
+  unsigned long long hdr[HDR_WORDS] = {0};   // the first 8 header words; the optional-work counts read 0 (use
+  for (int i = 0; i < 8; ++i) hdr[i] = ((const unsigned long long*)pinned_host_64)[i];   // sfgs_raster_read_counters)
+  unpack_counters(hdr, out);
   return SFGS_OK;
 }
 
@@ -1255,8 +1289,16 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   if (num_duplicates != 0) {  // < 0: unknown (render enqueued before the counters were read)
     { ProfScope ps_(KID_SORT_SMALL, stream);
       hipLaunchKernelGGL(sort_tiles_reg_kernel, dim3((T8 + 3) / 4), dim3(256), 0, stream, T8, tv.tile_range, bv.items,
-                         bv.sorted_id, bv.sorted_dup); }
+                         bv.sorted_id, bv.sorted_dup, (const unsigned long long*)tv.hdr,
+                         (unsigned long long*)frame->feedback); }
     SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
+    if (frame->launch_hints & SFGS_HINT_FEW_LONG_LISTS) {
+      // the caller expects (next to) no list beyond 512 entries: ONE catch-all launch -- the LDS kernel takes every long
+      // list, whatever its size class -- instead of three that each cost ~5 us of queue time when they find nothing
+      ProfScope ps_(KID_SORT_LDS, stream);
+      hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_SMALL,
+                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
+    } else {
     { ProfScope ps_(KID_SORT_REG_LONG, stream);
       hipLaunchKernelGGL(sort_tiles_reg_long_kernel<16>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
@@ -1266,6 +1308,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
     { ProfScope ps_(KID_SORT_LDS, stream);
       hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_MAX,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
+    }
     SFGS_POST_LAUNCH("sort_tiles_long", stream, frame->debug);
   }
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;

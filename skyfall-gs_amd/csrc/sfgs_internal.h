@@ -101,6 +101,8 @@ __device__ __forceinline__ FrameParams load_frame(const KFrame& k) {
 
 // ---- blob layouts -------------------------------------------------------------------------------
 constexpr int PRE_BLOCK = 256;      // threads per block of the per-Gaussian kernels
+// SfgsFrame.feedback: 8 uint64 words of caller-owned persistent device memory (late statistics of the previous frame)
+enum { FB_VALID = 0, FB_LONG_TILES = 1, FB_MAX_LIST = 2, FB_PREFILLED = 3 };
 constexpr int HDR_WORDS = 64;       // uint64 words at the head of the tiles blob
 
 enum HeaderSlot {

@@ -57,6 +57,17 @@ _ncb_cache = {}  # (W, H) -> number of coarse bins
 _zeros = {}      # device index -> 1-element zero tensor
 _budget = {}     # device index -> scratch budget in bytes (half of the device memory)
 _cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin capacity) to plan with
+# Launch hints (include/sfgs.h SFGS_HINT_*): what the previous frames of a (device, stream) taught about the frame's
+# optional kernels. `fb` is the 64-byte persistent device buffer the library leaves a frame's late statistics in
+# (SfgsFrame.feedback); SFGS_HINTS=0 in the environment switches the mechanism off (tests compare both).
+_hint_state = {}  # (device index, stream) -> dict(fb=tensor, huge=int, long=int, prefilled=int, bwd=int)
+HINT_NO_HUGE_SPLATS, HINT_FEW_LONG_LISTS, HINT_NO_PREFILL, HINT_NO_BIG_CHUNKS = 1, 2, 4, 8
+PREFILL_PROBE_EVERY = 32   # backward passes between two launches of the dead-entry prefill kernel while it keeps saying no
+
+
+def _hints_on():
+    import os
+    return os.environ.get("SFGS_HINTS", "1") != "0"
 
 
 def _scratch_budget(dev):
@@ -92,7 +103,7 @@ def _pinned_counters(dev, stream):
     key = (dev.index, stream.cuda_stream)
     entry = table.get(key)
     if entry is None:
-        entry = table[key] = (torch.empty(8, dtype=torch.int64).pin_memory(),
+        entry = table[key] = (torch.empty(16, dtype=torch.int64).pin_memory(),   # 128 bytes: sfgs_raster_forward_plan
                               torch.cuda.Event(enable_timing=False, blocking=False))
     return entry
 
@@ -145,7 +156,7 @@ def _settings_tensors(settings, dev):
     return sub, bg, view, proj, campos
 
 
-def _frame(settings, dev, sh_coeffs, keep):
+def _frame(settings, dev, sh_coeffs, keep, hints=0, feedback=None):
     H, W = int(settings.image_height), int(settings.image_width)
     sub, bg, view, proj, campos = _settings_tensors(settings, dev)
     keep.extend([sub, bg, view, proj, campos])
@@ -154,7 +165,7 @@ def _frame(settings, dev, sh_coeffs, keep):
                        float(settings.kernel_size), float(settings.scale_modifier), int(settings.sh_degree),
                        int(sh_coeffs), int(bool(settings.prefiltered)), int(bool(settings.debug)),
                        int(getattr(settings, "depth_mode", 0)), int(rows[0]), int(rows[1]), L.ptr(sub), L.ptr(bg), L.ptr(view), L.ptr(proj),
-                       L.ptr(campos))
+                       L.ptr(campos), int(hints), L.ptr(feedback))
 
 
 def C_sizeof(t):
@@ -176,7 +187,6 @@ class _Rasterize(torch.autograd.Function):
         sh_coeffs = 0 if shs is None else int(shs.shape[1])
         keep = []
         with torch.cuda.device(dev):
-            frame = _frame(settings, dev, sh_coeffs, keep)
             stream = _stream(dev)
             gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                                  L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
@@ -203,6 +213,18 @@ class _Rasterize(torch.autograd.Function):
             color, depth, alpha = outs[0:3], outs[3:4], outs[4:5]
             radii = torch.empty(N, dtype=torch.int32, device=dev)
             al = lambda n: (n + 255) // 256 * 256
+            tstream = torch.cuda.current_stream(dev)
+            hkey = (dev.index, tstream.cuda_stream)
+            hs = None
+            if _hints_on():
+                hs = _hint_state.get(hkey)
+                if hs is None:   # first frame on this stream: no hints yet, everything is launched
+                    hs = _hint_state[hkey] = dict(fb=torch.zeros(8, dtype=torch.int64, device=dev), huge=1, long=1,
+                                                  prefilled=1, bwd=0, prefill_ran=False)
+            fwd_hints = 0
+            if hs is not None:
+                fwd_hints = (HINT_NO_HUGE_SPLATS if hs["huge"] == 0 else 0) | (HINT_FEW_LONG_LISTS if hs["long"] == 0 else 0)
+            feedback = hs["fb"] if hs is not None else None
             while True:
                 L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
                 o_tiles = al(max(sizes.geom_bytes, 1))
@@ -217,13 +239,13 @@ class _Rasterize(torch.autograd.Function):
                 scratch = torch.empty(total, dtype=torch.uint8, device=dev)
                 geom, tiles, bins = scratch[:o_tiles], scratch[o_tiles:o_bins], scratch[o_bins:o_image]
                 image = scratch[o_image:] if need_bwd else None
+                frame = _frame(settings, dev, sh_coeffs, keep, fwd_hints, feedback)
                 # plan and render are enqueued back to back. The plan's last kernel writes the frame's counters into
                 # pinned host memory; an event recorded between the two stages lets the host read them -- the one
                 # host wait of the frame -- WHILE the render stage runs, so the wrapper's epilogue, the caller's loss
                 # and the backward's launch overlap with the compositing kernel instead of following a drained
                 # stream. Both stages are redone in the rare case a capacity was exceeded (an overflowing plan is
-                # memory-safe).
-                tstream = torch.cuda.current_stream(dev)
+                # memory-safe) or a launch hint turned out wrong.
                 pin, ev = _pinned_counters(dev, tstream)
                 L.check(lib.sfgs_raster_forward_plan(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom),
                                                      geom.numel(), L.ptr(tiles), tiles.numel(), L.ptr(bins),
@@ -235,15 +257,29 @@ class _Rasterize(torch.autograd.Function):
                                                        stream))
                 cnt = L.SfgsRasterCounters()
                 if _stats["full"]:  # diagnostics: wait for the render too, so that max_tile_list is included
-                    L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(cnt), stream))
+                    ev.synchronize()
+                    L.check(lib.sfgs_raster_counters_decode(L.C.c_void_p(pin.data_ptr()), L.C.byref(cnt)))
+                    full = L.SfgsRasterCounters()
+                    L.check(lib.sfgs_raster_read_counters(L.ptr(tiles), L.C.byref(full), stream))
+                    cnt.max_tile_list = full.max_tile_list
                 else:
                     ev.synchronize()
                     L.check(lib.sfgs_raster_counters_decode(L.C.c_void_p(pin.data_ptr()), L.C.byref(cnt)))
                 D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
+                if (fwd_hints & HINT_NO_HUGE_SPLATS) and cnt.num_huge_splats:
+                    fwd_hints &= ~HINT_NO_HUGE_SPLATS      # this frame HAS splats the skipped walk bins: redo with it
+                    continue
                 if not cnt.overflow and slots(D) <= cap and cmax <= ccap:
                     break
                 cap = max(cap, slots(int(D * 1.25) + 1024))
                 ccap = max(ccap, int(cmax * 1.25) + 256)
+            if hs is not None:
+                if cnt.prev_valid:   # the previous frame's render / backward stages, as this frame's plan found them
+                    hs["long"] = int(cnt.prev_long_tiles)
+                    if hs["prefill_ran"]:
+                        hs["prefilled"] = int(cnt.prev_prefilled)
+                hs["huge"] = int(cnt.num_huge_splats)
+                hs["prefill_ran"] = False
             _cap_hint[(dev.index, W, H)] = (max(slots(int(D * 1.25) + 1024), min(cap, slots(2 * D + 1024))),
                                     max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
             global _last_counters
@@ -260,6 +296,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if need_bwd:
             ctx.settings, ctx.D, ctx.ccap, ctx.sh_coeffs, ctx.ndup = settings, cap, ccap, sh_coeffs, D
+            ctx.big_chunks, ctx.hkey = int(cnt.num_big_chunks), hkey
             ctx.keep = keep
             ctx.has_colors, ctx.has_shs = colors_precomp is not None, shs is not None
             ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, geom, tiles, bins,
@@ -275,7 +312,19 @@ class _Rasterize(torch.autograd.Function):
         settings, D = ctx.settings, ctx.D
         with torch.cuda.device(dev):  # autograd worker thread: select the device, use ITS current stream
             keep = []
-            frame = _frame(settings, dev, ctx.sh_coeffs, keep)
+            bwd_hints = 0
+            hs = _hint_state.get(ctx.hkey) if _hints_on() else None
+            if hs is not None:
+                if ctx.big_chunks == 0:
+                    bwd_hints |= HINT_NO_BIG_CHUNKS            # exact: this frame's own plan counted none
+                # the dead-entry prefill decides on the device; while it keeps deciding "no" it is only launched every
+                # PREFILL_PROBE_EVERY-th backward (either way the gradients are the same bits: tests/test_gpu_raster.py)
+                hs["bwd"] += 1
+                if hs["prefilled"] == 0 and hs["bwd"] % PREFILL_PROBE_EVERY != 0:
+                    bwd_hints |= HINT_NO_PREFILL
+                else:
+                    hs["prefill_ran"] = True
+            frame = _frame(settings, dev, ctx.sh_coeffs, keep, bwd_hints, hs["fb"] if hs is not None else None)
             stream = _stream(dev)
             gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                                  L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -19,7 +19,8 @@ class SfgsFrame(C.Structure):
                 ("prefiltered", C.c_int32), ("debug", C.c_int32), ("depth_mode", C.c_int32),
                 ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
                 ("subpixel_offset", C.c_void_p), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
-                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("launch_hints", C.c_uint32),
+                ("feedback", C.c_void_p)]
 
 
 class SfgsGaussians(C.Structure):
@@ -60,7 +61,9 @@ class SfgsDensifyTensor(C.Structure):
 
 class SfgsRasterCounters(C.Structure):
     _fields_ = [("num_duplicates", C.c_int64), ("num_duplicates_ref", C.c_int64), ("num_visible", C.c_int64),
-                ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64)]
+                ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64),
+                ("num_huge_splats", C.c_int64), ("num_big_chunks", C.c_int64), ("prev_valid", C.c_int64),
+                ("prev_long_tiles", C.c_int64), ("prev_max_tile_list", C.c_int64), ("prev_prefilled", C.c_int64)]
 
 
 # every symbol include/sfgs.h declares: name -> (restype, argtypes)

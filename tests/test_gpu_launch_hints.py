@@ -1,0 +1,89 @@
+"""Launch hints (include/sfgs.h SFGS_HINT_*; diff_gauss keeps per-stream state from the previous frames): a frame's optional
+kernels -- huge-splat walk, long-list sorts, dead-entry prefill, chunk pre-reduction -- are only launched when the
+previous frames say they have work. A WRONG prediction must never change a result: the huge-splat hint is verified
+against the plan's own count and the frame redone, the others are correct by construction. Every case renders a
+sequence of frames whose character changes abruptly, once with the mechanism on and once with SFGS_HINTS=0, and compares
+bit for bit (images, radii, every gradient)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sfgs.synth import city_scene, scene, upstream_grads
+
+pytestmark = pytest.mark.gpu
+W, H = 512, 288
+
+
+def _frames():
+    """(name, frame, gaussians): calm -> screen-filling splats -> calm -> long lists -> opaque city (dead entries)"""
+    out = []
+    f, g = scene(40000, W, H, seed=1, zrange=(250., 350.), scale_range=(0.2, 2.0))
+    out.append(("calm", f, g))
+    f2, g2 = scene(3000, W, H, seed=2, zrange=(4., 8.), scale_range=(0.5, 6.0))       # splats covering the whole screen
+    out.append(("huge_splats", f2, g2))
+    out.append(("calm_again", f, g))
+    f3, g3 = scene(400000, W, H, seed=3, zrange=(250., 350.), scale_range=(1.0, 6.0))  # lists of > 512 .. > 2048 entries
+    out.append(("long_lists", f3, g3))
+    f4, g4 = city_scene(120000, W, H, 25.0, seed=4)
+    out.append(("opaque_city", f4, g4))
+    out.append(("calm_last", f, g))
+    return out
+
+
+def _run(frames, reps):
+    from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, last_counters
+    dev = torch.device("cuda:0")
+    res = []
+    for name, frame, g in frames:
+        for rep in range(reps):     # the second pass over the same content runs WITH the hints learnt from the first
+            settings = GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"],
+                kernel_size=frame["kernel_size"], subpixel_offset=None, bg=frame["bg"].to(dev), scale_modifier=1.0,
+                viewmatrix=frame["view"].to(dev), projmatrix=frame["proj"].to(dev), sh_degree=0,
+                campos=frame["campos"].to(dev), prefiltered=False, debug=False)
+            t = {k: v.to(dev).requires_grad_(True) for k, v in g.items() if v is not None}
+            m2 = torch.zeros(t["means3D"].shape[0], 3, device=dev, requires_grad=True)
+            color, depth, _, alpha, radii, _ = GaussianRasterizer(settings)(
+                means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors_precomp"],
+                scales=t["scales"], rotations=t["rotations"])
+            gc, gd = upstream_grads(W, H, 7)
+            gd = gd.to(dev).clone()
+            gd[torch.isnan(depth)] = 0
+            torch.autograd.backward([color, torch.nan_to_num(depth)], [gc.to(dev), gd])
+            rec = dict(name=f"{name}#{rep}", color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
+                       radii=radii.cpu().numpy(), m2=m2.grad.cpu().numpy(),
+                       **{"g_" + k: v.grad.cpu().numpy() for k, v in t.items()})
+            rec["counters"] = last_counters()
+            res.append(rec)
+    return res
+
+
+def test_hints_never_change_a_result():
+    import diff_gauss
+    frames = _frames()
+    old = os.environ.get("SFGS_HINTS")
+    try:
+        os.environ["SFGS_HINTS"] = "0"
+        diff_gauss._hint_state.clear()
+        ref = _run(frames, 2)
+        os.environ["SFGS_HINTS"] = "1"
+        diff_gauss._hint_state.clear()
+        got = _run(frames, 2)
+        state = dict(next(iter(diff_gauss._hint_state.values())))
+    finally:
+        if old is None:
+            os.environ.pop("SFGS_HINTS", None)
+        else:
+            os.environ["SFGS_HINTS"] = old
+    assert state["fb"] is not None and int(state["fb"][0]) == 1 and state["huge"] == 0
+    for a, b in zip(ref, got):
+        for k in a:
+            if k in ("name", "counters"):
+                continue
+            np.testing.assert_array_equal(np.nan_to_num(a[k], nan=-1.0), np.nan_to_num(b[k], nan=-1.0),
+                                          err_msg=f"{a['name']}: {k}")
+    # the sequence did exercise what it claims to
+    by = {r["name"]: r["counters"] for r in got}
+    assert by["long_lists#1"]["num_duplicates"] > 10 * by["calm#1"]["num_duplicates"]
