@@ -17,12 +17,14 @@
 
 #include <algorithm>
 
+#include <type_traits>
+
 #include "sfgs_internal.h"
 
 namespace sfgs {
 
 constexpr int REG_SORT_SMALL = 512;  // lists up to here: sort_tiles_reg_kernel (<= 8 keys per lane, 8 waves per SIMD)
-constexpr int REG_SORT_MAX = 2048;   // lists up to here: register network too (16 / 32 keys per lane), separate kernel
+constexpr int REG_SORT_MAX = 1024;   // lists up to here: register network too (16 keys per lane), separate kernel
 
 // ------------------------------------------------------------------------------------------------
 // max |subpixel_offset| -> header (float bits; non-negative floats order like unsigned ints)
@@ -631,9 +633,9 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
   else sort_tile_in_registers<8>(tr.x, L, lane, items, sorted_id, sorted_dup);
 }
 
-// K4a': the same register network with EPL = 16 / 32 keys per lane for lists of 513..1024 / 1025..2048 entries
-// (low-elevation views, dense frames). Kernels of their own: 99 / 195 VGPRs would otherwise cut the occupancy of the
-// common short lists (and of each other). One wave per tile, persistent over the device-side list of long tiles.
+// K4a': the same register network with EPL = 16 keys per lane for lists of 513..1024 entries (low-elevation views, dense
+// frames). A kernel of its own: 99 VGPRs would otherwise cut the occupancy of the common short lists. One wave per tile,
+// persistent over the device-side list of long tiles. (Longer lists: the bucketed sort of sort_tiles_long_kernel.)
 template <int EPL>
 __global__ void __launch_bounds__(256)
 sort_tiles_reg_long_kernel(const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
@@ -660,7 +662,7 @@ sort_tiles_reg_long_kernel(const uint32_t* __restrict__ long_tiles, const unsign
 //              relaxed (they bypass the per-CU L1, so the waves of the workgroup see each other's exchanges after
 //              the barrier).
 template <int CAP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)   // three workgroups per CU: what the 52 KB of LDS allow
 sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
                        const uint2* __restrict__ tile_range, uint4* items, uint32_t* __restrict__ sorted_id,
                        uint32_t* __restrict__ sorted_dup) {
@@ -669,6 +671,151 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
   constexpr int NT = 256;
   const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
   const int tid = threadIdx.x;
+  // ---- bucketed sort (lists of up to 2 CAP entries): O(n) partition by depth, then small register sorts ----------------
+  // The list is split into 256 equal-width depth bins (LDS histogram, counting scatter); consecutive bins are grouped
+  // into segments of at most SEG entries and every segment is sorted by ONE WAVE in registers on the full 64-bit key
+  // (depth bits, id) -- the network of the short lists, no barriers, no LDS exchanges. Only the depth bits and the
+  // entry's 16-bit position live in LDS (6 bytes per entry: the same 48 KB hold 2 CAP entries); ids and duplicate indices
+  // are gathered from the tile's item segment when a segment is loaded. A bitonic network over 4 096 entries has 78
+  // barrier-separated LDS steps, over 8 192 entries 23 of its 91 steps went through global memory; this needs three
+  // barriers and log^2(512) = 45 register steps per segment. Falls back to the network when one bin alone exceeds SEG
+  // (a list concentrated in < 0.4 % of its own depth range) or all depths are equal.
+#ifndef SFGS_BK_SEG
+#define SFGS_BK_SEG 512
+#endif
+  constexpr int BK_BINS = 256, SEG = SFGS_BK_SEG, BK_CAP = 2 * CAP;
+  uint32_t* bk_depth = reinterpret_cast<uint32_t*>(k);          // [BK_CAP] depth bits, grouped by bin
+  uint16_t* bk_pos = reinterpret_cast<uint16_t*>(pl);           // [BK_CAP] position in the tile's item segment
+  __shared__ unsigned bk_hist[BK_BINS], bk_start[BK_BINS + 1], bk_red[2 * (NT / 64)];
+  __shared__ unsigned short bk_seg_bin[BK_BINS + 1], bk_next[BK_BINS];   // first bin of every segment (+ end marker)
+  static_assert(NT == BK_BINS, "one thread per depth bin");
+  __shared__ unsigned bk_nseg, bk_fallback;
+  // Two LDS layouts: lists of up to CAP entries keep (depth, id, duplicate index) in LDS -- the tile's items are read from
+  // memory exactly once; lists of up to 2 CAP entries keep (depth, 16-bit position) and gather id / duplicate index from
+  // the item segment when a segment is sorted (a second, scattered read of the items).
+  uint32_t* bk_id = reinterpret_cast<uint32_t*>(k) + CAP;         // [CAP]  (narrow layout only)
+  auto bucket_sort = [&](unsigned s, int L, auto wide_tag) -> bool {
+    constexpr bool WIDE = decltype(wide_tag)::value;
+    const int lane = tid & 63, wave = tid >> 6;
+    // the thread's depths stay in registers for all three passes (min / max, histogram, scatter): read from memory in
+    // every pass, each pass was a chain of dependent global-load latencies
+    constexpr int PER = (WIDE ? BK_CAP : CAP) / NT;
+    unsigned dreg[PER], idreg[WIDE ? 1 : PER], dupreg[WIDE ? 1 : PER];
+    unsigned dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = tid + NT * r;
+      if constexpr (WIDE) {
+        dreg[r] = i < L ? items[s + i].y : 0u;
+      } else {
+        uint4 it = make_uint4(0u, 0u, 0u, 0u);
+        if (i < L) it = items[s + i];
+        dreg[r] = it.y; idreg[r] = it.x; dupreg[r] = it.z;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+      if (tid + NT * r < L) { dmin = min(dmin, dreg[r]); dmax = max(dmax, dreg[r]); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o)); dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o)); }
+    if (lane == 0) { bk_red[wave] = dmin; bk_red[NT / 64 + wave] = dmax; }
+    if (tid < BK_BINS) bk_hist[tid] = 0u;
+    __syncthreads();
+    dmin = min(min(bk_red[0], bk_red[1]), min(bk_red[2], bk_red[3]));
+    dmax = max(max(bk_red[4], bk_red[5]), max(bk_red[6], bk_red[7]));
+    if (dmin == dmax) return false;                               // uniform across the workgroup
+    // view depths are positive floats: their bit patterns order like the values, and the float arithmetic below is
+    // monotonic in the depth (subtract, scale, truncate)
+    const float fmin = __uint_as_float(dmin), scale = 255.5f / (__uint_as_float(dmax) - fmin);
+    auto bin_of = [&](unsigned d) { return min((unsigned)((__uint_as_float(d) - fmin) * scale), (unsigned)(BK_BINS - 1)); };
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+      if (tid + NT * r < L) atomicAdd(&bk_hist[bin_of(dreg[r])], 1u);
+    __syncthreads();
+    if (wave == 0) {   // exclusive scan of the 256 counts (4 per lane), largest bin
+      unsigned c[4], sum = 0, big = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { c[q] = bk_hist[lane * 4 + q]; sum += c[q]; big = max(big, c[q]); }
+      unsigned incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o));
+      unsigned run = incl - sum;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { bk_start[lane * 4 + q] = run; bk_hist[lane * 4 + q] = run; run += c[q]; }   // hist -> cursors
+      if (lane == 63) bk_start[BK_BINS] = run;
+      if (lane == 0) bk_fallback = big > (unsigned)SEG ? 1u : 0u;
+    }
+    __syncthreads();
+    if (bk_fallback) return false;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = tid + NT * r;
+      if (i < L) {
+        const unsigned pos = atomicAdd(&bk_hist[bin_of(dreg[r])], 1u);
+        bk_depth[pos] = dreg[r];
+        if constexpr (WIDE) bk_pos[pos] = (uint16_t)i;
+        else { bk_id[pos] = idreg[r]; pl[pos] = dupreg[r]; }
+      }
+    }
+    // greedy grouping of consecutive bins into segments of at most SEG entries: every bin finds, by binary search on the
+    // prefix sums, the first bin that no longer fits a segment starting at itself; one thread then hops along
+    {
+      const unsigned base = bk_start[tid];          // NT == BK_BINS threads
+      int lo_b = tid + 1, hi_b = BK_BINS;           // largest e in (tid, 256] with bk_start[e] - base <= SEG
+      while (lo_b < hi_b) {
+        const int mid = (lo_b + hi_b + 1) >> 1;
+        if (bk_start[mid] - base <= (unsigned)SEG) lo_b = mid; else hi_b = mid - 1;
+      }
+      bk_next[tid] = (unsigned short)lo_b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned ns = 0, bb = 0;
+      while (bb < (unsigned)BK_BINS && bk_start[bb] < (unsigned)L) { bk_seg_bin[ns++] = (unsigned short)bb; bb = bk_next[bb]; }
+      bk_seg_bin[ns] = (unsigned short)BK_BINS;
+      bk_nseg = ns;
+    }
+    __syncthreads();
+    const unsigned nseg = bk_nseg;
+    for (unsigned g = wave; g < nseg; g += NT / 64) {
+      // a segment ends where the next one begins (empty bins in between belong to nobody)
+      const unsigned a = bk_start[bk_seg_bin[g]], e = bk_start[bk_seg_bin[g + 1]];
+      const int n = (int)(e - a);
+      auto run_seg = [&](auto epl_tag) {
+        constexpr int E = decltype(epl_tag)::value;
+        unsigned long long key[E];
+        unsigned pay[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int i = r * 64 + lane;
+          key[r] = ~0ull; pay[r] = 0u;
+          if (i < n) {
+            if constexpr (WIDE) {
+              const uint4 it = items[s + bk_pos[a + i]];
+              key[r] = ((unsigned long long)bk_depth[a + i] << 32) | it.x;
+              pay[r] = it.z;
+            } else {
+              key[r] = ((unsigned long long)bk_depth[a + i] << 32) | bk_id[a + i];
+              pay[r] = pl[a + i];
+            }
+          }
+        }
+        wave_bitonic_sort<E>(key, pay, lane);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int q = lane * E + r;
+          if (q < n) { sorted_id[s + a + q] = (unsigned)(key[r] & 0xffffffffull); sorted_dup[s + a + q] = pay[r]; }
+        }
+      };
+      if (n <= 64) run_seg(std::integral_constant<int, 1>{});
+      else if (n <= 128) run_seg(std::integral_constant<int, 2>{});
+      else if (n <= 256) run_seg(std::integral_constant<int, 4>{});
+      else run_seg(std::integral_constant<int, 8>{});
+    }
+    return true;
+  };
 
   // comparators (i, i ^ mask-ish) of one network step restricted to LDS-resident positions [0, m)
   auto lds_mirror = [&](int m, int size) {   // first step of `size`: i <-> block_end - 1 - offset
@@ -692,25 +839,12 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
     }
   };
 
-  // full sort of the m (power of two, <= CAP) entries in LDS. For m = 4096 each of the four waves first sorts its own
-  // 1024 entries in REGISTERS (the network of sort_tile_in_registers, 16 keys per lane: no barriers, no LDS traffic),
-  // which leaves only the 23 merge steps of sizes 2048 and 4096 to LDS instead of all 78
+  // full sort of the m (power of two, <= CAP) entries in LDS: the bitonic network, one barrier per step. Only the
+  // bucketed sort's fallback and the chunks of lists beyond 2 CAP entries come here (a register presort of the four
+  // 1 024-entry quarters used to save 55 of the 78 steps at m = 4096, for 127 VGPRs: with the bucketed sort in front it
+  // would only cost the common path its occupancy).
   auto sort_lds = [&](int m) {
-    int first = 2;
-    if (m == 4 * 1024) {
-      constexpr int E = 16;
-      const int wv = tid >> 6, ln = tid & 63, cb = 1024 * wv;
-      unsigned long long key[E];
-      unsigned pay[E];
-#pragma unroll
-      for (int r = 0; r < E; ++r) { key[r] = k[cb + r * 64 + ln]; pay[r] = pl[cb + r * 64 + ln]; }
-      wave_bitonic_sort<E>(key, pay, ln);
-#pragma unroll
-      for (int r = 0; r < E; ++r) { k[cb + ln * E + r] = key[r]; pl[cb + ln * E + r] = pay[r]; }
-      __syncthreads();
-      first = 2048;
-    }
-    for (int size = first; size <= m; size <<= 1) { lds_mirror(m, size); lds_strides(m, size >> 2); }
+    for (int size = 2; size <= m; size <<= 1) { lds_mirror(m, size); lds_strides(m, size >> 2); }
   };
 
   for (unsigned li = blockIdx.x; li < n_long; li += gridDim.x) {  // uniform per workgroup
@@ -718,6 +852,8 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
     const unsigned s = tr.x;
     const long long L = (long long)tr.y;
     if (L <= lo) continue;
+    __syncthreads();
+    if (L <= CAP ? bucket_sort(s, (int)L, std::false_type{}) : (L <= BK_CAP && bucket_sort(s, (int)L, std::true_type{}))) continue;
     __syncthreads();
     long long n = 1;
     while (n < L) n <<= 1;
@@ -1299,10 +1435,10 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
       hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_SMALL,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
     } else {
+    // size classes: 513..1024 -> register network with 16 keys per lane; longer -> bucketed sort (a 32-key register
+    // network used to take 1025..2048: 195 VGPRs, one more launch, and slower than the buckets -- city 0.179 -> 0.152 ms)
     { ProfScope ps_(KID_SORT_REG_LONG, stream);
       hipLaunchKernelGGL(sort_tiles_reg_long_kernel<16>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
-                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
-      hipLaunchKernelGGL(sort_tiles_reg_long_kernel<32>, dim3(std::min((T8 + 3) / 4, 2048)), dim3(256), 0, stream,
                          tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
     SFGS_POST_LAUNCH("sort_tiles_reg_long", stream, frame->debug);
     { ProfScope ps_(KID_SORT_LDS, stream);

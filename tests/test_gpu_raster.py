@@ -30,14 +30,18 @@ CASES = {
     # the headline scene generator at its full viewport, 1/10 of the Gaussians (the oracle needs ~1 s for it)
     "cfg2_200k_1080p": dict(n=200000, W=1920, H=1080, kw=dict()),
     "cfg4_like_1440p": dict(n=150000, W=2560, H=1440, kw=dict(zrange=(500., 700.))),
-    # long per-tile lists, one case per sort path: ~800 (register network, 16 keys per lane), ~2000 (32 keys per lane),
-    # ~3000 (LDS), ~6000 (LDS chunks + one global-memory level), ~10000 (two global-memory levels); low opacity so that
+    # long per-tile lists, one case per sort path: ~800 (register network, 16 keys per lane), ~2000 and ~3000 (bucketed
+    # sort, narrow LDS layout), ~6000 (bucketed, wide layout), ~10000 (LDS chunks + global-memory levels); low opacity so that
     # pixels do not saturate after a few dozen splats and the long lists are really composited
     "lists_800": dict(n=900, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.03))),
     "lists_2k": dict(n=2000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.02))),
     "lists_3k": dict(n=3000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
     "lists_6k": dict(n=6000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
     "lists_10k": dict(n=18000, W=16, H=16, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
+    # the bucketed sort's exits: every depth equal (order = Gaussian id alone) and a handful of distinct depths (one depth
+    # bin holds more than a segment): both fall back to the network
+    "lists_3k_equal_depth": dict(n=3000, W=24, H=24, kw=dict(zrange=(5., 5.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
+    "lists_3k_few_depths": dict(n=3000, W=24, H=24, kw=dict(zrange=(5., 5.000002), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
 }
 
 
