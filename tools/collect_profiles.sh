@@ -31,7 +31,8 @@ done
 EXIST=""
 for d in $DBS; do [ -f "$d" ] && EXIST="$EXIST $d"; done
 KT=""; [ -f "$R/kt/kt_results.db" ] && KT="$R/kt/kt_results.db"
-python tools/prof_summary.py $KT --pmc $EXIST --json "$R/traffic.json" --sq-json "$R/sq.json" > "$R/summary.txt" 2>&1
+CAL=""; [ -f profiles/r3_sq_calibration.json ] && CAL="--cal profiles/r3_sq_calibration.json"   # tools/calibrate_sq.sh
+python tools/prof_summary.py $CAL $KT --pmc $EXIST --json "$R/traffic.json" --sq-json "$R/sq.json" > "$R/summary.txt" 2>&1
 grep '^{' "$R/kt.log" 2>/dev/null | tail -1 > "$R/bench_under_rocprof.json"
 for f in "$R"/*.log; do tail -3 "$f" > "$f.tail"; rm -f "$f"; done
 rm -rf "$R/kt" "$R/fetch" "$R/write" "$R/sq1" "$R/sq2" "$R/sq3"

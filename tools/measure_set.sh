@@ -10,13 +10,15 @@ B="timeout 300 python bench.py --cpu-sample 0"
 timeout 400 python bench.py > "$R/bench_default.json" 2> "$R/bench_default.err"
 $B --n 500000 > "$R/bench_500000.json" 2>/dev/null
 $B --n 1000000 > "$R/bench_1000000.json" 2>/dev/null
-$B --n 5000000 --width 2560 --height 1440 > "$R/bench_cfg4.json" 2>/dev/null
-$B --width 1024 --height 1024 > "$R/bench_idu1024.json" 2>/dev/null
+$B --config cfg4 > "$R/bench_cfg4.json" 2>/dev/null          # 5 M, 2560x1440, z ~ U(500, 700), dL/ddepth != 0
+$B --config cfg3 > "$R/bench_cfg3.json" 2>/dev/null          # 108 forward-only 1024^2 renders + the timed fwd+bwd steps
+$B --n 5000000 --width 2560 --height 1440 > "$R/bench_5M_1440p_cfg2geometry.json" 2>/dev/null   # (the r1/r2 "cfg 4" line)
+HSA_ENABLE_IPC_MODE_LEGACY=0 $B --force-dist > "$R/bench_force_dist_rccl.json" 2>/dev/null      # RCCL all-reduce every step, world = 1
 $B --sh-degree 1 > "$R/bench_sh1.json" 2>/dev/null
 $B --sh-degree 3 > "$R/bench_sh3.json" 2>/dev/null
 $B --forward-only > "$R/fps_2M.json" 2>/dev/null
-$B --forward-only --n 5000000 --width 2560 --height 1440 > "$R/fps_cfg4.json" 2>/dev/null
-$B --forward-only --width 1024 --height 1024 > "$R/fps_idu1024.json" 2>/dev/null
+$B --forward-only --config cfg4 > "$R/fps_cfg4.json" 2>/dev/null
+$B --forward-only --config cfg3 > "$R/fps_cfg3_1024sq.json" 2>/dev/null
 $B --forward-only --n 16000000 > "$R/fps_16M.json" 2>/dev/null
 timeout 600 python tools/bench_regimes.py > "$R/regimes.jsonl" 2>/dev/null
 timeout 300 python tools/bench_train_iter.py > "$R/train_iteration.json" 2>/dev/null
