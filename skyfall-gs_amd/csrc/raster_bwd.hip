@@ -165,28 +165,37 @@ __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, flo
 template <int B, bool HAS_BG>
 __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsigned pm, float sx, float sy, int lane) {
   constexpr int ROW = BwdLds<B>::ROW;
-  // two entries per iteration: their record reads, exponentials and reciprocals are independent and overlap; only the
-  // short transmittance / "colour behind" recurrences chain them
+  // SFGS_P1_K entries per iteration: their record reads, exponentials and reciprocals are independent and overlap; only
+  // the short transmittance / "colour behind" recurrences chain them
   // do-while: the caller only enters with at least one blended entry in the wave (a batch without any skips the phase)
+#ifndef SFGS_P1_K
+#define SFGS_P1_K 2
+#endif
+  constexpr int K = SFGS_P1_K;
   do {
-    unsigned fb;
-    asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));            // 0xffffffff for pm == 0
-    const unsigned j1 = min(fb ^ 31u, (unsigned)B);            // -> B (the dummy entry) for pm == 0
-    pm = __builtin_amdgcn_ubfe(pm, 0u, j1);                    // clear bit j1 and everything above it
-    asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));
-    const unsigned j2 = min(fb ^ 31u, (unsigned)B);
-    pm = __builtin_amdgcn_ubfe(pm, 0u, j2);
-    const float4 a0 = lds.recs[j1 * 3], a1 = lds.recs[j1 * 3 + 1];
-    const float2 a2 = *reinterpret_cast<const float2*>(&lds.recs[j1 * 3 + 2]);
-    const float4 b0 = lds.recs[j2 * 3], b1 = lds.recs[j2 * 3 + 1];
-    const float2 b2 = *reinterpret_cast<const float2*>(&lds.recs[j2 * 3 + 2]);
-    const SplatEval e1 = eval_splat(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, sx, sy);
-    const SplatEval e2 = eval_splat(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, sx, sy);
-    float u1, w1, u2, w2;
-    pixel_bwd_scalars<HAS_BG>(ps, e1, a2.y, a1.z, a1.w, a2.x, u1, w1);
-    pixel_bwd_scalars<HAS_BG>(ps, e2, b2.y, b1.z, b1.w, b2.x, u2, w2);
-    lds.UW[j1 * ROW + lane] = make_float2(u1, w1);
-    lds.UW[j2 * ROW + lane] = make_float2(u2, w2);
+    unsigned j[K];
+    float4 r0[K], r1[K];
+    float2 r2[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      unsigned fb;
+      asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));            // 0xffffffff for pm == 0
+      j[q] = min(fb ^ 31u, (unsigned)B);                          // -> B (the dummy entry) for pm == 0
+      pm = __builtin_amdgcn_ubfe(pm, 0u, j[q]);                   // clear bit j and everything above it
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      r0[q] = lds.recs[j[q] * 3]; r1[q] = lds.recs[j[q] * 3 + 1];
+      r2[q] = *reinterpret_cast<const float2*>(&lds.recs[j[q] * 3 + 2]);
+    }
+    SplatEval e[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) e[q] = eval_splat(r0[q].x, r0[q].y, r0[q].z, r0[q].w, r1[q].x, r1[q].y, sx, sy);
+    float u[K], w[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) pixel_bwd_scalars<HAS_BG>(ps, e[q], r2[q].y, r1[q].z, r1[q].w, r2[q].x, u[q], w[q]);
+#pragma unroll
+    for (int q = 0; q < K; ++q) lds.UW[j[q] * ROW + lane] = make_float2(u[q], w[q]);
   } while (__ballot(pm != 0u) != 0ull);
 }
 
