@@ -96,18 +96,35 @@ compact_gather_kernel(const CompactTable tab, const unsigned char* __restrict__ 
   const long long row0 = base / ru;                                         // one 64-bit division per block
   const unsigned rem0 = (unsigned)(base - row0 * ru);
   const float inv = 1.0f / (float)ru;
+  // three phases so that every load of the thread is in flight before the first use: rows and keep flags, then
+  // destination rows and source words (unconditional, from clamped indices), then the predicated stores. (One loop with
+  // `if (keep[row]) dst[..dst_index[row]..] = src[w]` serialises three dependent round trips per word.)
+  long long rowv[CP_WORDS_PER_THREAD];
+  unsigned colv[CP_WORDS_PER_THREAD];
+  unsigned char kp[CP_WORDS_PER_THREAD];
 #pragma unroll
   for (int k = 0; k < CP_WORDS_PER_THREAD; ++k) {
     const unsigned off = threadIdx.x + k * CP_NT;
-    const long long w = base + off;
-    if (w < words) {
-      // (rem0 + off) / ru with x < 2^24: float estimate + one correction step is exact
-      const unsigned x = rem0 + off;
-      unsigned q = (unsigned)((float)x * inv);
-      if (q * ru > x) --q; else if ((q + 1) * ru <= x) ++q;
-      const long long row = row0 + q;
-      if (keep[row]) dst[(long long)dst_index[row] * ru + (x - q * ru)] = src[w];
-    }
+    // (rem0 + off) / ru with x < 2^24: float estimate + one correction step is exact
+    const unsigned x = rem0 + off;
+    unsigned q = (unsigned)((float)x * inv);
+    if (q * ru > x) --q; else if ((q + 1) * ru <= x) ++q;
+    rowv[k] = min(row0 + (long long)q, N - 1);
+    colv[k] = x - q * ru;
+    kp[k] = keep[rowv[k]];
+  }
+  U val[CP_WORDS_PER_THREAD];
+  unsigned di[CP_WORDS_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < CP_WORDS_PER_THREAD; ++k) {
+    const long long w = min(base + (long long)(threadIdx.x + k * CP_NT), words - 1);
+    val[k] = src[w];
+    di[k] = dst_index[rowv[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < CP_WORDS_PER_THREAD; ++k) {
+    const long long w = base + (long long)(threadIdx.x + k * CP_NT);
+    if (w < words && kp[k]) dst[(long long)di[k] * ru + colv[k]] = val[k];
   }
 }
 

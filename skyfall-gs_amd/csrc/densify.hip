@@ -228,27 +228,37 @@ densify_gather_kernel(const DensifyTable tab, long long N, const unsigned char* 
   const long long row0 = base / ru;
   const unsigned rem0 = (unsigned)(base - row0 * ru);
   const float inv = 1.0f / (float)ru;
+  // loads first (row codes; then source words and target indices, unconditional from clamped indices), stores last: one
+  // loop with the loads under `if (code & ...)` serialises three dependent round trips to memory per word
+  long long rowv[DG_WORDS_PER_THREAD];
+  unsigned colv[DG_WORDS_PER_THREAD], cv[DG_WORDS_PER_THREAD];
 #pragma unroll
   for (int k = 0; k < DG_WORDS_PER_THREAD; ++k) {
-    const unsigned off = threadIdx.x + k * DN_NT;
-    const long long w = base + off;
-    if (w < words) {
-      const unsigned x = rem0 + off;
-      unsigned q = (unsigned)((float)x * inv);
-      if (q * ru > x) --q; else if ((q + 1) * ru <= x) ++q;
-      const long long row = row0 + q;
-      const unsigned col = x - q * ru;
-      const unsigned c = code[row];
-      if (c & (DN_KEEP_ORIG | DN_KEEP_CLONE | DN_KEEP_CHILD)) {
-        const uint32_t val = src[w];
-        const uint32_t nv = zero_new ? 0u : val;
-        const unsigned* ix = idx + 4 * row;
-        if (c & DN_KEEP_ORIG) dst[(long long)ix[0] * ru + col] = val;
-        if (c & DN_KEEP_CLONE) dst[(long long)(n_orig + ix[1]) * ru + col] = nv;
-        if (c & DN_KEEP_CHILD) {
-          dst[(long long)(n_orig + n_clone + ix[2]) * ru + col] = nv;
-          dst[(long long)(n_orig + n_clone + n_child + ix[2]) * ru + col] = nv;
-        }
+    const unsigned x = rem0 + threadIdx.x + k * DN_NT;
+    unsigned q = (unsigned)((float)x * inv);
+    if (q * ru > x) --q; else if ((q + 1) * ru <= x) ++q;
+    rowv[k] = min(row0 + (long long)q, N - 1);
+    colv[k] = x - q * ru;
+    cv[k] = code[rowv[k]];
+  }
+  uint32_t val[DG_WORDS_PER_THREAD];
+  uint4 ixv[DG_WORDS_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < DG_WORDS_PER_THREAD; ++k) {
+    val[k] = src[min(base + (long long)(threadIdx.x + k * DN_NT), words - 1)];
+    ixv[k] = *reinterpret_cast<const uint4*>(idx + 4 * rowv[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < DG_WORDS_PER_THREAD; ++k) {
+    const long long w = base + (long long)(threadIdx.x + k * DN_NT);
+    const unsigned c = cv[k], col = colv[k];
+    if (w < words && (c & (DN_KEEP_ORIG | DN_KEEP_CLONE | DN_KEEP_CHILD))) {
+      const uint32_t nv = zero_new ? 0u : val[k];
+      if (c & DN_KEEP_ORIG) dst[(long long)ixv[k].x * ru + col] = val[k];
+      if (c & DN_KEEP_CLONE) dst[(long long)(n_orig + ixv[k].y) * ru + col] = nv;
+      if (c & DN_KEEP_CHILD) {
+        dst[(long long)(n_orig + n_clone + ixv[k].z) * ru + col] = nv;
+        dst[(long long)(n_orig + n_clone + n_child + ixv[k].z) * ru + col] = nv;
       }
     }
   }

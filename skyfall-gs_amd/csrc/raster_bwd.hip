@@ -646,11 +646,17 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
       const unsigned c1 = min(c0 + PB_CHUNK, w1);
       if (__ballot(small && rb < c1 && re > c0) == 0ull) continue;   // a stretch that belongs to bigger splats only
       const unsigned n4 = (c1 - c0) * DG_F4;
+      // all of the chunk's loads in flight together: unconditional from a clamped index.
+      // (Written as `if (u < n4) stage[u] = dupgrad[..]`, every load got its own exec-masked block with an s_waitcnt
+      // vmcnt(0) behind it: six serialised round trips to memory per chunk -- found by reading the ISA, round 3.)
+      constexpr int NLD = PB_CHUNK * DG_F4 / 64;
+      float4 tmp[NLD];
 #pragma unroll
-      for (int k = 0; k < PB_CHUNK * DG_F4 / 64; ++k) {
-        const unsigned u = k * 64 + lane;
-        if (u < n4) stage[u] = dupgrad[(size_t)c0 * DG_F4 + u];
-      }
+      for (int k = 0; k < NLD; ++k) tmp[k] = dupgrad[(size_t)c0 * DG_F4 + min((unsigned)(k * 64 + lane), n4 - 1u)];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) stage[k * 64 + lane] = tmp[k];   // unconditional too (the stage holds PB_CHUNK records;
+                                                                     // its tail beyond n4 is never read): a predicated
+                                                                     // store lets the compiler sink the load back under it
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (small) {

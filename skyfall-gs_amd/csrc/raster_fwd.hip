@@ -444,11 +444,15 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
   // take the remainder from memory in both passes
   constexpr int FB_R = 12;
   uint4 reg[FB_R];
+  // UNCONDITIONAL loads from a clamped index, the tile mask cleared afterwards: written as `i < n ? slab[i] : 0` every
+  // load sat in its own exec-masked block with an s_waitcnt vmcnt(0) right behind it -- twelve serialised round trips to
+  // memory per workgroup instead of one (found by reading the ISA, round 3)
+  const unsigned last = n ? n - 1u : 0u;
 #pragma unroll
-  for (int k = 0; k < FB_R; ++k) {
-    const unsigned i = tid + 256u * k;
-    reg[k] = i < n ? slab[i] : make_uint4(0u, 0u, 0u, 0u);
-  }
+  for (int k = 0; k < FB_R; ++k) reg[k] = slab[min(tid + 256u * k, last)];
+#pragma unroll
+  for (int k = 0; k < FB_R; ++k)
+    if (tid + 256u * k >= n) reg[k].w = 0u;
 #pragma unroll
   for (int k = 0; k < FB_R; ++k) {
     unsigned m = reg[k].w;
@@ -592,15 +596,16 @@ __device__ __forceinline__ void sort_tile_in_registers(unsigned s, int L, int la
                                                        uint32_t* __restrict__ sorted_dup) {
   unsigned long long key[EPL];
   unsigned pay[EPL];
+  // coalesced (striped) loads, all in flight together: unconditional from a clamped index, padding selected afterwards
+  // (a load under `if (i < L)` gets its own exec-masked block and, every few of them, an s_waitcnt vmcnt(0))
+  uint4 it[EPL];
 #pragma unroll
-  for (int r = 0; r < EPL; ++r) {  // coalesced (striped) load: the network sorts any initial arrangement
-    const int i = r * 64 + lane;
-    key[r] = ~0ull; pay[r] = 0u;
-    if (i < L) {
-      const uint4 it = items[s + i];
-      key[r] = ((unsigned long long)it.y << 32) | it.x;
-      pay[r] = it.z;
-    }
+  for (int r = 0; r < EPL; ++r) it[r] = items[s + min(r * 64 + lane, L - 1)];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) {   // the network sorts any initial arrangement
+    const bool in = r * 64 + lane < L;
+    key[r] = in ? (((unsigned long long)it[r].y << 32) | it[r].x) : ~0ull;
+    pay[r] = in ? it[r].z : 0u;
   }
   wave_bitonic_sort<EPL>(key, pay, lane);
 #pragma unroll
@@ -705,11 +710,11 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
       const int i = tid + NT * r;
+      // unconditional loads from a clamped index (entries beyond L are never used: every later pass tests i < L)
       if constexpr (WIDE) {
-        dreg[r] = i < L ? items[s + i].y : 0u;
+        dreg[r] = items[s + min(i, L - 1)].y;
       } else {
-        uint4 it = make_uint4(0u, 0u, 0u, 0u);
-        if (i < L) it = items[s + i];
+        const uint4 it = items[s + min(i, L - 1)];
         dreg[r] = it.y; idreg[r] = it.x; dupreg[r] = it.z;
       }
     }
