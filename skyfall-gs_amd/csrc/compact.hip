@@ -35,8 +35,11 @@ compact_count_kernel(const unsigned char* __restrict__ keep, long long N, unsign
   __shared__ unsigned smem[CP_NT / 64 + 1];
   const long long base = (long long)blockIdx.x * CP_CHUNK + (long long)threadIdx.x * CP_ROWS_PER_THREAD;
   unsigned c = 0;
+  unsigned char kv[CP_ROWS_PER_THREAD];
 #pragma unroll
-  for (int k = 0; k < CP_ROWS_PER_THREAD; ++k) c += (base + k < N && keep[base + k]) ? 1u : 0u;
+  for (int k = 0; k < CP_ROWS_PER_THREAD; ++k) kv[k] = keep[min(base + k, N - 1)];   // loads first (see compact_gather)
+#pragma unroll
+  for (int k = 0; k < CP_ROWS_PER_THREAD; ++k) c += (base + k < N && kv[k]) ? 1u : 0u;
   unsigned total;
   block_excl_scan_u32<CP_NT>(c, &total, smem);
   if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
@@ -63,9 +66,12 @@ compact_index_kernel(const unsigned char* __restrict__ keep, long long N, const 
   __shared__ unsigned smem[CP_NT / 64 + 1];
   const long long base = (long long)blockIdx.x * CP_CHUNK + (long long)threadIdx.x * CP_ROWS_PER_THREAD;
   unsigned flags = 0, c = 0;
+  unsigned char kv[CP_ROWS_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < CP_ROWS_PER_THREAD; ++k) kv[k] = keep[min(base + k, N - 1)];
 #pragma unroll
   for (int k = 0; k < CP_ROWS_PER_THREAD; ++k)
-    if (base + k < N && keep[base + k]) { flags |= 1u << k; ++c; }
+    if (base + k < N && kv[k]) { flags |= 1u << k; ++c; }
   unsigned total;
   unsigned pos = block_sum[blockIdx.x] + block_excl_scan_u32<CP_NT>(c, &total, smem);
 #pragma unroll

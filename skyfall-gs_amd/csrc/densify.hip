@@ -57,13 +57,16 @@ select_hist_kernel(const float* __restrict__ v, long long N, SelectState* st) {
   __syncthreads();
   const unsigned prefix = st->prefix, mask = st->mask;
   const long long base = (long long)blockIdx.x * SEL_CHUNK;
-#pragma unroll 4
+  // loads first, all in flight (unconditional, clamped index), then the histogram: a load under `if (i < N)` gets an
+  // exec-masked block of its own with s_waitcnt vmcnt(0) behind it
+  unsigned bv[SEL_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < SEL_PER_THREAD; ++k)
+    bv[k] = __float_as_uint(v[min(base + (long long)k * SEL_NT + threadIdx.x, N - 1)]);
+#pragma unroll
   for (int k = 0; k < SEL_PER_THREAD; ++k) {
     const long long i = base + (long long)k * SEL_NT + threadIdx.x;
-    if (i < N) {
-      const unsigned b = __float_as_uint(v[i]);
-      if ((b & mask) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
-    }
+    if (i < N && (bv[k] & mask) == prefix) atomicAdd(&h[(bv[k] >> SHIFT) & ((1u << BITS) - 1u)], 1u);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < (1 << BITS); i += SEL_NT)
@@ -99,10 +102,13 @@ select_successor_kernel(const float* __restrict__ v, long long N, SelectState* s
   const unsigned a = st->prefix;
   unsigned best = 0xffffffffu;
   const long long base = (long long)blockIdx.x * SEL_CHUNK;
-  for (int k = 0; k < SEL_PER_THREAD; ++k) {
-    const long long i = base + (long long)k * SEL_NT + threadIdx.x;
-    if (i < N) { const unsigned b = __float_as_uint(v[i]); if (b > a && b < best) best = b; }
-  }
+  unsigned bv[SEL_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < SEL_PER_THREAD; ++k)   // (a clamped index repeats the last element: harmless for a minimum)
+    bv[k] = __float_as_uint(v[min(base + (long long)k * SEL_NT + threadIdx.x, N - 1)]);
+#pragma unroll
+  for (int k = 0; k < SEL_PER_THREAD; ++k)
+    if (bv[k] > a && bv[k] < best) best = bv[k];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, d));
   if (lane_id() == 0 && best != 0xffffffffu) atomicMin(&st->succ, best);
