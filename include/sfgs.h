@@ -166,8 +166,10 @@ const char* sfgs_profile_kernel_name(int32_t id);
 int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);
 
 /* Blob sizes for N Gaussians, a W x H image, a list-slot capacity D (bins, image, dupgrad) and a per-coarse-bin
- * item capacity (bins). Every 8x8 tile's list starts on a multiple of 64 slots, so a frame with num_duplicates
- * (Gaussian, tile) pairs needs D >= sfgs_raster_slot_capacity(W, H, num_duplicates) = num_duplicates + 64 * tiles. */
+ * item capacity (bins). Every 8x8 tile's list starts on a multiple of 64 slots and every 32x32-pixel coarse bin's lists
+ * are placed from the bin's tile-hit total (an upper bound, scanned by the plan: no allocator), so a frame with
+ * num_duplicates (Gaussian, tile) pairs needs D >= sfgs_raster_slot_capacity(W, H, num_duplicates) = num_duplicates +
+ * 1088 * coarse bins (index space only: unused slots are never touched). */
 int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse_capacity,
                       SfgsRasterSizes* out);
 int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates);

@@ -262,8 +262,21 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       const int h = 63 - __clzll(heads & le);                      // first lane of this lane's run
       const unsigned long long above = heads & ~le;
       const int next = above ? __ffsll((long long)above) - 1 : 64;  // first lane of the next run
+      // the counter is 64 bits wide: items appended in the low word (the returned value is the run's first rank), the
+      // TILE hits of those items in the high word -- plan_scan turns the per-bin hit totals into list-slot bases, so that
+      // fine_bin needs no allocator (2 040 returning atomics on one word were a third of its time)
+      const unsigned pc = m ? (unsigned)__popc(m) : 0u;
+      unsigned run_hits = pc;                      // every lane its own run (a shuffled scene): no scan needed
+      if (heads != ~0ull) {                        // wave-uniform
+        const unsigned pincl = wave_incl_scan_u32(pc);
+        run_hits = (unsigned)__shfl((int)pincl, next - 1) - (pincl - pc);   // meaningful in lane h
+      }
       unsigned rank0 = 0;
-      if (m && h == lane) rank0 = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], (unsigned)(next - h));
+      // (the 64-bit atomic costs preprocess ~5 us on the shuffled headline scene -- 14 + 18 bits packed into a 32-bit
+      // one ~3 us, not worth a capacity-dependent format -- against 20 us of allocator queueing removed from fine_bin)
+      if (m && h == lane)
+        rank0 = (unsigned)atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)cb * CC_STRIDE]),
+                                    (unsigned long long)(unsigned)(next - h) | ((unsigned long long)run_hits << 32));
       rank0 = (unsigned)__shfl((int)rank0, h);
       if (m) {
         const unsigned rank = rank0 + (unsigned)(lane - h);
@@ -287,7 +300,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       const unsigned m = (unsigned)(bal >> (16 * q)) & 0xffffu;
       if ((lane & 15) == 0 && m) {  // the first lane of each 16-lane group appends its coarse bin's item
         const unsigned before = (unsigned)__popcll(bal & ((1ull << (16 * q)) - 1ull));
-        const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+        const unsigned rank = (unsigned)atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)cb * CC_STRIDE]),
+                                                  1ull | ((unsigned long long)(unsigned)__popc(m) << 32));
         if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + before, m);
         else hdr[HDR_OVERFLOW] = 1ull;
       }
@@ -376,7 +390,8 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
       const unsigned c = (unsigned)__popc(m);
       const unsigned incl = wave_incl_scan_u32(c);
       if (m) {
-        const unsigned rank = atomicAdd(&coarse_count[(size_t)cb * CC_STRIDE], 1u);
+        const unsigned rank = (unsigned)atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)cb * CC_STRIDE]),
+                                                  1ull | ((unsigned long long)c << 32));
         if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g, depth_bits, dup + incl - c, m);
         else hdr[HDR_OVERFLOW] = 1ull;
       }
@@ -385,13 +400,47 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
   }
 }
 
+// List-slot bases of the coarse bins (one workgroup, any thread count that is a multiple of 64 up to 1024): bin cb's
+// tiles will need at most hits(cb) + 16 x 63 slots (every list starts on a multiple of 64), rounded up to 64; the
+// exclusive scan over the bins goes into word 2 of the bin's counter line, the total into the header. Replaces a device
+// atomic per bin on ONE allocator word in fine_bin (2 040 returning atomics at ~10 ns: 20 of its 61 us).
+__device__ __forceinline__ unsigned bin_slots_needed(unsigned hits) {
+  return hits ? ((hits + COARSE_TILES * (LIST_ALIGN - 1) + LIST_ALIGN - 1) & ~(unsigned)(LIST_ALIGN - 1)) : 0u;
+}
+__device__ void bin_base_scan(int NCB, uint32_t* __restrict__ coarse_count, unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned long long bb_wave[17];
+  const int nt = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+  unsigned long long carry = 0;
+  for (int c0 = 0; c0 < NCB; c0 += nt) {
+    const int cb = c0 + threadIdx.x;
+    const unsigned need = cb < NCB ? bin_slots_needed(coarse_count[(size_t)cb * CC_STRIDE + 1]) : 0u;
+    unsigned long long incl = need;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) bb_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long before = carry, all = 0;
+    for (int w = 0; w < nw; ++w) { const unsigned long long t = bb_wave[w]; if (w < wave) before += t; all += t; }
+    if (cb < NCB) coarse_count[(size_t)cb * CC_STRIDE + 2] = (unsigned)min(before + incl - need, 0xffffffffull);
+    carry += all;
+  }
+  if (threadIdx.x == 0) hdr[HDR_ITEM_ALLOC] = carry;
+}
+
+__global__ void __launch_bounds__(1024) bin_base_scan_kernel(int NCB, uint32_t* __restrict__ coarse_count,
+                                                            unsigned long long* __restrict__ hdr) {
+  bin_base_scan(NCB, coarse_count, hdr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: single workgroup: counters for the host (visible count, reference duplicate total, fullest coarse bin).
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
-plan_scan_kernel(int NCB, int NB, const uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
+plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                  const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
                  const unsigned long long* __restrict__ feedback, unsigned long long* __restrict__ host_out) {
+  if (blockIdx.x == 1) { bin_base_scan(NCB, coarse_count, hdr); return; }   // second workgroup, concurrently
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
   unsigned long long nvis = 0, dref = 0, cmax = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
@@ -482,9 +531,11 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
     const unsigned total = __shfl(incl, COARSE_TILES - 1);
     unsigned long long base = 0;
     if (tid == 0) {
-      if (total) base = atomicAdd(&hdr[HDR_ITEM_ALLOC], (unsigned long long)total);
-      // memory safety when the caller's slot capacity is too small (the wrapper sizes it as D + 64 T8, which always
-      // suffices): the bin's lists are dropped and the frame is flagged
+      // the bin's first list slot: scanned by the plan from the bins' tile-hit totals (an upper bound of what the bin's
+      // lists take: `total` <= hits + 16 x 63), no allocator atomic
+      base = coarse_count[(size_t)cb * CC_STRIDE + 2];
+      // memory safety when the caller's slot capacity is too small (the wrapper sizes it with
+      // sfgs_raster_slot_capacity, which always suffices): the bin's lists are dropped and the frame is flagged
       if (base + total > slot_capacity) { hdr[HDR_OVERFLOW] = 1ull; base = ~0ull; }
       s_base = base;
     }
@@ -498,7 +549,12 @@ fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ 
         if (c > REG_SORT_SMALL && !dropped) long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)(ty * TX8 + tx);  // rare
       }
       cnt[tid] = off;  // becomes the per-tile cursor
-      if (c) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], c);
+    }
+    {  // longest list of the bin: ONE atomic per workgroup (16 same-address atomics per bin serialise in the L2)
+      unsigned cm = tid < COARSE_TILES ? c : 0u;
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) cm = max(cm, (unsigned)__shfl_xor((int)cm, d));
+      if (tid == 0 && cm) atomicMax((unsigned int*)&hdr[HDR_MAX_LIST], cm);
     }
   }
   __syncthreads();
@@ -1168,7 +1224,8 @@ extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int
 
 extern "C" int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates) {
   if (W <= 0 || H <= 0 || num_duplicates < 0) return -1;
-  return num_duplicates + (int64_t)LIST_ALIGN * tiles8(W, H);
+  // every coarse bin's lists take at most its tile hits + 16 x 63 alignment slots, rounded up to 64 (bin_slots_needed)
+  return num_duplicates + (int64_t)(COARSE_TILES * (LIST_ALIGN - 1) + 2 * LIST_ALIGN - 1) / LIST_ALIGN * LIST_ALIGN * coarse_bins(W, H);
 }
 
 extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* geom,
@@ -1222,7 +1279,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
                        tv.block_dref, tv.hdr,
                        (const unsigned long long*)frame->feedback,
                        (unsigned long long*)counters_pinned_host); }
@@ -1271,8 +1328,9 @@ plan_merge_rec_kernel(MergeParts mp, float4* __restrict__ rec) {
 __global__ void __launch_bounds__(256)
 plan_merge_items_kernel(MergeParts mp, unsigned export_capacity, unsigned coarse_capacity,
                         uint32_t* __restrict__ coarse_count, uint4* __restrict__ slabs, unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_hits[4];
   const size_t cb = blockIdx.x;
-  unsigned off = 0;
+  unsigned off = 0, hits = 0;
   for (int p = 0; p < mp.parts; ++p) {
     const unsigned n = min(mp.count[p][cb], export_capacity);
     for (unsigned k = threadIdx.x; k < n; k += 256) {
@@ -1280,11 +1338,17 @@ plan_merge_items_kernel(MergeParts mp, unsigned export_capacity, unsigned coarse
       it.x += mp.base[p];
       it.z = 0u;            // duplicate indices belong to the backward: a merged plan is rendered, not differentiated
       if (off + k < coarse_capacity) slabs[cb * coarse_capacity + off + k] = it;
+      hits += (unsigned)__popc(it.w);
     }
     off += n;
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) hits += (unsigned)__shfl_xor((int)hits, d);
+  if ((threadIdx.x & 63) == 0) s_hits[threadIdx.x >> 6] = hits;
+  __syncthreads();
   if (threadIdx.x == 0) {
     coarse_count[cb * CC_STRIDE] = off;
+    coarse_count[cb * CC_STRIDE + 1] = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];   // tile hits: list-slot need
     if (off > coarse_capacity) hdr[HDR_OVERFLOW] = 1ull;
   }
 }
@@ -1351,6 +1415,7 @@ extern "C" int sfgs_raster_plan_merge(const SfgsFrame* frame, int32_t parts, con
   if (N > 0) hipLaunchKernelGGL(plan_merge_rec_kernel, dim3(2048), dim3(256), 0, stream, mp, gv.rec);
   hipLaunchKernelGGL(plan_merge_items_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, mp, (unsigned)export_capacity,
                      (unsigned)coarse_capacity, tv.coarse_count, bv.slabs, tv.hdr);
+  hipLaunchKernelGGL(bin_base_scan_kernel, dim3(1), dim3(1024), 0, stream, (int)NCB, tv.coarse_count, tv.hdr);
   SFGS_POST_LAUNCH("plan_merge", stream, frame->debug);
   return SFGS_OK;
 }

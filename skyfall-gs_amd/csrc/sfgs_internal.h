@@ -112,7 +112,7 @@ enum HeaderSlot {
   HDR_MAX_LIST = 3,   // longest per-tile list
   HDR_OVERFLOW = 4,   // set by preprocess when dup_capacity / coarse_capacity is too small (redo the plan)
   HDR_SUBPIX_BOUND = 5,  // float bits of max |subpixel_offset| (0 when none)
-  HDR_ITEM_ALLOC = 6,    // list-slot allocator of the fine-binning kernel
+  HDR_ITEM_ALLOC = 6,    // list slots the coarse bins' lists can take at most (total of the plan's per-bin bases)
   HDR_MAX_COARSE = 7,    // fullest coarse bin (sizes coarse_capacity for the next frame)
   HDR_LONG_COUNT = 8,    // tiles whose list is too long for the register sort (> 512 entries)
   HDR_BIG_CHUNKS = 9,    // entries of BinsView::big_chunks (1024-record chunks of Gaussians with > BWD_BIG duplicates)
@@ -156,8 +156,9 @@ constexpr int CC_STRIDE = 32;       // coarse counters live 128 bytes apart: ato
 
 struct TilesView {
   unsigned long long* hdr;  // [HDR_WORDS]
-  uint32_t* coarse_count;   // [NCB * CC_STRIDE] items appended to every coarse bin, one counter per 128 bytes
-                            //                   (zeroed by plan; keeps counting past capacity)
+  uint32_t* coarse_count;   // [NCB * CC_STRIDE] one 128-byte line per coarse bin: word 0 = items appended (keeps counting
+                            //   past capacity), word 1 = tile hits of those items (words 0-1 are ONE 64-bit atomic
+                            //   counter), word 2 = the bin's first list slot (scanned by the plan from the hits)
   uint2* tile_range;        // [T8] (first list slot, list length) of every 8x8 tile
   uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]

@@ -1,0 +1,9 @@
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r3q; mkdir -p $O
+E=skyfall-gs_amd/sfgs/_exp
+( timeout 1200 python -m pytest tests/test_gpu_raster.py tests/test_gpu_joint_render.py tests/test_gpu_launch_hints.py tests/test_gpu_fullsize_parity.py -m gpu -q -x 2>&1 | tail -6 ) > $O/all.log 2>&1; tail -6 $O/all.log
+for r in 1 2 3; do for v in amax scanalloc2; do SFGS_LIB=$PWD/$E/lib_$v.so timeout 200 python bench.py --forward-only --cpu-sample 0 --steps 100 --warmup 30 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$v fwd-only', round(d['ms_per_step'],4), round(d['value'],1), {k: round(v,4) for k,v in d['roofline_step']['kernel_ms_per_step'].items()})"; done; done | tee $O/ab.log
+( bash tools/ab.sh $E/lib_amax.so $E/lib_scanalloc2.so -- --steps 60 --warmup 20 ) | tee -a $O/ab.log
