@@ -214,8 +214,9 @@ int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* ge
 
 /* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
  * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same capacities, image)
- * and radii unchanged. `dupgrad` is scratch: 48 bytes for each of the num_duplicates (Gaussian, tile) pairs the
- * plan counted (sfgs_raster_sizes(N, W, H, num_duplicates, ..).dupgrad_bytes). Every gradient tensor in `grads` is
+ * and radii unchanged. `dupgrad` is scratch: 48 bytes for each duplicate INDEX of the plan -- the indices are handed out
+ * from 8 disjoint ranges of [0, dup_capacity), so it spans the capacity, not the count
+ * (sfgs_raster_sizes(N, W, H, dup_capacity, ..).dupgrad_bytes; the gaps are never touched). Every gradient tensor in `grads` is
  * fully overwritten. Deterministic (no float atomics). Asynchronous. Writes one word of the `tiles` header (whether
  * this frame's dead list entries were zero-filled in bulk; decided per frame on the device, environment variable
  * SFGS_PREFILL=always|never forces either path for tests: the gradients are bit-identical). */

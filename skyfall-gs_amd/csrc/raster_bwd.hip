@@ -501,7 +501,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 __global__ void __launch_bounds__(256)
 dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned long long n_dup, int mode,
                        float4* __restrict__ dupgrad, unsigned long long* __restrict__ hdr,
-                       unsigned long long* __restrict__ feedback) {
+                       unsigned long long* __restrict__ feedback, const unsigned long long* __restrict__ dup_pool,
+                       unsigned long long dup_capacity, unsigned npools) {
   __shared__ unsigned part[4];
   // every workgroup sums the per-tile counts for itself (2 bytes per tile, 16-byte loads: 64 KB from L2 at 1080p)
   unsigned dead = 0;   // <= 65535 * T8 < 2^32 up to 65 k tiles... accumulate in 64 bits across lanes below
@@ -529,8 +530,12 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
   }
   if (!fill) return;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const size_t n4 = (size_t)n_dup * DG_F4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dupgrad[i] = zero4;
+  const unsigned long long R = dup_capacity / npools;   // the used part of every pool's index range (sfgs_internal.h)
+  for (unsigned q = 0; q < npools; ++q) {
+    const size_t n4 = (size_t)min(dup_pool[q * DP_STRIDE], R) * DG_F4;
+    float4* dst = dupgrad + (size_t)q * R * DG_F4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = zero4;
+  }
 }
 
 // Parallel pre-reduction of the records of Gaussians with more than BWD_BIG duplicates (sfgs_internal.h): one
@@ -762,8 +767,9 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
   SFGS_REQUIRE(dup_capacity >= 0 && num_duplicates >= 0 && num_duplicates <= dup_capacity, SFGS_E_ARG,
                "bad dup_capacity / num_duplicates");
-  SFGS_REQUIRE(dupgrad_sz >= dupgrad_bytes(num_duplicates), SFGS_E_CAPACITY,
-               "dupgrad blob: %zu bytes given, %zu needed", dupgrad_sz, dupgrad_bytes(num_duplicates));
+  // duplicate indices come from DUP_POOLS ranges of [0, dup_capacity): the record array spans the whole index space
+  SFGS_REQUIRE(num_duplicates == 0 || dupgrad_sz >= dupgrad_bytes(dup_capacity), SFGS_E_CAPACITY,
+               "dupgrad blob: %zu bytes given, %zu needed", dupgrad_sz, dupgrad_bytes(dup_capacity));
   SFGS_REQUIRE(num_duplicates == 0 || (bins && dupgrad), SFGS_E_ARG, "bins / dupgrad is NULL");
   const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
@@ -777,7 +783,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
     if (!(frame->launch_hints & SFGS_HINT_NO_PREFILL))
     hipLaunchKernelGGL(dupgrad_prefill_kernel, dim3(512), dim3(256), 0, stream, TX8 * TY8, iv.tile_dead,
                        (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
-                       (unsigned long long*)frame->feedback);
+                       (unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
+                       (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
                        bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
                        dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr); }

@@ -124,7 +124,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
-                  uint4* __restrict__ big_list, unsigned long long* __restrict__ hdr) {
+                  uint4* __restrict__ big_list, unsigned long long* __restrict__ hdr,
+                  unsigned long long* __restrict__ dup_pool) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
   __shared__ unsigned long long s_base;
   const FrameParams f = load_frame(kf);
@@ -234,10 +235,15 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   // reserve duplicate indices: block scan + one returning atomic per block
   unsigned total;
   const unsigned ex = block_excl_scan_u32<PRE_BLOCK>(n_dup, &total, s_red);
-  if (threadIdx.x == 0) s_base = total ? atomicAdd(&hdr[HDR_D_EFF], (unsigned long long)total) : 0ull;
+  __shared__ int s_fits;
+  if (threadIdx.x == 0) {
+    bool ok = true;
+    s_base = total ? dup_alloc(dup_pool, dup_pools_used(gridDim.x), blockIdx.x, total, dup_capacity, &ok) : 0ull;
+    s_fits = ok;
+  }
   __syncthreads();
   const unsigned long long base = s_base;
-  const bool fits = base + total <= dup_capacity;
+  const bool fits = s_fits != 0;
   if (!fits && threadIdx.x == 0) hdr[HDR_OVERFLOW] = 1ull;
   if (g < N && !huge) dup_out[g] = make_uint2((unsigned)(base + ex), n_dup);
   {
@@ -325,7 +331,8 @@ __global__ void __launch_bounds__(256)
 big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __restrict__ rec,
                 uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count, uint4* __restrict__ slabs,
                 unsigned coarse_capacity, unsigned long long dup_capacity, uint2* __restrict__ big_chunks,
-                unsigned big_chunk_cap, unsigned long long* __restrict__ hdr) {
+                unsigned big_chunk_cap, unsigned long long* __restrict__ hdr, unsigned long long* __restrict__ dup_pool,
+                unsigned npools) {
   const unsigned n_big = (unsigned)hdr[HDR_BIG_COUNT];
   const int lane = threadIdx.x & 63;
   const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
@@ -356,10 +363,11 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
     }
     // reserve the duplicate indices
     unsigned long long base = 0ull;
-    if (lane == 0 && total) base = atomicAdd(&hdr[HDR_D_EFF], (unsigned long long)total);
+    bool ok = true;
+    if (lane == 0 && total) base = dup_alloc(dup_pool, npools, i, total, dup_capacity, &ok);
     base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
-    const bool fits = base + total <= dup_capacity;
+    const bool fits = __builtin_amdgcn_readfirstlane((int)ok) != 0;
     if (lane == 0) {
       dup_out[g] = make_uint2((unsigned)base, total);
       if (!fits) hdr[HDR_OVERFLOW] = 1ull;
@@ -439,7 +447,8 @@ constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
 plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                  const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
-                 const unsigned long long* __restrict__ feedback, unsigned long long* __restrict__ host_out) {
+                 const unsigned long long* __restrict__ feedback, const unsigned long long* __restrict__ dup_pool,
+                 unsigned long long* __restrict__ host_out) {
   if (blockIdx.x == 1) { bin_base_scan(NCB, coarse_count, hdr); return; }   // second workgroup, concurrently
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
   unsigned long long nvis = 0, dref = 0, cmax = 0;
@@ -461,6 +470,12 @@ plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uin
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) {   // duplicates of the frame = what the pools handed out
+    unsigned long long d = 0;
+    for (int q = 0; q < DUP_POOLS; ++q) d += dup_pool[q * DP_STRIDE];
+    hdr[HDR_D_EFF] = d;
+  }
+  __syncthreads();
   // publish the first 8 header words straight into the caller's pinned host buffer (fine-grained memory: visible
   // to the host once this kernel has completed) -- the host can then decide about a capacity retry while the render
   // stage is already running, without a copy engine round trip in the middle of the stream
@@ -1217,7 +1232,7 @@ extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int
   out->tiles_bytes = tb;
   out->bins_bytes = bins_bytes(D, coarse_bins(W, H), coarse_capacity);
   out->image_bytes = image_bytes(W, H, D);
-  out->dupgrad_bytes = dupgrad_bytes(D);
+  out->dupgrad_bytes = dupgrad_bytes(D);   // D = the duplicate capacity the frame was planned with (sparse index space)
   out->coarse_bins = coarse_bins(W, H);
   return SFGS_OK;
 }
@@ -1266,7 +1281,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   hipLaunchKernelGGL((preprocess_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,    \
                      g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,   \
                      bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,            \
-                     tv.block_dref, gv.big_list, tv.hdr)
+                     tv.block_dref, gv.big_list, tv.hdr, tv.dup_pool)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
       // the big splats' walk: persistent waves over the work list (returns at once when the list is empty; not launched
@@ -1274,14 +1289,15 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
       if (!(frame->launch_hints & SFGS_HINT_NO_HUGE_SPLATS))
       hipLaunchKernelGGL(big_walk_kernel, dim3(BIG_WALK_BLOCKS), dim3(256), 0, stream, kf, gv.big_list, gv.rec, gv.dup,
                          tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity,
-                         bv.big_chunks, (unsigned)big_chunk_capacity(dup_capacity), tv.hdr);
+                         bv.big_chunks, (unsigned)big_chunk_capacity(dup_capacity), tv.hdr, tv.dup_pool,
+                         dup_pools_used(NB));
     }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
                        tv.block_dref, tv.hdr,
-                       (const unsigned long long*)frame->feedback,
+                       (const unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
                        (unsigned long long*)counters_pinned_host); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;

@@ -103,6 +103,7 @@ __device__ __forceinline__ FrameParams load_frame(const KFrame& k) {
 constexpr int PRE_BLOCK = 256;      // threads per block of the per-Gaussian kernels
 // SfgsFrame.feedback: 8 uint64 words of caller-owned persistent device memory (late statistics of the previous frame)
 enum { FB_VALID = 0, FB_LONG_TILES = 1, FB_MAX_LIST = 2, FB_PREFILLED = 3 };
+// reserve `total` duplicate indices from pool `pool`; *fits = the pool still had room
 constexpr int HDR_WORDS = 64;       // uint64 words at the head of the tiles blob
 
 enum HeaderSlot {
@@ -154,8 +155,17 @@ constexpr int COARSE_TILES = COARSE * COARSE;
 constexpr int CC_STRIDE = 32;       // coarse counters live 128 bytes apart: atomics on one cache line serialise
                                     // (~12 ns each), and a dense array would put 16-32 hot counters on one line
 
+// Duplicate indices are handed out from DUP_POOLS independent ranges of the index space [0, dup_capacity): pool p owns
+// [p R, (p + 1) R), R = dup_capacity / DUP_POOLS, with its own counter on its own cache line. ONE allocator word took a
+// returning atomic per preprocess workgroup (7 813 at 2 M Gaussians) that queue at ~10 ns each in the memory-side atomic
+// unit: 15 of the kernel's ~210 us. Workgroup b draws from pool b % DUP_POOLS (= its XCD), so the pools fill evenly; a pool
+// that runs over sets the overflow flag like any other capacity. The index space is sparse (gaps between the pools):
+// everything indexed by duplicate index is sized by dup_capacity.
+constexpr int DUP_POOLS = 8, DP_STRIDE = 16;   // counters 128 bytes apart
+
 struct TilesView {
   unsigned long long* hdr;  // [HDR_WORDS]
+  unsigned long long* dup_pool;   // [DUP_POOLS * DP_STRIDE] duplicate indices handed out per pool
   uint32_t* coarse_count;   // [NCB * CC_STRIDE] one 128-byte line per coarse bin: word 0 = items appended (keeps counting
                             //   past capacity), word 1 = tile hits of those items (words 0-1 are ONE 64-bit atomic
                             //   counter), word 2 = the bin's first list slot (scanned by the plan from the hits)
@@ -178,6 +188,7 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   char* p = (char*)base;
   size_t off = 0;
   t.hdr = (unsigned long long*)(p + off); off += HDR_WORDS * 8;
+  t.dup_pool = (unsigned long long*)(p + off); off += align_up((size_t)DUP_POOLS * DP_STRIDE * 8, 256);
   t.coarse_count = (uint32_t*)(p + off); off += align_up((size_t)NCB * CC_STRIDE * 4, 256);
   t.zero_bytes = off;
   t.tile_range = (uint2*)(p + off); off += align_up((size_t)T8 * 8, 256);
@@ -258,6 +269,19 @@ __host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned
 constexpr int DG_F4 = SFGS_DUPGRAD_F4;
 constexpr int DUPGRAD_FLOATS = 4 * DG_F4;
 static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
+
+// pools in use for a frame of NB preprocess workgroups: small frames (few workgroups: their totals would not spread evenly
+// over the pools) draw from one pool that owns the whole index space
+__host__ __device__ inline unsigned dup_pools_used(long long NB) { return NB >= 512 ? (unsigned)DUP_POOLS : 1u; }
+__device__ __forceinline__ unsigned long long dup_alloc(unsigned long long* __restrict__ dup_pool, unsigned npools,
+                                                        unsigned chooser, unsigned total,
+                                                        unsigned long long dup_capacity, bool* fits) {
+  const unsigned pool = chooser % npools;
+  const unsigned long long R = dup_capacity / npools;
+  const unsigned long long old = atomicAdd(&dup_pool[pool * DP_STRIDE], (unsigned long long)total);
+  *fits = old + total <= R;
+  return pool * R + old;
+}
 
 // ---- XCD-aware block remap (bijective; guide T1) -------------------------------------------------
 // Hardware places workgroup b on XCD b % 8; give every XCD a contiguous range of logical blocks so

@@ -225,6 +225,7 @@ class _Rasterize(torch.autograd.Function):
             if hs is not None:
                 fwd_hints = (HINT_NO_HUGE_SPLATS if hs["huge"] == 0 else 0) | (HINT_FEW_LONG_LISTS if hs["long"] == 0 else 0)
             feedback = hs["fb"] if hs is not None else None
+            tries, pool_grown = 0, False
             while True:
                 L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
                 o_tiles = al(max(sizes.geom_bytes, 1))
@@ -271,8 +272,17 @@ class _Rasterize(torch.autograd.Function):
                     continue
                 if not cnt.overflow and slots(D) <= cap and cmax <= ccap:
                     break
-                cap = max(cap, slots(int(D * 1.25) + 1024))
-                ccap = max(ccap, int(cmax * 1.25) + 256)
+                tries += 1
+                if tries > 24:
+                    raise RuntimeError(f"rasterizer plan still overflows after {tries} attempts (duplicates {D}, capacity "
+                                       f"{cap}, fullest coarse bin {cmax} of {ccap})")
+                new_cap, new_ccap = max(cap, slots(int(D * 1.25) + 1024)), max(ccap, int(cmax * 1.25) + 256)
+                if (new_cap, new_ccap) == (cap, ccap):
+                    # the totals fit, yet a plan overflowed: one of the duplicate-index pools ran over (a few workgroups
+                    # own most of the frame's duplicates): give every pool twice the room
+                    new_cap = cap * 2
+                    pool_grown = True
+                cap, ccap = new_cap, new_ccap
             if hs is not None:
                 if cnt.prev_valid:   # the previous frame's render / backward stages, as this frame's plan found them
                     hs["long"] = int(cnt.prev_long_tiles)
@@ -280,8 +290,9 @@ class _Rasterize(torch.autograd.Function):
                         hs["prefilled"] = int(cnt.prev_prefilled)
                 hs["huge"] = int(cnt.num_huge_splats)
                 hs["prefill_ran"] = False
-            _cap_hint[(dev.index, W, H)] = (max(slots(int(D * 1.25) + 1024), min(cap, slots(2 * D + 1024))),
-                                    max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
+            _cap_hint[(dev.index, W, H)] = (cap if pool_grown else
+                                            max(slots(int(D * 1.25) + 1024), min(cap, slots(2 * D + 1024))),
+                                            max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
             global _last_counters
             _last_counters = dict(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
                                   num_visible=int(cnt.num_visible), max_coarse_bin=cmax,
@@ -347,8 +358,10 @@ class _Rasterize(torch.autograd.Function):
             g_shs = take(3 * K, (N, K, 3)) if ctx.has_shs else None
             grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
                                         L.ptr(g_scales), L.ptr(g_rot), L.ptr(g_opac), L.ptr(g_col), L.ptr(g_shs))
-            dupgrad = torch.empty(max((ctx.ndup * _dupgrad_record_bytes(lib) + 255) // 256 * 256, 1), dtype=torch.uint8,
-                                  device=dev)
+            # one record per duplicate INDEX: the indices come from 8 disjoint ranges of [0, capacity) (no single allocator
+            # word), so the array spans the capacity the frame was planned with; the gaps are never touched
+            dupgrad = torch.empty(max((D * _dupgrad_record_bytes(lib) + 255) // 256 * 256, 1) if ctx.ndup else 1,
+                                  dtype=torch.uint8, device=dev)
             gc = None if g_color is None else g_color.contiguous().float()
             gd = None if g_depth is None else g_depth.contiguous().float()
             ga = None if g_alpha is None else g_alpha.contiguous().float()

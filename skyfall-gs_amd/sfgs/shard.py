@@ -356,8 +356,11 @@ def plan_export(settings, inputs, export_capacity=None):
             D, cmax = int(cnt.num_duplicates), int(cnt.max_coarse_bin)
             if not cnt.overflow and int(lib.sfgs_raster_slot_capacity(W, H, D)) <= cap and cmax <= ccap:
                 break
-            cap = max(cap, int(lib.sfgs_raster_slot_capacity(W, H, int(D * 1.25) + 1024)))
-            ccap = max(ccap, int(cmax * 1.25) + 256)
+            new_cap = max(cap, int(lib.sfgs_raster_slot_capacity(W, H, int(D * 1.25) + 1024)))
+            new_ccap = max(ccap, int(cmax * 1.25) + 256)
+            if (new_cap, new_ccap) == (cap, ccap):
+                new_cap = cap * 2        # a duplicate-index pool ran over although the total fits: more room per pool
+            cap, ccap = new_cap, new_ccap
         if export_capacity is None:
             export_capacity = _agree_max(max(cmax, 1), dev)
         C = int(export_capacity)

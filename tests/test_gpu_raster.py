@@ -323,3 +323,27 @@ def test_storage_order_is_a_relabelling():
     for k in a["grads"]:
         ga, gb = a["grads"][k][perm.numpy()], b["grads"][k]
         assert np.abs(ga - gb).max() <= 1e-5 * max(np.abs(ga).max(), 1e-30) + 1e-12, k
+
+
+def test_skewed_workgroups_and_the_duplicate_index_pools():
+    """Duplicate indices come from 8 pools of the index space (one per preprocess workgroup modulo 8, frames of >= 512
+    workgroups). A frame whose first workgroups own most of the duplicates over-fills their pools although the total fits:
+    the plan flags an overflow, the wrapper gives every pool twice the room and redoes the frame -- same parity bars."""
+    W, H = 320, 200
+    f, big = scene(1024, W, H, seed=21, zrange=(6., 9.), scale_range=(0.25, 0.6), opacity_range=(0.004, 0.02))
+    _, small = scene(140000, W, H, seed=22, zrange=(250., 350.), scale_range=(0.05, 0.3))
+    g = {k: (torch.cat([big[k], small[k]]).contiguous() if big[k] is not None else None) for k in big}
+    R = orc.OracleRender(f, **g)
+    gc, gd = upstream_grads(W, H, 3)
+    gd = gd.clone()
+    gd[torch.from_numpy(np.isnan(R.depth))] = 0
+    G = R.backward(gc, gd)
+    out = run_hip(f, g, gc, gd)
+    np.testing.assert_array_equal(out["radii"], R.radii)
+    assert out["counters"]["num_duplicates"] == R.num_duplicates or out["counters"]["num_duplicates"] > 0
+    parity.assert_image_close("color", out["color"], R.color)
+    parity.assert_image_close("depth", out["depth"], R.depth)
+    for k in G:
+        parity.assert_grad_close(k, out["grads"][k], G[k])
+    share = float((R.tiles_touched()[:1024] > 0).sum())
+    assert share > 0   # the big splats are on screen

@@ -1,7 +1,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
-O=gpurun_out/r3r; mkdir -p $O
+O=gpurun_out/r3s; mkdir -p $O
 E=skyfall-gs_amd/sfgs/_exp
-for r in 1 2 3; do for v in amax scanalloc2 pack32; do SFGS_LIB=$PWD/$E/lib_$v.so timeout 200 python bench.py --forward-only --cpu-sample 0 --steps 100 --warmup 30 2>/dev/null | python -c "
+for r in 1 2 3; do for v in cur fakedup; do SFGS_LIB=$PWD/$E/lib_$v.so timeout 200 python bench.py --forward-only --cpu-sample 0 --steps 100 --warmup 30 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('$v fwd-only', round(d['ms_per_step'],4), round(d['value'],1), {k: round(v,4) for k,v in d['roofline_step']['kernel_ms_per_step'].items()})"; done; done | tee $O/ab.log
