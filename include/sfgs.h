@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 8
+#define SFGS_ABI_VERSION 9
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -108,6 +108,17 @@ typedef struct SfgsGaussians {
   const float* opacities;        /* [N,1]  (already 3D-filter compensated)         */
   const float* colors_precomp;   /* [N,3] or NULL                                  */
   const float* shs;              /* [N,sh_coeffs,3] or NULL                        */
+  /* RAW-PARAMETER MODE (the activations + Mip-Splatting 3D filter folded into preprocess and
+   * preprocess_bwd). When filter_3D is non-NULL, `scales`, `rotations` and `opacities` above are the model's RAW
+   * parameters -- _scaling, _rotation, _opacity of scene/gaussian_model.py -- and the library evaluates
+   * get_scaling_with_3D_filter (:207-213), get_opacity_with_3D_filter (:237-249) and get_rotation (:216-217) itself, with
+   * the same float sequence as sfgs_prepass_forward (the frame equals, bit for bit, the one rendered from that function's
+   * outputs). The backward then writes the gradients of the RAW parameters (sfgs_prepass_backward's results) into
+   * SfgsGaussianGrads.scales / rotations / opacities. */
+  const void* filter_3D;         /* [N,1] float32 or float64, or NULL = activated inputs (the mode above this comment) */
+  int32_t raw_f64_mask;          /* bit 0: filter_3D is float64; bit 1: `opacities` points to float64 raw opacities
+                                    (the reference's _opacity after its first reset_opacity, :483-501); 0 when
+                                    filter_3D is NULL */
 } SfgsGaussians;
 
 /* Gradient outputs of the backward pass (all device, float32, fully overwritten). */
@@ -118,7 +129,7 @@ typedef struct SfgsGaussianGrads {
                             (scene/gaussian_model.py:744-749)                                    */
   float* scales;         /* [N,3] */
   float* rotations;      /* [N,4] */
-  float* opacities;      /* [N,1] */
+  float* opacities;      /* [N,1]; raw-parameter mode with raw_f64_mask bit 1: [N,1] float64 (cast the pointer) */
   float* colors_precomp; /* [N,3] or NULL */
   float* shs;            /* [N,sh_coeffs,3] or NULL */
 } SfgsGaussianGrads;

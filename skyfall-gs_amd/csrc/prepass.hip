@@ -12,51 +12,10 @@
 // float32 arithmetic according to the filter's dtype), so results agree with the reference to the last bit
 // except where libm's expf differs from the device's.
 // 36-40 B read, 32 B written per Gaussian forward; HBM-bound.
+#include "act_math.h"
 #include "sfgs_internal.h"
 
 namespace sfgs {
-
-// the reference's intermediate quantities, in its own promotion rules (FT = dtype of filter_3D):
-//   sq_i  = square(exp(raw_i))                    float32
-//   det1  = prod_i sq_i                           float32
-//   t_i   = sq_i + square(filter)                 FT
-//   det2  = prod_i t_i                            FT
-//   coef  = sqrt(det1 / det2)                     FT
-// OT = dtype of the raw opacity parameter: float32, or float64 after the reference's reset_opacity
-// (scene/gaussian_model.py:483-501 divides by a float64 coefficient, so from the first opacity reset on -- iteration
-// 3000 of the default schedule -- `_opacity` and its Adam moments are float64 tensors and sigmoid runs in float64).
-template <typename FT, typename OT>
-struct PrepassTerms {
-  float sq[3], det1;
-  OT o;
-  FT f2, t[3], det2, coef;
-};
-
-template <typename FT>
-__device__ __forceinline__ FT sqrt_t(FT v);
-template <> __device__ __forceinline__ float sqrt_t<float>(float v) { return sqrtf(v); }
-template <> __device__ __forceinline__ double sqrt_t<double>(double v) { return sqrt(v); }
-
-template <typename FT, typename OT>
-__device__ __forceinline__ PrepassTerms<FT, OT> prepass_terms(const float* __restrict__ scaling_raw,
-                                                              const OT* __restrict__ opacity_raw,
-                                                              const FT* __restrict__ filter3d, int g) {
-  PrepassTerms<FT, OT> p;
-  const FT f = filter3d[g];
-  p.f2 = f * f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float s = expf(scaling_raw[3 * (size_t)g + i]);
-    p.sq[i] = s * s;
-    p.t[i] = (FT)p.sq[i] + p.f2;
-  }
-  p.det1 = (p.sq[0] * p.sq[1]) * p.sq[2];
-  p.det2 = (p.t[0] * p.t[1]) * p.t[2];
-  p.coef = sqrt_t<FT>((FT)p.det1 / p.det2);
-  if constexpr (sizeof(OT) == 8) p.o = 1.0 / (1.0 + exp(-opacity_raw[g]));
-  else p.o = 1.0f / (1.0f + expf(-opacity_raw[g]));
-  return p;
-}
 
 template <typename FT, typename OT>
 __global__ void __launch_bounds__(256)
@@ -65,14 +24,15 @@ prepass_fwd_kernel(int N, const float* __restrict__ scaling_raw, const OT* __res
                    float* __restrict__ scales, float* __restrict__ opacities, float* __restrict__ rotations) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
-  const PrepassTerms<FT, OT> p = prepass_terms<FT, OT>(scaling_raw, opacity_raw, filter3d, g);
+  const float rs[3] = {scaling_raw[3 * (size_t)g], scaling_raw[3 * (size_t)g + 1], scaling_raw[3 * (size_t)g + 2]};
+  const ActTerms<FT, OT> p = act_terms<FT, OT>(rs, opacity_raw[g], filter3d[g]);
+  float sc[3], op;
+  act_outputs(p, sc, &op);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) scales[3 * (size_t)g + i] = (float)sqrt_t<FT>(p.t[i]);
-  if constexpr (sizeof(OT) == 8) opacities[g] = (float)(p.o * (double)p.coef);   // torch promotes to float64
-  else opacities[g] = (float)((FT)p.o * p.coef);
-  const float4 q = *reinterpret_cast<const float4*>(rotation_raw + 4 * (size_t)g);
-  const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-  *reinterpret_cast<float4*>(rotations + 4 * (size_t)g) = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+  for (int i = 0; i < 3; ++i) scales[3 * (size_t)g + i] = sc[i];
+  opacities[g] = op;
+  *reinterpret_cast<float4*>(rotations + 4 * (size_t)g) =
+      act_rotation(*reinterpret_cast<const float4*>(rotation_raw + 4 * (size_t)g));
 }
 
 template <typename FT, typename OT>
@@ -84,48 +44,24 @@ prepass_bwd_kernel(int N, const float* __restrict__ scaling_raw, const OT* __res
                    OT* __restrict__ g_opacity_raw, float* __restrict__ g_rotation_raw) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
-  const PrepassTerms<FT, OT> p = prepass_terms<FT, OT>(scaling_raw, opacity_raw, filter3d, g);
-  const double coef = (double)p.coef, o = (double)p.o;
-  const double go = g_opacities ? (double)g_opacities[g] : 0.0;
-  g_opacity_raw[g] = (OT)(go * coef * o * (1.0 - o));
+  const float rs[3] = {scaling_raw[3 * (size_t)g], scaling_raw[3 * (size_t)g + 1], scaling_raw[3 * (size_t)g + 2]};
+  const ActTerms<FT, OT> p = act_terms<FT, OT>(rs, opacity_raw[g], filter3d[g]);
+  float gs[3] = {0.f, 0.f, 0.f}, grs[3];
+  if (g_scales) { gs[0] = g_scales[3 * (size_t)g]; gs[1] = g_scales[3 * (size_t)g + 1]; gs[2] = g_scales[3 * (size_t)g + 2]; }
+  OT gro;
+  act_backward(p, gs, g_opacities ? g_opacities[g] : 0.f, grs, &gro);
+  g_opacity_raw[g] = gro;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    // d scales_i / d raw_i = s_i^2 / sqrt(s_i^2 + f^2) ; d (o coef) / d raw_i = o coef f^2 / (s_i^2 + f^2)
-    const double gs = g_scales ? (double)g_scales[3 * (size_t)g + i] : 0.0;
-    const double t = (double)p.t[i];
-    g_scaling_raw[3 * (size_t)g + i] = (float)(gs * (double)p.sq[i] / sqrt(t) + go * o * coef * (double)p.f2 / t);
-  }
-  const float4 q = *reinterpret_cast<const float4*>(rotation_raw + 4 * (size_t)g);
+  for (int i = 0; i < 3; ++i) g_scaling_raw[3 * (size_t)g + i] = grs[i];
   float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g_rotations) gr = *reinterpret_cast<const float4*>(g_rotations + 4 * (size_t)g);
-  const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  float4 out;
-  if (nn > 1e-12f) {  // d (q/|q|) : (g - q_hat (q_hat . g)) / |q|
-    const float inv = 1.0f / nn;
-    const float4 h = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-    const float dot = h.x * gr.x + h.y * gr.y + h.z * gr.z + h.w * gr.w;
-    out = make_float4((gr.x - h.x * dot) * inv, (gr.y - h.y * dot) * inv, (gr.z - h.z * dot) * inv,
-                      (gr.w - h.w * dot) * inv);
-  } else {  // clamped denominator: q / 1e-12
-    out = make_float4(gr.x * 1e12f, gr.y * 1e12f, gr.z * 1e12f, gr.w * 1e12f);
-  }
-  *reinterpret_cast<float4*>(g_rotation_raw + 4 * (size_t)g) = out;
+  *reinterpret_cast<float4*>(g_rotation_raw + 4 * (size_t)g) =
+      act_rotation_backward(*reinterpret_cast<const float4*>(rotation_raw + 4 * (size_t)g), gr);
 }
 
 }  // namespace sfgs
 
 using namespace sfgs;
-
-// dispatch on (filter dtype, raw opacity dtype)
-#define SFGS_PREPASS_DISPATCH(MASK, LAUNCH)                                      \
-  do {                                                                           \
-    switch ((MASK) & 3) {                                                        \
-      case 0: LAUNCH(float, float); break;                                       \
-      case 1: LAUNCH(double, float); break;                                      \
-      case 2: LAUNCH(float, double); break;                                      \
-      default: LAUNCH(double, double); break;                                    \
-    }                                                                            \
-  } while (0)
 
 extern "C" int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const void* opacity_raw,
                                     const float* rotation_raw, const void* filter3d, int32_t f64_mask,
@@ -141,7 +77,7 @@ extern "C" int sfgs_prepass_forward(int32_t N, const float* scaling_raw, const v
 #define SFGS_LAUNCH_PF(FT, OT)                                                                                      \
   hipLaunchKernelGGL((prepass_fwd_kernel<FT, OT>), grid, block, 0, stream, N, scaling_raw, (const OT*)opacity_raw, \
                      rotation_raw, (const FT*)filter3d, scales, opacities, rotations)
-    SFGS_PREPASS_DISPATCH(f64_mask, SFGS_LAUNCH_PF);
+    SFGS_ACT_DISPATCH(f64_mask, SFGS_LAUNCH_PF);
 #undef SFGS_LAUNCH_PF
   }
   SFGS_POST_LAUNCH("prepass_fwd", stream, 0);
@@ -164,7 +100,7 @@ extern "C" int sfgs_prepass_backward(int32_t N, const float* scaling_raw, const 
   hipLaunchKernelGGL((prepass_bwd_kernel<FT, OT>), grid, block, 0, stream, N, scaling_raw, (const OT*)opacity_raw, \
                      rotation_raw, (const FT*)filter3d, g_scales, g_opacities, g_rotations, g_scaling_raw,         \
                      (OT*)g_opacity_raw, g_rotation_raw)
-    SFGS_PREPASS_DISPATCH(f64_mask, SFGS_LAUNCH_PB);
+    SFGS_ACT_DISPATCH(f64_mask, SFGS_LAUNCH_PB);
 #undef SFGS_LAUNCH_PB
   }
   SFGS_POST_LAUNCH("prepass_bwd", stream, 0);

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "act_math.h"
 #include "sfgs_internal.h"
 
 // Ablation builds (tools/ablate_bwd.sh; never the shipped library): -DSFGS_BWD_ABLATE=<bits> removes one part of
@@ -605,14 +606,17 @@ struct DupAcc {
 
 // one thread per Gaussian. K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree:
 // compile-time so that the coefficient / gradient rows live in registers, not scratch.
-template <int K, int DEG>
+// RAW (SfgsGaussians raw-parameter mode): `scales`, `rots`, `opac_` are the model's raw parameters; the activations are
+// recomputed here and the chain rule continues through them, so g_scales / g_rots / g_opac_ receive the RAW parameters'
+// gradients (what sfgs_prepass_backward would make of this kernel's non-raw outputs: the same functions, act_math.h).
+template <int K, int DEG, bool RAW>
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
-                      const float* __restrict__ rots, const float* __restrict__ opac,
-                      const float* __restrict__ shs, const int* __restrict__ radii,
+                      const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
+                      int raw_mask, const float* __restrict__ shs, const int* __restrict__ radii,
                       const uint2* __restrict__ dup, const float4* __restrict__ dupgrad,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
-                      float* __restrict__ g_rots, float* __restrict__ g_opac, float* __restrict__ g_colors,
+                      float* __restrict__ g_rots, void* __restrict__ g_opac_, float* __restrict__ g_colors,
                       float* __restrict__ g_shs) {
   constexpr int PB_CHUNK = 128;   // records per staging chunk and wave: 6 KB of LDS
   static_assert((PB_CHUNK * DG_F4) % 64 == 0, "whole load rounds");
@@ -707,16 +711,44 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     A.gA = acc.get(4); A.gB = acc.get(5); A.gC = acc.get(6); A.gop = acc.get(7);
     A.grgb[0] = acc.get(8); A.grgb[1] = acc.get(9); A.grgb[2] = acc.get(10); A.gdepth = acc.get(11);
     const float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
-    const float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
-    const float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
+    float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
+    const float4 qraw = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
+    float4 qv = qraw;
+    float opacity;
+    const float sraw[3] = {s[0], s[1], s[2]};
+    if constexpr (!RAW) {
+      opacity = static_cast<const float*>(opac_)[g];
+    } else {
+#define SFGS_ACT_FWD(FT, OT) \
+  act_outputs(act_terms<FT, OT>(sraw, static_cast<const OT*>(opac_)[g], static_cast<const FT*>(filt)[g]), s, &opacity)
+      SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_FWD);
+#undef SFGS_ACT_FWD
+      qv = act_rotation(qraw);
+    }
     const float q[4] = {qv.x, qv.y, qv.z, qv.w};
     if constexpr (K > 0) {
       float shl[ROW];
       load_row<ROW>(shs + (size_t)ROW * g, shl);
-      preprocess_backward_one(f, p, s, q, opac[g], shl, A, out, gshl);
+      preprocess_backward_one(f, p, s, q, opacity, shl, A, out, gshl);
     } else {
-      preprocess_backward_one(f, p, s, q, opac[g], nullptr, A, out, gshl);
+      preprocess_backward_one(f, p, s, q, opacity, nullptr, A, out, gshl);
     }
+    if constexpr (RAW) {   // ... and on through the activations (terms recomputed: cheaper than carrying 11 values)
+      const float gs[3] = {out.scales[0], out.scales[1], out.scales[2]};
+#define SFGS_ACT_BWD(FT, OT)                                                                                         \
+  do {                                                                                                              \
+    OT gro;                                                                                                         \
+    act_backward(act_terms<FT, OT>(sraw, static_cast<const OT*>(opac_)[g], static_cast<const FT*>(filt)[g]), gs,    \
+                 out.opacity, out.scales, &gro);                                                                    \
+    static_cast<OT*>(g_opac_)[g] = gro;                                                                             \
+  } while (0)
+      SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_BWD);
+#undef SFGS_ACT_BWD
+      const float4 gq = act_rotation_backward(qraw, make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]));
+      out.rot[0] = gq.x; out.rot[1] = gq.y; out.rot[2] = gq.z; out.rot[3] = gq.w;
+    }
+  } else if constexpr (RAW) {   // not visible: every gradient is zero (the raw opacity's in its own dtype)
+    if (raw_mask & 2) static_cast<double*>(g_opac_)[g] = 0.0; else static_cast<float*>(g_opac_)[g] = 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -725,7 +757,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     g_scales[3 * (size_t)g + i] = out.scales[i];
   }
   *reinterpret_cast<float4*>(g_rots + 4 * (size_t)g) = make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]);
-  g_opac[g] = out.opacity;
+  if constexpr (!RAW) static_cast<float*>(g_opac_)[g] = out.opacity;
   if constexpr (K > 0) {
     store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
   } else {
@@ -765,6 +797,9 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_REQUIRE((g->colors_precomp != nullptr) == (grads->colors_precomp != nullptr) &&
                    (g->shs != nullptr) == (grads->shs != nullptr),
                SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
+  SFGS_REQUIRE(g->filter_3D ? (g->raw_f64_mask & ~3) == 0 : g->raw_f64_mask == 0, SFGS_E_ARG,
+               "raw_f64_mask %d: bit 0 = filter_3D is float64, bit 1 = raw opacities are float64; 0 without filter_3D",
+               g->raw_f64_mask);
   SFGS_REQUIRE(dup_capacity >= 0 && num_duplicates >= 0 && num_duplicates <= dup_capacity, SFGS_E_ARG,
                "bad dup_capacity / num_duplicates");
   // duplicate indices come from DUP_POOLS ranges of [0, dup_capacity): the record array spans the whole index space
@@ -794,13 +829,15 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
     if (!(frame->launch_hints & SFGS_HINT_NO_BIG_CHUNKS))   // the caller read num_big_chunks == 0 from this frame's plan
     hipLaunchKernelGGL(dupgrad_reduce_kernel, dim3(1024), dim3(256), 0, stream, tv.hdr, bv.big_chunks,
                        (unsigned)big_chunk_capacity(dup_capacity), gv.dup, (float4*)dupgrad);
-#define SFGS_LAUNCH_PBWD(K, D)                                                                                          \
-  hipLaunchKernelGGL((preprocess_bwd_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales, \
-                     g->rotations, g->opacities, g->shs, radii, gv.dup, (const float4*)dupgrad, grads->means3D,        \
-                     grads->means2D, grads->scales, grads->rotations, grads->opacities, grads->colors_precomp,         \
-                     grads->shs)
+#define SFGS_LAUNCH_PBWD_(K, D, RAW)                                                                                   \
+  hipLaunchKernelGGL((preprocess_bwd_kernel<K, D, RAW>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,      \
+                     g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask, g->shs,   \
+                     radii, gv.dup, (const float4*)dupgrad, grads->means3D, grads->means2D, grads->scales,             \
+                     grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs)
+#define SFGS_LAUNCH_PBWD(K, D) do { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true); else SFGS_LAUNCH_PBWD_(K, D, false); } while (0)
     SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PBWD);
 #undef SFGS_LAUNCH_PBWD
+#undef SFGS_LAUNCH_PBWD_
   }
   SFGS_POST_LAUNCH("preprocess_bwd", stream, frame->debug);
   return SFGS_OK;

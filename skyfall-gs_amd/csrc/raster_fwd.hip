@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include "act_math.h"
 #include "sfgs_internal.h"
 
 namespace sfgs {
@@ -116,10 +117,13 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 // one 16-byte coarse item (id, depth, first duplicate index, mask) appended to the bin's slab with ONE
 // returning device atomic. The block reserves its duplicate indices (one per set mask bit, in walk order)
 // with one atomic per block.
-template <int K, int DEG>  // K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree
+// RAW: `scales`, `rots`, `opac` are the model's raw parameters and `filt` its 3D filter (SfgsGaussians raw-parameter
+// mode): the activations of act_math.h run here instead of in a pre-pass kernel that writes N-sized intermediates.
+template <int K, int DEG, bool RAW>  // K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
-                  const float* __restrict__ rots, const float* __restrict__ opac,
+                  const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
+                  int raw_mask,
                   const float* __restrict__ colors, const float* __restrict__ shs, int* __restrict__ radii,
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
@@ -148,11 +152,23 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     // behind `if (pr.visible)`: three dependent round trips to memory per thread otherwise)
     float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
     float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
-    const float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
-    const float opacity_in = opac[g];
+    float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
+    float opacity_in = 0.f;
+    if constexpr (!RAW) opacity_in = static_cast<const float*>(opac_)[g];
     float rgb_in[3] = {0.f, 0.f, 0.f};
     if constexpr (K == 0) { rgb_in[0] = colors[3 * (size_t)g]; rgb_in[1] = colors[3 * (size_t)g + 1]; rgb_in[2] = colors[3 * (size_t)g + 2]; }
     asm volatile("" :: "v"(p[2]), "v"(s[0]), "v"(qv.x), "v"(opacity_in), "v"(rgb_in[0]));   // all five in registers here
+    if constexpr (RAW) {   // raw parameters -> what render() would have passed (the mask is uniform over the launch)
+#define SFGS_ACT_FWD(FT, OT)                                                                                        \
+  do {                                                                                                              \
+    const OT o_raw = static_cast<const OT*>(opac_)[g];                                                              \
+    const FT f_raw = static_cast<const FT*>(filt)[g];                                                               \
+    act_outputs(act_terms<FT, OT>(s, o_raw, f_raw), s, &opacity_in);                                                \
+  } while (0)
+      SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_FWD);
+#undef SFGS_ACT_FWD
+      qv = act_rotation(qv);
+    }
     float q[4] = {qv.x, qv.y, qv.z, qv.w};
     const Projected pr = project_gaussian(f, p, s, q);
     radii[g] = pr.radius;
@@ -1212,6 +1228,9 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
     SFGS_REQUIRE(g->means3D && g->scales && g->rotations && g->opacities, SFGS_E_ARG, "Gaussian tensor pointer is NULL");
     SFGS_REQUIRE((g->colors_precomp != nullptr) != (g->shs != nullptr), SFGS_E_ARG,
                  "provide exactly one of colors_precomp / shs");
+    SFGS_REQUIRE(g->filter_3D ? (g->raw_f64_mask & ~3) == 0 : g->raw_f64_mask == 0, SFGS_E_ARG,
+                 "raw_f64_mask %d: bit 0 = filter_3D is float64, bit 1 = raw opacities are float64; 0 without filter_3D",
+                 g->raw_f64_mask);
     if (g->shs)
       SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) &&
                        (f->sh_coeffs == 1 || f->sh_coeffs == 4 || f->sh_coeffs == 9 || f->sh_coeffs == 16),
@@ -1277,13 +1296,16 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   }
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
-#define SFGS_LAUNCH_PRE(K, D)                                                                                          \
-  hipLaunchKernelGGL((preprocess_kernel<K, D>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D, g->scales,    \
-                     g->rotations, g->opacities, g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count,   \
-                     bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis,            \
-                     tv.block_dref, gv.big_list, tv.hdr, tv.dup_pool)
+#define SFGS_LAUNCH_PRE_(K, D, RAW)                                                                                    \
+  hipLaunchKernelGGL((preprocess_kernel<K, D, RAW>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,          \
+                     g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask,           \
+                     g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count, bv.slabs,                      \
+                     (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
+                     gv.big_list, tv.hdr, tv.dup_pool)
+#define SFGS_LAUNCH_PRE(K, D) do { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true); else SFGS_LAUNCH_PRE_(K, D, false); } while (0)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
+#undef SFGS_LAUNCH_PRE_
       // the big splats' walk: persistent waves over the work list (returns at once when the list is empty; not launched
       // at all when the caller asserts there are none -- it checks counters.num_huge_splats afterwards)
       if (!(frame->launch_hints & SFGS_HINT_NO_HUGE_SPLATS))

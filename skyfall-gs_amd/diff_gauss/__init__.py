@@ -179,7 +179,9 @@ def _stream(dev):
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings, filter_3D=None):
+        # filter_3D given: RAW-PARAMETER MODE (include/sfgs.h SfgsGaussians) -- opacities / scales / rotations are the
+        # model's raw parameters (opacities possibly float64) and the gradients returned for them are the raw ones
         lib = L.load()
         dev = means3D.device
         N = int(means3D.shape[0])
@@ -188,8 +190,7 @@ class _Rasterize(torch.autograd.Function):
         keep = []
         with torch.cuda.device(dev):
             stream = _stream(dev)
-            gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
-                                 L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
+            gs = _gaussians(N, means3D, scales, rotations, opacities, colors_precomp, shs, filter_3D)
             sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
             # Neither the duplicate count D nor the fullest coarse bin is known before the plan: plan into a bins
             # blob sized from the previous frames (geometric growth) and redo the plan in the rare case it
@@ -203,6 +204,7 @@ class _Rasterize(torch.autograd.Function):
             cap = max(hint[0], slots(4 * N))
             ccap = max(hint[1], 8 * N // ncb, 256)
             need_bwd = any(ctx.needs_input_grad[:7])
+            ctx.filter_3D = filter_3D
             if need_bwd and getattr(settings, "tile_rows", None):
                 raise ValueError("tile_rows (band rendering) is a forward-only extension: the backward needs the whole "
                                  "frame's per-pixel state")
@@ -337,8 +339,7 @@ class _Rasterize(torch.autograd.Function):
                     hs["prefill_ran"] = True
             frame = _frame(settings, dev, ctx.sh_coeffs, keep, bwd_hints, hs["fb"] if hs is not None else None)
             stream = _stream(dev)
-            gs = L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
-                                 L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
+            gs = _gaussians(N, means3D, scales, rotations, opacities, colors_precomp, shs, ctx.filter_3D)
             # one allocation for all gradient tensors (views), one for the per-duplicate scratch
             K = ctx.sh_coeffs
             ncol = 3 * K if ctx.has_shs else 3
@@ -353,7 +354,9 @@ class _Rasterize(torch.autograd.Function):
                 return v
             g_rot = take(4, (N, 4))
             g_means3D, g_means2D, g_scales = take(3, (N, 3)), take(3, (N, 3)), take(3, (N, 3))
-            g_opac = take(1, (N, 1))
+            # (raw-parameter mode after the reference's reset_opacity: the raw opacity and its gradient are float64)
+            g_opac = take(1, (N, 1)) if opacities.dtype == torch.float32 else torch.empty(N, 1, dtype=opacities.dtype,
+                                                                                          device=dev)
             g_col = take(3, (N, 3)) if ctx.has_colors else None
             g_shs = take(3 * K, (N, K, 3)) if ctx.has_shs else None
             grads = L.SfgsGaussianGrads(C_sizeof(L.SfgsGaussianGrads), L.ptr(g_means3D), L.ptr(g_means2D),
@@ -368,7 +371,17 @@ class _Rasterize(torch.autograd.Function):
             L.check(lib.sfgs_raster_backward(L.C.byref(frame), L.C.byref(gs), L.ptr(radii), L.ptr(geom), L.ptr(tiles),
                                              L.ptr(bins), D, ctx.ccap, ctx.ndup, L.ptr(image), L.ptr(gc), L.ptr(gd), L.ptr(ga),
                                              L.ptr(dupgrad), dupgrad.numel(), L.C.byref(grads), stream))
-        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None
+        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None
+
+
+def _gaussians(N, means3D, scales, rotations, opacities, colors_precomp, shs, filter_3D):
+    if filter_3D is None:
+        return L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                               L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
+    from sfgs.prepass import f64_mask
+    return L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                           L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs), L.ptr(filter_3D),
+                           f64_mask(filter_3D, opacities))
 
 
 class _HipBackend:
@@ -385,6 +398,13 @@ class _HipBackend:
     @staticmethod
     def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings):
         return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
+
+    @staticmethod
+    def rasterize_raw(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation, filter_3D,
+                      raster_settings):
+        """Raw-parameter mode: the activations + 3D filter of sfgs.prepass run inside preprocess / preprocess_bwd."""
+        return _Rasterize.apply(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation,
+                                raster_settings, filter_3D)
 
 
 _backend = _HipBackend
@@ -414,12 +434,20 @@ class GaussianRasterizer(nn.Module):
             raise ValueError("means3D must be [N,3]")
         if means2D is None:
             means2D = torch.zeros_like(means3D)
-        scales = _f32c(scales, "scales", (3,))
-        rotations = _f32c(rotations, "rotations", (4,))
-        opacities = _f32c(opacities, "opacities")
-        if opacities.numel() != N:
-            raise ValueError(f"opacities must have N={N} elements")
-        opacities = opacities.reshape(N, 1)
+        # Deferred results of sfgs.prepass's patched getters (render() only passed them through .float()): the library
+        # applies the activations itself, from the raw parameters. Anything else Deferred is materialised here.
+        from sfgs import prepass
+        raw = prepass.raw_parameters(scales, opacities, rotations) if hasattr(_backend, "rasterize_raw") else None
+        if raw is None:
+            scales, opacities, rotations = (prepass.materialise(t) for t in (scales, opacities, rotations))
+            scales = _f32c(scales, "scales", (3,))
+            rotations = _f32c(rotations, "rotations", (4,))
+            opacities = _f32c(opacities, "opacities")
+            if opacities.numel() != N:
+                raise ValueError(f"opacities must have N={N} elements")
+            opacities = opacities.reshape(N, 1)
+        else:
+            scales, opacities, rotations, filter_3D = raw      # validated by prepass (dtypes, shapes, device)
         colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
         if shs is not None:
             shs = _f32c(shs, "shs")
@@ -433,6 +461,10 @@ class GaussianRasterizer(nn.Module):
             if t is not None and (t.shape[0] != N or t.device != means3D.device):
                 raise ValueError(f"{name}: first dimension / device must match means3D")
         _settings_tensors(self.raster_settings, means3D.device)   # shapes / dtypes / devices of the 14-field tuple
-        color, depth, norm, alpha, radii = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
-                                                               rotations, self.raster_settings)
+        if raw is not None:
+            color, depth, norm, alpha, radii = _backend.rasterize_raw(means3D, means2D, shs, colors_precomp, opacities,
+                                                                      scales, rotations, filter_3D, self.raster_settings)
+        else:
+            color, depth, norm, alpha, radii = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities,
+                                                                   scales, rotations, self.raster_settings)
         return color, depth, norm, alpha, radii, None

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -26,7 +26,7 @@ class SfgsFrame(C.Structure):
 class SfgsGaussians(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("count", C.c_int32), ("means3D", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("opacities", C.c_void_p), ("colors_precomp", C.c_void_p),
-                ("shs", C.c_void_p)]
+                ("shs", C.c_void_p), ("filter_3D", C.c_void_p), ("raw_f64_mask", C.c_int32)]   # raw-parameter mode
 
 
 class SfgsGaussianGrads(C.Structure):

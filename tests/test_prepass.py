@@ -96,3 +96,53 @@ def test_install_patches_a_gaussian_model_shaped_class():
     finally:
         prepass.uninstall(GaussianModel)
     assert isinstance(GaussianModel.__dict__["get_rotation"], property) and GaussianModel not in prepass._ORIG
+
+
+def test_deferred_handles_materialise_for_everyone_but_the_rasterizer(monkeypatch):
+    """sfgs.prepass.Deferred (what the patched getters return with fold=True) on a GPU-less host: metadata and render()'s
+    `.float()` leave it alone, any other use turns it into the ordinary tensors of ONE launch with their autograd graph,
+    and a rasterizer backend without a raw-parameter route (here: the oracle double) gets materialised values."""
+    from sfgs import prepass
+    a, b, c, f = _inputs("f64")
+    launches = []
+
+    def fake(sa, sb, sc_, sf, _state=None):   # the real op needs the GPU library; same contract
+        launches.append(1)
+        return tuple(t.float() for t in prepass_reference(sa, sb, sc_, sf))
+    monkeypatch.setattr(prepass, "fused_activations", fake)
+    n = a.shape[0]
+    shared = prepass._Shared((a, b, c, f))
+    sc, op, ro = (prepass.Deferred(shared, i, s) for i, s in enumerate(((n, 3), (n, 1), (n, 4))))
+    assert isinstance(sc, torch.Tensor) and tuple(sc.shape) == (n, 3) and sc.dtype == torch.float32 and not sc.is_cuda
+    assert sc.float() is sc and op.numel() == n and ro.dim() == 2 and len(ro) == n and sc.size(1) == 3
+    assert prepass.raw_parameters(sc.float(), op.float(), ro) == (a, b, c, f) and not launches
+    assert prepass.raw_parameters(sc, op, torch.zeros(n, 4)) is None
+    assert prepass.raw_parameters(op, sc, ro) is None            # handles in the wrong slots
+    ref = [t.float() for t in prepass_reference(a, b, c, f)]
+    got = sc * 1.0
+    assert type(got) is torch.Tensor and torch.equal(got, ref[0]) and len(launches) == 1
+    assert torch.equal(op[3:5], ref[1][3:5]) and torch.equal(torch.cat([ro, ro])[n:], ref[2]) and len(launches) == 1
+    (sc.sum() + (op * op).sum()).backward()
+    assert a.grad is not None and b.grad is not None and float(a.grad.abs().sum()) > 0
+    assert "tensor" in repr(ro)
+
+    # through the validation layer of diff_gauss with a backend that has no raw-parameter route
+    import diff_gauss
+    from tests import oracle_backend
+    seen = {}
+
+    class Probe(oracle_backend.OracleBackend):
+        @staticmethod
+        def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings):
+            seen.update(scales=scales, opacities=opacities, rotations=rotations)
+            z = torch.zeros(1)
+            return z, z, z, z, z
+    monkeypatch.setattr(diff_gauss, "_backend", Probe)
+    shared2 = prepass._Shared((a, b, c, f))
+    h = [prepass.Deferred(shared2, i, s) for i, s in enumerate(((n, 3), (n, 1), (n, 4)))]
+    settings = diff_gauss.GaussianRasterizationSettings(8, 8, 1.0, 1.0, 0.1, None, torch.zeros(3), 1.0, torch.eye(4),
+                                                        torch.eye(4), 0, torch.zeros(3), False, False)
+    diff_gauss.GaussianRasterizer(settings)(means3D=torch.zeros(n, 3), means2D=None, opacities=h[1].float(),
+                                            colors_precomp=torch.zeros(n, 3), scales=h[0].float(), rotations=h[2])
+    for k, r in zip(("scales", "opacities", "rotations"), ref):
+        assert type(seen[k]) is torch.Tensor and torch.equal(seen[k], r), k
