@@ -117,8 +117,9 @@ class Deferred(torch.Tensor):
 
     @staticmethod
     def __new__(cls, shared, index, shape):
-        t = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=shared.raw[0].device,
-                                                requires_grad=False)
+        t = torch.Tensor._make_wrapper_subclass(
+            cls, shape, dtype=torch.float32, device=shared.raw[0].device,
+            requires_grad=torch.is_grad_enabled() and any(p.requires_grad for p in shared.raw[:3]))
         t._sfgs_shared, t._sfgs_index = shared, index
         return t
 
@@ -178,7 +179,7 @@ def _cached(self):
                 for t in (self._scaling, self._opacity, self._rotation, self.filter_3D))
     key += (torch.is_grad_enabled(),)
     hit = getattr(self, "_sfgs_prepass_cache", None)
-    if _FOLD.get(type(self), False) and self._scaling.is_cuda:
+    if _FOLD.get(type(self), False):
         if hit is None or hit[0] != key or hit[2]["consumed"] or not isinstance(hit[1][0], Deferred):
             N = int(self._scaling.shape[0])
             raw = _checked(self._scaling, self._opacity, self._rotation, self.filter_3D)

@@ -17,7 +17,9 @@ Every rasterizer call is recorded -- argument names, dtypes, shapes, STRIDES, th
 outputs, the upstream gradients autograd delivered and the gradients returned -- into
 tests/golden/reference_render_trace.npz; tests/test_gpu_render_trace.py replays it into the HIP path on the GPU.
 
-usage: python tests/golden/make_golden_r3.py [--check]     (--check: regenerate and compare with the committed file)
+usage: python tests/golden/make_golden_r3.py [--check] [--with-prepass-hook]
+  --check: regenerate and compare with the committed file
+  --with-prepass-hook: with sfgs.prepass installed on the real GaussianModel (Deferred getter handles)
 """
 import json
 import math
@@ -148,11 +150,32 @@ def _loss(loss_utils, image, depth, cam, lambda_dssim=0.2, lambda_depth=0.5):
     return loss + lambda_depth * (1 - pearson)
 
 
+HOOKED = None
+
+
 def run():
     """Returns (trace records, summary dict)."""
     import oracle_backend as ob
     _redirect_cuda()
     render, Camera, GaussianModel, loss_utils = _import_reference()
+    if "--with-prepass-hook" in sys.argv:
+        # sfgs.prepass's getter hook on the REAL GaussianModel: render() receives Deferred handles, casts them with
+        # .float() and hands them to the rasterizer (which, behind the oracle double, materialises them). The HIP op
+        # behind a materialisation needs the GPU library: stand-in = the torch restatement that tests/test_prepass.py
+        # pins bit for bit to the real getters, so the committed trace must be reproduced exactly.
+        from oracle.prepass_torch import prepass_reference
+        from sfgs import prepass
+        def stand_in(a, b, c, f, _state=None):
+            out = tuple(t.float() for t in prepass_reference(a, b, c, f))
+            for t in out:   # like the real op's backward: a consumed graph is not handed out again
+                if _state is not None and t.requires_grad:
+                    t.register_hook(lambda g, st=_state: st.__setitem__("consumed", True))
+            return out
+        prepass.fused_activations = stand_in
+        prepass._checked = lambda a, b, c, f: (a, b, c, f.detach())
+        prepass.install(GaussianModel, fold=True)
+        global HOOKED
+        HOOKED = prepass
     cams = _cameras(Camera)
     pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     black, white = torch.zeros(3), torch.ones(3)
@@ -180,6 +203,9 @@ def run():
             with torch.no_grad():
                 pkg = render(cam, model, pipe, bg, kernel_size=KERNEL_SIZE, **kw)
         assert len(trace) == n0 + 1
+        if HOOKED is not None:   # the handles really travelled through render()
+            a = trace[-1]["arg_tensors"]
+            assert all(isinstance(a[k], HOOKED.Deferred) for k in ("scales", "opacities", "rotations")), name
         trace[-1]["name"] = name
         assert set(pkg) == {"render", "render_depth", "render_norm", "render_alpha", "viewspace_points",
                             "visibility_filter", "radii", "extra"}

@@ -27,6 +27,19 @@ def test_real_render_runs_on_our_package_and_reproduces_the_committed_trace(tmp_
     assert "reproduced: 7 calls" in r.stdout
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gaussian_renderer")), reason="reference tree not present (GPU box)")
+def test_real_render_passes_the_prepass_hooks_deferred_handles_through(tmp_path):
+    """sfgs.prepass.install(GaussianModel, fold=True) on the REAL class: its getters return Deferred handles, the REAL
+    render() casts them (.float()) and passes them on unchanged (the driver asserts that all three arrive as handles in
+    every one of the 7 calls), and everything downstream -- here the oracle double, which has no raw-parameter route and
+    materialises them -- reproduces the committed trace bit for bit, dtypes / strides / requires_grad included. The GPU
+    side of the same route (the rasterizer's raw-parameter mode) is tests/test_gpu_prepass_fold.py."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden_r3.py"), "--check",
+                        "--with-prepass-hook"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "reproduced: 7 calls" in r.stdout
+
+
 def test_committed_trace_is_what_render_hands_the_rasterizer():
     """Static facts of the recorded boundary (runs everywhere): the 14 settings fields in the reference's order, the
     keyword set, dtypes and shapes of gaussian_renderer/__init__.py:132-140."""
