@@ -1,0 +1,4 @@
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r3w; mkdir -p $O
+for r in 1 2 3; do echo "== process $r"; timeout 200 python tools/diag_placement.py 2>&1 | tail -9; done | tee $O/placement.log
