@@ -14,6 +14,7 @@
 //
 // Compile with -ffp-contract=off: integer outputs depend on exact float32 sequences (raster_math.h).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -129,7 +130,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
                   uint4* __restrict__ big_list, unsigned long long* __restrict__ hdr,
-                  unsigned long long* __restrict__ dup_pool) {
+                  unsigned long long* __restrict__ dup_pool, uint4* __restrict__ pairs,
+                  uint32_t* __restrict__ block_items) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
   __shared__ unsigned long long s_base;
   const FrameParams f = load_frame(kf);
@@ -248,9 +250,20 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                                        (unsigned)br.y0 | ((unsigned)br.y1 << 16), 0u);
     }
   }
-  // reserve duplicate indices: block scan + one returning atomic per block
+  // reserve duplicate indices: block scan + one returning atomic per block. Two-pass binning (`pairs`): the same scan
+  // ranks the thread's coarse ITEMS inside the workgroup's stretch of the pair list -- packed into one word: a
+  // workgroup has < 2^20 duplicates (256 threads x at most 63 coarse bins x 16 tiles) and at most 1 536 own items
+  unsigned n_items = 0;
+  if (pairs && n_dup && !big && !huge) {
+#pragma unroll
+    for (int k = 0; k < BIG_WALK; ++k)
+      n_items += ((k < 4 ? mask_lo >> (16 * k) : mask_hi >> (16 * (k - 4))) & 0xffffull) != 0ull;
+  }
+  static_assert(PAIRS_PER_BLOCK == PRE_BLOCK * BIG_WALK, "a thread emits at most BIG_WALK items itself");
   unsigned total;
-  const unsigned ex = block_excl_scan_u32<PRE_BLOCK>(n_dup, &total, s_red);
+  const unsigned ex_packed = block_excl_scan_u32<PRE_BLOCK>(n_dup | (n_items << 20), &total, s_red);
+  const unsigned ex = ex_packed & 0xfffffu, ex_items = ex_packed >> 20, total_items = total >> 20;
+  total &= 0xfffffu;
   __shared__ int s_fits;
   if (threadIdx.x == 0) {
     bool ok = true;
@@ -273,6 +286,25 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     const int nb = emit ? (cx1 - cx0) * (cy1 - cy0) : 0;
     unsigned dup = (unsigned)(base + ex);
     int cx = cx0, cy = cy0;
+    if (pairs) {
+      // TWO-PASS BINNING (round 3): the items go, with plain stores and the coarse bin in the upper half of the mask
+      // word, into this workgroup's stretch of the pair list; bin_scatter_kernel then ranks them per bin with LDS
+      // atomics and reserves slab ranges with ONE device atomic per (scatter workgroup, bin) -- 0.5 M instead of 2.7 M
+      // returning device atomics on the headline scene, which is what this kernel was bound by.
+      unsigned pos = blockIdx.x * (unsigned)PAIRS_PER_BLOCK + ex_items;
+#pragma unroll
+      for (int k = 0; k < BIG_WALK; ++k) {
+        if (k < nb) {
+          const unsigned m = (unsigned)((k < 4 ? mask_lo >> (16 * k) : mask_hi >> (16 * (k - 4))) & 0xffffull);
+          if (m) {
+            pairs[pos++] = make_uint4((unsigned)g, depth_bits, dup, m | ((unsigned)(cy * CX + cx) << 16));
+            dup += (unsigned)__popc(m);
+          }
+          if (++cx == cx1) { cx = cx0; ++cy; }
+        }
+      }
+      if (threadIdx.x == 0) block_items[blockIdx.x] = fits ? total_items : 0u;
+    } else {
     const unsigned long long le = (2ull << lane) - 1ull;   // lanes <= this one
     for (int k = 0; __ballot(k < nb) != 0ull; ++k) {
       unsigned m = 0;
@@ -308,6 +340,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       }
       if (k < nb && ++cx == cx1) { cx = cx0; ++cy; }
     }
+    }
   }
   for (unsigned long long bl = fits ? big_lanes : 0ull; bl; bl &= bl - 1) {  // cooperative emission (fits is block-uniform)
     const int L = __builtin_ctzll(bl);
@@ -335,6 +368,148 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   if (threadIdx.x == 0) block_nvis[blockIdx.x] = total;
   block_excl_scan_u32<PRE_BLOCK>(dref, &total, s_red);
   if (threadIdx.x == 0) block_dref[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1s: second pass of the two-pass binning. One workgroup per SCATTER_BLOCKS consecutive preprocess workgroups
+// (~11 000 pairs on the headline scene):
+//   1. count its pairs per coarse bin in LDS (items and tile hits);
+//   2. reserve every touched bin's slab range with ONE 64-bit device atomic (items | hits, the counter format of the
+//      direct path: big splats still append to the same counters directly) -- 0.5 M device atomics instead of one per
+//      pair (2.7 M at the chip's 26.7 G/s were 0.10 ms of preprocess);
+//   3. counting-sort the pairs by bin (positions from LDS cursors, 16-bit pair indices in LDS) and
+//   4. write them in SORTED order: consecutive lanes store consecutive items of a bin's run, so a run of ~5 items leaves
+//      the CU as one or two line writes instead of five scattered 16-byte sector writes (the slab lines are shared by
+//      workgroups on all XCDs: every partial line goes to memory on its own).
+// The order of a bin's items is irrelevant (its tiles are sorted by (depth, id) afterwards).
+#ifndef SFGS_SCATTER_BLOCKS
+#define SFGS_SCATTER_BLOCKS 32
+#endif
+#ifndef SFGS_SCATTER_ABLATE   // experiment builds only: 1 no device atomics, 2 no sorted stores, 4 no step 3 / 4, 8 no counting
+#define SFGS_SCATTER_ABLATE 0
+#endif
+constexpr int SCATTER_NT = 1024, SCATTER_BLOCKS = SFGS_SCATTER_BLOCKS, SCATTER_BINS = 4096, SCATTER_IDX = 15360;
+static_assert(SCATTER_BLOCKS * PAIRS_PER_BLOCK <= 65536, "16-bit pair indices");
+__global__ void __launch_bounds__(SCATTER_NT)
+bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
+                   uint32_t* __restrict__ coarse_count, uint4* __restrict__ slabs, unsigned coarse_capacity,
+                   unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
+  __shared__ unsigned s_red[SCATTER_NT / 64 + 1];
+  __shared__ unsigned s_items[SCATTER_BINS];   // pairs of this workgroup per bin; then (bin's first slab rank - first sorted position)
+  __shared__ unsigned s_hits[SCATTER_BINS];    // their tile hits; then the bin's cursor in the sorted order
+  __shared__ unsigned short s_idx[SCATTER_IDX];   // pair index at every sorted position
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * SCATTER_BLOCKS, nblk = min(SCATTER_BLOCKS, NB - b0);
+  if (tid < 64) {
+    static_assert(SCATTER_BLOCKS <= 64, "one wave scans the block counts");
+    const unsigned c = tid < nblk ? block_items[b0 + tid] : 0u;
+    const unsigned incl = wave_incl_scan_u32(c);
+    if (tid < SCATTER_BLOCKS) s_prefix[tid + 1] = incl;
+    if (tid == 0) s_prefix[0] = 0u;
+  }
+  __syncthreads();
+  const unsigned total = s_prefix[nblk];
+  if (total == 0u) return;
+  // flat pair index -> address: the preprocess workgroup it belongs to by binary search over <= 33 prefix sums
+  auto pair_ptr = [&](unsigned i) {
+    int lo = 0, hi = nblk;                 // s_prefix[lo] <= i < s_prefix[hi]
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {       // 2^6 > SCATTER_BLOCKS
+      const int mid = (lo + hi) >> 1;
+      if (hi - lo > 1) { if (s_prefix[mid] <= i) lo = mid; else hi = mid; }
+    }
+    return pairs + (size_t)(b0 + lo) * PAIRS_PER_BLOCK + (i - s_prefix[lo]);
+  };
+  for (int r0 = 0; r0 < NCB; r0 += SCATTER_BINS) {   // one round up to 4 096 bins (1080p: 2 040, 2160p: 8 160)
+    const int nbins = min(SCATTER_BINS, NCB - r0);
+    for (int i = tid; i < nbins; i += SCATTER_NT) { s_items[i] = 0u; s_hits[i] = 0u; }
+    __syncthreads();
+    // ---- 1. count ----
+    if (!(SFGS_SCATTER_ABLATE & 8))
+    for (unsigned i0 = tid; i0 < total; i0 += 4 * SCATTER_NT) {   // four independent loads in flight per thread
+      unsigned w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = i0 + u * SCATTER_NT < total ? pair_ptr(i0 + u * SCATTER_NT)->w : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cb = (int)(w[u] >> 16) - r0;
+        if ((w[u] & 0xffffu) && cb >= 0 && cb < nbins) {
+          atomicAdd(&s_items[cb], 1u);
+          atomicAdd(&s_hits[cb], (unsigned)__popc(w[u] & 0xffffu));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 2. reserve, and scan the counts into sorted positions (a thread's four bins are neighbours in that order) ----
+    {  // the (up to four) reservations of a thread are all in flight before the first returned rank is used: named 64-bit
+       // registers and one common wait (an array, or a re-used half of a returned pair, makes the compiler wait per atomic)
+      static_assert(SCATTER_BINS <= 4 * SCATTER_NT, "four bins per thread");
+      unsigned long long rs0 = 0ull, rs1 = 0ull, rs2 = 0ull, rs3 = 0ull;
+      unsigned c0, c1, c2, c3;
+#define SFGS_RESERVE(U, RS, C)                                                                                        \
+  { const int i = tid + U * SCATTER_NT;                                                                               \
+    C = i < nbins ? s_items[i] : 0u;                                                                                  \
+    if (C && !(SFGS_SCATTER_ABLATE & 1))                                                                              \
+      RS = atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)(r0 + i) * CC_STRIDE]),              \
+                          (unsigned long long)C | ((unsigned long long)s_hits[i] << 32)); }
+      SFGS_RESERVE(0, rs0, c0) SFGS_RESERVE(1, rs1, c1) SFGS_RESERVE(2, rs2, c2) SFGS_RESERVE(3, rs3, c3)
+#undef SFGS_RESERVE
+      unsigned round_total;
+      const unsigned base = block_excl_scan_u32<SCATTER_NT>(c0 + c1 + c2 + c3, &round_total, s_red);   // (syncs: s_hits read above)
+      asm volatile("" :: "v"(rs0), "v"(rs1), "v"(rs2), "v"(rs3));
+      const unsigned p0 = base, p1 = p0 + c0, p2 = p1 + c1, p3 = p2 + c2;
+      if (tid < nbins) { s_items[tid] = (unsigned)rs0 - p0; s_hits[tid] = p0; }
+      if (tid + SCATTER_NT < nbins) { s_items[tid + SCATTER_NT] = (unsigned)rs1 - p1; s_hits[tid + SCATTER_NT] = p1; }
+      if (tid + 2 * SCATTER_NT < nbins) { s_items[tid + 2 * SCATTER_NT] = (unsigned)rs2 - p2; s_hits[tid + 2 * SCATTER_NT] = p2; }
+      if (tid + 3 * SCATTER_NT < nbins) { s_items[tid + 3 * SCATTER_NT] = (unsigned)rs3 - p3; s_hits[tid + 3 * SCATTER_NT] = p3; }
+      __syncthreads();
+      // ---- 3. sorted position of every pair; those beyond the index buffer (a workgroup with > 15 360 pairs in this round
+      //         of bins) are written at once, unsorted ----
+      if (!(SFGS_SCATTER_ABLATE & 4))
+      for (unsigned i0 = tid; i0 < total; i0 += 4 * SCATTER_NT) {
+        uint4 it[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          it[u] = i0 + u * SCATTER_NT < total ? *pair_ptr(i0 + u * SCATTER_NT) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned m = it[u].w & 0xffffu;
+          const int cb = (int)(it[u].w >> 16) - r0;
+          if (m && cb >= 0 && cb < nbins) {
+            const unsigned pos = atomicAdd(&s_hits[cb], 1u);
+            if (pos < (unsigned)SCATTER_IDX) {
+              s_idx[pos] = (unsigned short)(i0 + u * SCATTER_NT);
+            } else {
+              const unsigned rank = s_items[cb] + pos;
+              if (rank < coarse_capacity) slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, m);
+              else hdr[HDR_OVERFLOW] = 1ull;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- 4. write in sorted order ----
+      const unsigned nsorted = (SFGS_SCATTER_ABLATE & 6) ? 0u : min(round_total, (unsigned)SCATTER_IDX);
+      for (unsigned q0 = tid; q0 < nsorted; q0 += 4 * SCATTER_NT) {
+        uint4 it[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          it[u] = q0 + u * SCATTER_NT < nsorted ? *pair_ptr(s_idx[q0 + u * SCATTER_NT]) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (q0 + u * SCATTER_NT < nsorted) {
+            const int cb = (int)(it[u].w >> 16) - r0;
+            const unsigned rank = s_items[cb] + (q0 + u * SCATTER_NT);
+            if (rank < coarse_capacity)
+              slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, it[u].w & 0xffffu);
+            else hdr[HDR_OVERFLOW] = 1ull;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1220,6 +1395,11 @@ static int check_frame(const SfgsFrame* f) {
   return SFGS_OK;
 }
 
+static bool binning_direct() {
+  const char* e = getenv("SFGS_BINNING");
+  return e && !strcmp(e, "direct");
+}
+
 static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
   SFGS_REQUIRE(g != nullptr, SFGS_E_ARG, "gaussians is NULL");
   SFGS_REQUIRE(g->struct_size == sizeof(SfgsGaussians), SFGS_E_ARG, "SfgsGaussians.struct_size mismatch");
@@ -1294,6 +1474,9 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
       hipLaunchKernelGGL(subpix_bound_kernel, dim3(blocks), dim3(256), 0, stream, frame->subpixel_offset, n, tv.hdr); }
     SFGS_POST_LAUNCH("subpix_bound", stream, frame->debug);
   }
+  // two-pass binning (pair list + bin_scatter_kernel) unless the coarse-bin index does not fit the pair's 16 bits (images
+  // beyond 65 536 coarse bins = 8 192 x 8 192 pixels) or SFGS_BINNING=direct asks for the one-pass path (A/B, tests)
+  const bool two_pass = NCB <= 65536 && !binning_direct();
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
 #define SFGS_LAUNCH_PRE_(K, D, RAW)                                                                                    \
@@ -1301,7 +1484,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask,           \
                      g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count, bv.slabs,                      \
                      (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
-                     gv.big_list, tv.hdr, tv.dup_pool)
+                     gv.big_list, tv.hdr, tv.dup_pool, two_pass ? gv.pairs : nullptr, gv.block_items)
 #define SFGS_LAUNCH_PRE(K, D) do { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true); else SFGS_LAUNCH_PRE_(K, D, false); } while (0)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
@@ -1315,6 +1498,13 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                          dup_pools_used(NB));
     }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
+    if (two_pass) {
+      ProfScope ps_(KID_BIN_SCATTER, stream);
+      hipLaunchKernelGGL(bin_scatter_kernel, dim3((NB + SCATTER_BLOCKS - 1) / SCATTER_BLOCKS), dim3(SCATTER_NT), 0, stream,
+                         NB, (int)NCB, gv.pairs, gv.block_items, tv.coarse_count, bv.slabs, (unsigned)coarse_capacity,
+                         tv.hdr);
+    }
+    SFGS_POST_LAUNCH("bin_scatter", stream, frame->debug);
   }
   { ProfScope ps_(KID_PLAN_SCAN, stream);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,

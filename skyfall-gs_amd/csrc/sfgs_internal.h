@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 
 // ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
 enum KernelId {
-  KID_SUBPIX = 0, KID_PREPROCESS, KID_PLAN_SCAN, KID_FINE_BIN, KID_SORT_SMALL, KID_SORT_REG_LONG, KID_SORT_LDS,
+  KID_SUBPIX = 0, KID_PREPROCESS, KID_BIN_SCATTER, KID_PLAN_SCAN, KID_FINE_BIN, KID_SORT_SMALL, KID_SORT_REG_LONG, KID_SORT_LDS,
   KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN, KID_PREPASS_FWD, KID_PREPASS_BWD, KID_FILTER3D, KID_DENSIFY_STATS, KID_ADAM, KID_SH_EVAL_FWD, KID_SH_EVAL_BWD, KID_COMPACT_SCAN, KID_COMPACT_GATHER, KID_DENSIFY,
   KID_COUNT
 };
@@ -134,16 +134,26 @@ struct GeomView {
   uint2* dup;       // [N] (first duplicate index, duplicate count) of every Gaussian
   uint4* big_list;  // [N] work list of big_walk_kernel: (Gaussian id, tile range x0 | x1 << 16, y0 | y1 << 16, 0);
                     //     HDR_BIG_COUNT entries, written only for splats that reach more than BIG_WALK coarse bins
+  uint4* pairs;     // [NB][PAIRS_PER_BLOCK] two-pass binning: the coarse items of preprocess workgroup b, densely from
+                    //     pairs[b][0] -- (Gaussian id, depth bits, first dup, tile mask | coarse bin << 16) -- written
+                    //     with plain stores (no atomics); bin_scatter_kernel moves them into the bins' slabs
+  uint32_t* block_items;  // [NB] how many
 };
+constexpr int PAIRS_PER_BLOCK = PRE_BLOCK * 6;   // a thread emits at most BIG_WALK (= 6) items itself (raster_fwd.hip)
 static inline size_t geom_bytes(int64_t N) {
-  return align_up((size_t)N * 16 * REC_F4, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N * 16, 256);
+  const int64_t NB = (N + PRE_BLOCK - 1) / PRE_BLOCK;
+  return align_up((size_t)N * 16 * REC_F4, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N * 16, 256) +
+         align_up((size_t)NB * PAIRS_PER_BLOCK * 16, 256) + align_up((size_t)NB * 4, 256);
 }
 static inline GeomView geom_view(void* base, int64_t N) {
   GeomView g;
+  const int64_t NB = (N + PRE_BLOCK - 1) / PRE_BLOCK;
   char* p = (char*)base;
   g.rec = (float4*)p; p += align_up((size_t)N * 16 * REC_F4, 256);
   g.dup = (uint2*)p; p += align_up((size_t)N * 8, 256);
-  g.big_list = (uint4*)p;
+  g.big_list = (uint4*)p; p += align_up((size_t)N * 16, 256);
+  g.pairs = (uint4*)p; p += align_up((size_t)NB * PAIRS_PER_BLOCK * 16, 256);
+  g.block_items = (uint32_t*)p;
   return g;
 }
 

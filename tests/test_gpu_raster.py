@@ -347,3 +347,22 @@ def test_skewed_workgroups_and_the_duplicate_index_pools():
         parity.assert_grad_close(k, out["grads"][k], G[k])
     share = float((R.tiles_touched()[:1024] > 0).sum())
     assert share > 0   # the big splats are on screen
+
+
+@pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p"])
+def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
+    """Two-pass binning (pair list + bin_scatter_kernel, the default) and the one-pass path with one device atomic per
+    coarse item (SFGS_BINNING=direct) build the same frame: duplicate indices come from the same scan and every tile list
+    is sorted by (depth, id), so images, radii, counters and every gradient are equal bit for bit."""
+    c = CASES[case]
+    frame, g = scene(c["n"], c["W"], c["H"], seed=11, **c["kw"])
+    gc, gd = upstream_grads(c["W"], c["H"], 4)
+    a = run_hip(frame, g, gc, gd)
+    monkeypatch.setenv("SFGS_BINNING", "direct")
+    b = run_hip(frame, g, gc, gd)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in ("num_duplicates", "num_duplicates_ref", "num_visible", "max_coarse_bin", "max_tile_list"):
+        assert a["counters"][k] == b["counters"][k], k
+    for k in a["grads"]:
+        np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)

@@ -1,0 +1,8 @@
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r3x; mkdir -p $O
+E=$PWD/skyfall-gs_amd/sfgs/_exp
+( timeout 400 python -m pytest tests/test_gpu_raster.py -m gpu -q -x --timeout=120 2>&1 | tail -4 ) | tee $O/raster2.log
+for r in 1 2 3; do for v in tp tps; do SFGS_LIB=$E/lib_$v.so timeout 100 python bench.py --forward-only --cpu-sample 0 --steps 100 --warmup 30 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$v fwd-only', round(d['ms_per_step'],4), round(d['value'],1), {k: round(v,4) for k,v in d['roofline_step']['kernel_ms_per_step'].items()})"; done; done | tee $O/ab_tps.log
