@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
 
 // ---- profiler: HIP events recorded on the launch stream around every kernel ---------------------
 static const char* const kKernelNames[KID_COUNT] = {
-    "subpix_bound", "preprocess", "bin_scatter", "plan_scan", "fine_bin", "sort_tiles_small", "sort_tiles_reg_long",
+    "subpix_bound", "preprocess", "bin_count", "bin_rank", "bin_scatter", "plan_scan", "fine_bin", "sort_tiles_small", "sort_tiles_reg_long",
     "sort_tiles_lds", "composite_fwd", "composite_bwd", "preprocess_bwd", "ssim_fwd", "ssim_mean", "ssim_bwd",
     "knn_dist2", "prepass_fwd", "prepass_bwd", "filter3d", "densify_stats", "adam", "sh_eval_fwd", "sh_eval_bwd", "compact_scan", "compact_gather", "densify"};
 

@@ -371,68 +371,74 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1s: second pass of the two-pass binning. One workgroup per SCATTER_BLOCKS consecutive preprocess workgroups
-// (~11 000 pairs on the headline scene):
-//   1. count its pairs per coarse bin in LDS (items and tile hits);
-//   2. reserve every touched bin's slab range with ONE 64-bit device atomic (items | hits, the counter format of the
-//      direct path: big splats still append to the same counters directly) -- 0.5 M device atomics instead of one per
-//      pair (2.7 M at the chip's 26.7 G/s were 0.10 ms of preprocess);
-//   3. counting-sort the pairs by bin (positions from LDS cursors, 16-bit pair indices in LDS) and
-//   4. write them in SORTED order: consecutive lanes store consecutive items of a bin's run, so a run of ~5 items leaves
-//      the CU as one or two line writes instead of five scattered 16-byte sector writes (the slab lines are shared by
-//      workgroups on all XCDs: every partial line goes to memory on its own).
-// The order of a bin's items is irrelevant (its tiles are sorted by (depth, id) afterwards).
-#ifndef SFGS_SCATTER_BLOCKS
-#define SFGS_SCATTER_BLOCKS 32
-#endif
-#ifndef SFGS_SCATTER_ABLATE   // experiment builds only: 1 no device atomics, 2 no sorted stores, 4 no step 3 / 4, 8 no counting
+// K1s: second pass of the two-pass binning = ONE RADIX PASS over the (coarse bin, item) pairs with the coarse bin as the
+// digit, in the classic three steps -- no device atomics at all:
+//   bin_count_kernel    one workgroup per SCATTER_BLOCKS consecutive preprocess workgroups (~11 000 pairs on the headline
+//                       scene) counts its pairs per coarse bin in LDS (items, tile hits) and writes its row of the
+//                       [workgroup][bin] count matrices;
+//   bin_rank_kernel     column scan: for every bin the first slab rank of every workgroup's run (behind the items the big
+//                       splats appended directly, with atomics, while preprocess ran), and the bin's totals into its
+//                       64-bit counter (items | hits, the format of the direct path);
+//   bin_scatter_kernel  the same workgroups again: counting-sort their pairs by bin (LDS cursors, 16-bit pair indices)
+//                       and write them in SORTED order -- consecutive lanes store consecutive items of a bin's run.
+// With one returning device atomic per (workgroup, bin) instead (first version of this round: 0.5 M atomics, all
+// workgroups hitting the same 2 040 counter lines at the same moment) the reservation alone took 36 of the pass's 73 us
+// (profiles/r3_bin_scatter_ablation.txt). The order of a bin's items is irrelevant (its tiles are sorted afterwards).
+#ifndef SFGS_SCATTER_ABLATE   // experiment builds only: 2 no sorted stores, 4 no position / store sweeps, 8 no counting
 #define SFGS_SCATTER_ABLATE 0
 #endif
-constexpr int SCATTER_NT = 1024, SCATTER_BLOCKS = SFGS_SCATTER_BLOCKS, SCATTER_BINS = 4096, SCATTER_IDX = 15360;
+#ifndef SFGS_SCATTER_MLP
+#define SFGS_SCATTER_MLP 4
+#endif
+constexpr int SCATTER_NT = 1024, SCATTER_BINS = 4096, SCATTER_IDX = 15360, SCATTER_MLP = SFGS_SCATTER_MLP;
 static_assert(SCATTER_BLOCKS * PAIRS_PER_BLOCK <= 65536, "16-bit pair indices");
-__global__ void __launch_bounds__(SCATTER_NT)
-bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
-                   uint32_t* __restrict__ coarse_count, uint4* __restrict__ slabs, unsigned coarse_capacity,
-                   unsigned long long* __restrict__ hdr) {
-  __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
-  __shared__ unsigned s_red[SCATTER_NT / 64 + 1];
-  __shared__ unsigned s_items[SCATTER_BINS];   // pairs of this workgroup per bin; then (bin's first slab rank - first sorted position)
-  __shared__ unsigned s_hits[SCATTER_BINS];    // their tile hits; then the bin's cursor in the sorted order
-  __shared__ unsigned short s_idx[SCATTER_IDX];   // pair index at every sorted position
+static_assert(SCATTER_BLOCKS <= 64, "one wave scans the block counts");
+
+// prefix sums of the workgroup's SCATTER_BLOCKS block counts -> s_prefix[0 .. nblk]; returns the total
+__device__ __forceinline__ unsigned scatter_prefix(const uint32_t* __restrict__ block_items, int b0, int nblk,
+                                                   unsigned* s_prefix) {
   const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * SCATTER_BLOCKS, nblk = min(SCATTER_BLOCKS, NB - b0);
   if (tid < 64) {
-    static_assert(SCATTER_BLOCKS <= 64, "one wave scans the block counts");
     const unsigned c = tid < nblk ? block_items[b0 + tid] : 0u;
     const unsigned incl = wave_incl_scan_u32(c);
     if (tid < SCATTER_BLOCKS) s_prefix[tid + 1] = incl;
     if (tid == 0) s_prefix[0] = 0u;
   }
   __syncthreads();
-  const unsigned total = s_prefix[nblk];
-  if (total == 0u) return;
-  // flat pair index -> address: the preprocess workgroup it belongs to by binary search over <= 33 prefix sums
-  auto pair_ptr = [&](unsigned i) {
-    int lo = 0, hi = nblk;                 // s_prefix[lo] <= i < s_prefix[hi]
+  return s_prefix[nblk];
+}
+// flat pair index -> address: the preprocess workgroup it belongs to by binary search over <= 33 prefix sums
+__device__ __forceinline__ const uint4* scatter_pair(const uint4* __restrict__ pairs, const unsigned* s_prefix, int b0,
+                                                     int nblk, unsigned i) {
+  int lo = 0, hi = nblk;                 // s_prefix[lo] <= i < s_prefix[hi]
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {       // 2^6 > SCATTER_BLOCKS
-      const int mid = (lo + hi) >> 1;
-      if (hi - lo > 1) { if (s_prefix[mid] <= i) lo = mid; else hi = mid; }
-    }
-    return pairs + (size_t)(b0 + lo) * PAIRS_PER_BLOCK + (i - s_prefix[lo]);
-  };
+  for (int it = 0; it < 6; ++it) {       // 2^6 > SCATTER_BLOCKS
+    const int mid = (lo + hi) >> 1;
+    if (hi - lo > 1) { if (s_prefix[mid] <= i) lo = mid; else hi = mid; }
+  }
+  return pairs + (size_t)(b0 + lo) * PAIRS_PER_BLOCK + (i - s_prefix[lo]);
+}
+
+__global__ void __launch_bounds__(SCATTER_NT)
+bin_count_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
+                 uint32_t* __restrict__ sc_cnt, uint32_t* __restrict__ sc_hits) {
+  __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
+  __shared__ unsigned s_items[SCATTER_BINS], s_hits[SCATTER_BINS];
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * SCATTER_BLOCKS, nblk = min(SCATTER_BLOCKS, NB - b0);
+  const unsigned total = scatter_prefix(block_items, b0, nblk, s_prefix);
   for (int r0 = 0; r0 < NCB; r0 += SCATTER_BINS) {   // one round up to 4 096 bins (1080p: 2 040, 2160p: 8 160)
     const int nbins = min(SCATTER_BINS, NCB - r0);
     for (int i = tid; i < nbins; i += SCATTER_NT) { s_items[i] = 0u; s_hits[i] = 0u; }
     __syncthreads();
-    // ---- 1. count ----
     if (!(SFGS_SCATTER_ABLATE & 8))
-    for (unsigned i0 = tid; i0 < total; i0 += 4 * SCATTER_NT) {   // four independent loads in flight per thread
-      unsigned w[4];
+    for (unsigned i0 = tid; i0 < total; i0 += SCATTER_MLP * SCATTER_NT) {   // independent loads in flight per thread
+      unsigned w[SCATTER_MLP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) w[u] = i0 + u * SCATTER_NT < total ? pair_ptr(i0 + u * SCATTER_NT)->w : 0u;
+      for (int u = 0; u < SCATTER_MLP; ++u)
+        w[u] = i0 + u * SCATTER_NT < total ? scatter_pair(pairs, s_prefix, b0, nblk, i0 + u * SCATTER_NT)->w : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SCATTER_MLP; ++u) {
         const int cb = (int)(w[u] >> 16) - r0;
         if ((w[u] & 0xffffu) && cb >= 0 && cb < nbins) {
           atomicAdd(&s_items[cb], 1u);
@@ -441,70 +447,136 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
       }
     }
     __syncthreads();
-    // ---- 2. reserve, and scan the counts into sorted positions (a thread's four bins are neighbours in that order) ----
-    {  // the (up to four) reservations of a thread are all in flight before the first returned rank is used: named 64-bit
-       // registers and one common wait (an array, or a re-used half of a returned pair, makes the compiler wait per atomic)
-      static_assert(SCATTER_BINS <= 4 * SCATTER_NT, "four bins per thread");
-      unsigned long long rs0 = 0ull, rs1 = 0ull, rs2 = 0ull, rs3 = 0ull;
-      unsigned c0, c1, c2, c3;
-#define SFGS_RESERVE(U, RS, C)                                                                                        \
-  { const int i = tid + U * SCATTER_NT;                                                                               \
-    C = i < nbins ? s_items[i] : 0u;                                                                                  \
-    if (C && !(SFGS_SCATTER_ABLATE & 1))                                                                              \
-      RS = atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)(r0 + i) * CC_STRIDE]),              \
-                          (unsigned long long)C | ((unsigned long long)s_hits[i] << 32)); }
-      SFGS_RESERVE(0, rs0, c0) SFGS_RESERVE(1, rs1, c1) SFGS_RESERVE(2, rs2, c2) SFGS_RESERVE(3, rs3, c3)
-#undef SFGS_RESERVE
-      unsigned round_total;
-      const unsigned base = block_excl_scan_u32<SCATTER_NT>(c0 + c1 + c2 + c3, &round_total, s_red);   // (syncs: s_hits read above)
-      asm volatile("" :: "v"(rs0), "v"(rs1), "v"(rs2), "v"(rs3));
-      const unsigned p0 = base, p1 = p0 + c0, p2 = p1 + c1, p3 = p2 + c2;
-      if (tid < nbins) { s_items[tid] = (unsigned)rs0 - p0; s_hits[tid] = p0; }
-      if (tid + SCATTER_NT < nbins) { s_items[tid + SCATTER_NT] = (unsigned)rs1 - p1; s_hits[tid + SCATTER_NT] = p1; }
-      if (tid + 2 * SCATTER_NT < nbins) { s_items[tid + 2 * SCATTER_NT] = (unsigned)rs2 - p2; s_hits[tid + 2 * SCATTER_NT] = p2; }
-      if (tid + 3 * SCATTER_NT < nbins) { s_items[tid + 3 * SCATTER_NT] = (unsigned)rs3 - p3; s_hits[tid + 3 * SCATTER_NT] = p3; }
-      __syncthreads();
-      // ---- 3. sorted position of every pair; those beyond the index buffer (a workgroup with > 15 360 pairs in this round
-      //         of bins) are written at once, unsorted ----
-      if (!(SFGS_SCATTER_ABLATE & 4))
-      for (unsigned i0 = tid; i0 < total; i0 += 4 * SCATTER_NT) {
-        uint4 it[4];
+    for (int i = tid; i < nbins; i += SCATTER_NT) {   // the whole row, zeros included: the matrices are not cleared
+      sc_cnt[(size_t)blockIdx.x * NCB + r0 + i] = s_items[i];
+      sc_hits[(size_t)blockIdx.x * NCB + r0 + i] = s_hits[i];
+    }
+    __syncthreads();
+  }
+}
+
+// 16 bins (columns) per workgroup, 64 row groups: thread (g, c) owns rows [g R, (g + 1) R) of column c (R = 4 with the
+// headline's 245 rows); 128 workgroups at 1080p
+constexpr int RANK_COLS = 16, RANK_GROUPS = 64;
+__global__ void __launch_bounds__(RANK_COLS * RANK_GROUPS)
+bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_hits,
+                uint32_t* __restrict__ sc_base, uint32_t* __restrict__ coarse_count) {
+  __shared__ unsigned s_c[RANK_GROUPS][RANK_COLS], s_h[RANK_GROUPS][RANK_COLS];
+  const int c = threadIdx.x % RANK_COLS, g = threadIdx.x / RANK_COLS;
+  const int bin = min(blockIdx.x * RANK_COLS + c, NCB - 1);      // (lanes beyond the last bin repeat it and write nothing)
+  const bool live = blockIdx.x * RANK_COLS + c < NCB;
+  const int R = (NWG + RANK_GROUPS - 1) / RANK_GROUPS;
+  const int w0 = min(g * R, NWG), w1 = min(w0 + R, NWG);
+  unsigned long long* counter = reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)bin * CC_STRIDE]);
+  const unsigned long long old = *counter;           // what the big splats appended directly (preprocess / big_walk are done)
+  unsigned sc = 0u, sh = 0u;
+  for (int w = w0; w < w1; w += 4) {                  // four rows in flight (clamped: no predicated loads)
+    unsigned tc[4], th[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          it[u] = i0 + u * SCATTER_NT < total ? *pair_ptr(i0 + u * SCATTER_NT) : make_uint4(0u, 0u, 0u, 0u);
+    for (int u = 0; u < 4; ++u) {
+      const size_t at = (size_t)min(w + u, w1 - 1) * NCB + bin;
+      tc[u] = sc_cnt[at]; th[u] = sc_hits[at];
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned m = it[u].w & 0xffffu;
-          const int cb = (int)(it[u].w >> 16) - r0;
-          if (m && cb >= 0 && cb < nbins) {
-            const unsigned pos = atomicAdd(&s_hits[cb], 1u);
-            if (pos < (unsigned)SCATTER_IDX) {
-              s_idx[pos] = (unsigned short)(i0 + u * SCATTER_NT);
-            } else {
-              const unsigned rank = s_items[cb] + pos;
-              if (rank < coarse_capacity) slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, m);
-              else hdr[HDR_OVERFLOW] = 1ull;
-            }
+    for (int u = 0; u < 4; ++u)
+      if (w + u < w1) { sc += tc[u]; sh += th[u]; }
+  }
+  s_c[g][c] = sc; s_h[g][c] = sh;
+  __syncthreads();                                   // (every row group has read the counter BEFORE the last one rewrites it)
+  unsigned run = (unsigned)old;
+  for (int q = 0; q < g; ++q) run += s_c[q][c];
+  for (int w = w0; w < w1; w += 4) {
+    unsigned tc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tc[u] = sc_cnt[(size_t)min(w + u, w1 - 1) * NCB + bin];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (w + u < w1) {
+        if (live) sc_base[(size_t)(w + u) * NCB + bin] = run;
+        run += tc[u];
+      }
+  }
+  if (g == RANK_GROUPS - 1 && live) {   // (its `run` is the bin's new item count; empty trailing groups carry it along)
+    unsigned hits = (unsigned)(old >> 32);
+    for (int q = 0; q < RANK_GROUPS; ++q) hits += s_h[q][c];
+    *counter = (unsigned long long)run | ((unsigned long long)hits << 32);
+  }
+}
+
+__global__ void __launch_bounds__(SCATTER_NT)
+bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
+                   const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_base,
+                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
+  __shared__ unsigned s_red[SCATTER_NT / 64 + 1];
+  __shared__ unsigned s_delta[SCATTER_BINS];   // bin's first slab rank - its first sorted position
+  __shared__ unsigned s_cur[SCATTER_BINS];     // the bin's cursor in the sorted order
+  __shared__ unsigned short s_idx[SCATTER_IDX];   // pair index at every sorted position
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * SCATTER_BLOCKS, nblk = min(SCATTER_BLOCKS, NB - b0);
+  const unsigned total = scatter_prefix(block_items, b0, nblk, s_prefix);
+  if (total == 0u) return;
+  for (int r0 = 0; r0 < NCB; r0 += SCATTER_BINS) {
+    const int nbins = min(SCATTER_BINS, NCB - r0);
+    // counts -> sorted positions (a thread's four bins are neighbours in that order)
+    static_assert(SCATTER_BINS <= 4 * SCATTER_NT, "four bins per thread");
+    unsigned c[4], base[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * SCATTER_NT;
+      c[u] = i < nbins ? sc_cnt[(size_t)blockIdx.x * NCB + r0 + i] : 0u;
+      base[u] = i < nbins ? sc_base[(size_t)blockIdx.x * NCB + r0 + i] : 0u;
+    }
+    unsigned round_total;
+    unsigned p = block_excl_scan_u32<SCATTER_NT>(c[0] + c[1] + c[2] + c[3], &round_total, s_red);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * SCATTER_NT;
+      if (i < nbins) { s_delta[i] = base[u] - p; s_cur[i] = p; }
+      p += c[u];
+    }
+    __syncthreads();
+    // sorted position of every pair; those beyond the index buffer (a workgroup with > 15 360 pairs in this round of bins)
+    // are written at once, unsorted
+    if (!(SFGS_SCATTER_ABLATE & 4))
+    for (unsigned i0 = tid; i0 < total; i0 += SCATTER_MLP * SCATTER_NT) {
+      uint4 it[SCATTER_MLP];
+#pragma unroll
+      for (int u = 0; u < SCATTER_MLP; ++u)
+        it[u] = i0 + u * SCATTER_NT < total ? *scatter_pair(pairs, s_prefix, b0, nblk, i0 + u * SCATTER_NT)
+                                            : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int u = 0; u < SCATTER_MLP; ++u) {
+        const unsigned m = it[u].w & 0xffffu;
+        const int cb = (int)(it[u].w >> 16) - r0;
+        if (m && cb >= 0 && cb < nbins) {
+          const unsigned pos = atomicAdd(&s_cur[cb], 1u);
+          if (pos < (unsigned)SCATTER_IDX) {
+            s_idx[pos] = (unsigned short)(i0 + u * SCATTER_NT);
+          } else {
+            const unsigned rank = s_delta[cb] + pos;
+            if (rank < coarse_capacity) slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, m);
+            else hdr[HDR_OVERFLOW] = 1ull;
           }
         }
       }
-      __syncthreads();
-      // ---- 4. write in sorted order ----
-      const unsigned nsorted = (SFGS_SCATTER_ABLATE & 6) ? 0u : min(round_total, (unsigned)SCATTER_IDX);
-      for (unsigned q0 = tid; q0 < nsorted; q0 += 4 * SCATTER_NT) {
-        uint4 it[4];
+    }
+    __syncthreads();
+    const unsigned nsorted = (SFGS_SCATTER_ABLATE & 6) ? 0u : min(round_total, (unsigned)SCATTER_IDX);
+    for (unsigned q0 = tid; q0 < nsorted; q0 += SCATTER_MLP * SCATTER_NT) {
+      uint4 it[SCATTER_MLP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          it[u] = q0 + u * SCATTER_NT < nsorted ? *pair_ptr(s_idx[q0 + u * SCATTER_NT]) : make_uint4(0u, 0u, 0u, 0u);
+      for (int u = 0; u < SCATTER_MLP; ++u)
+        it[u] = q0 + u * SCATTER_NT < nsorted ? *scatter_pair(pairs, s_prefix, b0, nblk, s_idx[q0 + u * SCATTER_NT])
+                                              : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (q0 + u * SCATTER_NT < nsorted) {
-            const int cb = (int)(it[u].w >> 16) - r0;
-            const unsigned rank = s_items[cb] + (q0 + u * SCATTER_NT);
-            if (rank < coarse_capacity)
-              slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, it[u].w & 0xffffu);
-            else hdr[HDR_OVERFLOW] = 1ull;
-          }
+      for (int u = 0; u < SCATTER_MLP; ++u) {
+        if (q0 + u * SCATTER_NT < nsorted) {
+          const int cb = (int)(it[u].w >> 16) - r0;
+          const unsigned rank = s_delta[cb] + (q0 + u * SCATTER_NT);
+          if (rank < coarse_capacity)
+            slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, it[u].w & 0xffffu);
+          else hdr[HDR_OVERFLOW] = 1ull;
         }
       }
     }
@@ -1499,10 +1571,16 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
     }
     SFGS_POST_LAUNCH("preprocess", stream, frame->debug);
     if (two_pass) {
-      ProfScope ps_(KID_BIN_SCATTER, stream);
-      hipLaunchKernelGGL(bin_scatter_kernel, dim3((NB + SCATTER_BLOCKS - 1) / SCATTER_BLOCKS), dim3(SCATTER_NT), 0, stream,
-                         NB, (int)NCB, gv.pairs, gv.block_items, tv.coarse_count, bv.slabs, (unsigned)coarse_capacity,
-                         tv.hdr);
+      const int NWG = (int)scatter_groups(N);
+      { ProfScope ps_(KID_BIN_COUNT, stream);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(NWG), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, gv.pairs,
+                           gv.block_items, tv.sc_cnt, tv.sc_hits); }
+      { ProfScope ps_(KID_BIN_RANK, stream);
+        hipLaunchKernelGGL(bin_rank_kernel, dim3(((int)NCB + RANK_COLS - 1) / RANK_COLS), dim3(RANK_COLS * RANK_GROUPS), 0,
+                           stream, NWG, (int)NCB, tv.sc_cnt, tv.sc_hits, tv.sc_base, tv.coarse_count); }
+      { ProfScope ps_(KID_BIN_SCATTER, stream);
+        hipLaunchKernelGGL(bin_scatter_kernel, dim3(NWG), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, gv.pairs,
+                           gv.block_items, tv.sc_cnt, tv.sc_base, bv.slabs, (unsigned)coarse_capacity, tv.hdr); }
     }
     SFGS_POST_LAUNCH("bin_scatter", stream, frame->debug);
   }

@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 
 // ---- optional per-kernel profiler (api.cpp): HIP events on the launch stream ---------------------
 enum KernelId {
-  KID_SUBPIX = 0, KID_PREPROCESS, KID_BIN_SCATTER, KID_PLAN_SCAN, KID_FINE_BIN, KID_SORT_SMALL, KID_SORT_REG_LONG, KID_SORT_LDS,
+  KID_SUBPIX = 0, KID_PREPROCESS, KID_BIN_COUNT, KID_BIN_RANK, KID_BIN_SCATTER, KID_PLAN_SCAN, KID_FINE_BIN, KID_SORT_SMALL, KID_SORT_REG_LONG, KID_SORT_LDS,
   KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN, KID_PREPASS_FWD, KID_PREPASS_BWD, KID_FILTER3D, KID_DENSIFY_STATS, KID_ADAM, KID_SH_EVAL_FWD, KID_SH_EVAL_BWD, KID_COMPACT_SCAN, KID_COMPACT_GATHER, KID_DENSIFY,
   KID_COUNT
 };
@@ -184,7 +184,14 @@ struct TilesView {
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
+  // two-pass binning without device atomics: per (scatter workgroup, coarse bin) the workgroup's items, their tile hits
+  // and -- after the column scan -- the first slab rank of its run ([scatter_groups(N)][N_cb] each, fully rewritten per frame)
+  uint32_t *sc_cnt, *sc_hits, *sc_base;
 };
+#ifndef SFGS_SCATTER_BLOCKS
+#define SFGS_SCATTER_BLOCKS 32
+#endif
+constexpr int SCATTER_BLOCKS = SFGS_SCATTER_BLOCKS;   // preprocess workgroups per scatter workgroup
 static inline int tiles8_x(int W) { return (W + TILE_BIN - 1) / TILE_BIN; }
 static inline int tiles8_y(int H) { return (H + TILE_BIN - 1) / TILE_BIN; }
 static inline int64_t tiles8(int W, int H) { return (int64_t)tiles8_x(W) * tiles8_y(H); }
@@ -192,6 +199,7 @@ static inline int coarse_x(int W) { return (tiles8_x(W) + COARSE - 1) / COARSE; 
 static inline int coarse_y(int H) { return (tiles8_y(H) + COARSE - 1) / COARSE; }
 static inline int64_t coarse_bins(int W, int H) { return (int64_t)coarse_x(W) * coarse_y(H); }
 static inline int64_t pre_blocks(int64_t N) { return (N + PRE_BLOCK - 1) / PRE_BLOCK; }
+static inline int64_t scatter_groups(int64_t N) { return (pre_blocks(N) + SCATTER_BLOCKS - 1) / SCATTER_BLOCKS; }
 static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* total) {
   TilesView t;
   const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1, NCB = coarse_bins(W, H);
@@ -205,6 +213,10 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   t.long_tiles = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
+  const size_t msz = align_up((size_t)scatter_groups(N) * NCB * 4, 256);
+  t.sc_cnt = (uint32_t*)(p + off); off += msz;
+  t.sc_hits = (uint32_t*)(p + off); off += msz;
+  t.sc_base = (uint32_t*)(p + off); off += msz;
   if (total) *total = off;
   return t;
 }
