@@ -137,8 +137,9 @@ typedef struct SfgsGaussianGrads {
 /* Sizes (bytes) of the caller-owned scratch blobs. */
 typedef struct SfgsRasterSizes {
   uint32_t struct_size;
-  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, tile ranges, duplicate offsets      */
-  size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials */
+  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, duplicate offsets, the binning's pair list  */
+  size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials, the
+                            binning radix pass's [workgroup][coarse bin] matrices                 */
   size_t bins_bytes;     /* f(D, coarse_capacity): coarse-bin slabs, per-tile duplicates, sorted lists */
   size_t image_bytes;    /* f(W,H,D): per-pixel last contributor, final T, raw depth, and one 8-byte
                             blended-entries mask per pixel and 64-entry list batch (for backward) */
