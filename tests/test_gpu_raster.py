@@ -43,6 +43,13 @@ CASES = {
     "lists_3k_equal_depth": dict(n=3000, W=24, H=24, kw=dict(zrange=(5., 5.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
     "lists_3k_few_depths": dict(n=3000, W=24, H=24, kw=dict(zrange=(5., 5.000002), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
 }
+# Shapes that only the binning's radix pass cares about, compared with the one-pass path (which the cases above pin to the
+# oracle) for EQUALITY: 8 160 coarse bins = two rounds of its 4 096 LDS counters; ~3 coarse items per Gaussian = the first
+# scatter workgroup (8 192 Gaussians) holds more pairs than its 15 360 sorted-order index slots, the rest goes out unsorted.
+BINNING_CASES = {
+    "uhd_two_bin_rounds": dict(n=30000, W=3840, H=2160, kw=dict(zrange=(250., 350.), scale_range=(0.1, 1.2))),
+    "mid_splats_many_items": dict(n=20000, W=640, H=360, kw=dict(zrange=(40., 60.), scale_range=(0.3, 0.7), opacity_range=(0.02, 0.2))),
+}
 
 
 def run_hip(frame, g, gc=None, gd=None, backward=True, debug=True, depth_mode=0, full_counters=True):
@@ -349,12 +356,13 @@ def test_skewed_workgroups_and_the_duplicate_index_pools():
     assert share > 0   # the big splats are on screen
 
 
-@pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p"])
+@pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p", "uhd_two_bin_rounds",
+                                  "mid_splats_many_items"])
 def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
     """Two-pass binning (pair list + bin_scatter_kernel, the default) and the one-pass path with one device atomic per
     coarse item (SFGS_BINNING=direct) build the same frame: duplicate indices come from the same scan and every tile list
     is sorted by (depth, id), so images, radii, counters and every gradient are equal bit for bit."""
-    c = CASES[case]
+    c = CASES.get(case) or BINNING_CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=11, **c["kw"])
     gc, gd = upstream_grads(c["W"], c["H"], 4)
     a = run_hip(frame, g, gc, gd)
