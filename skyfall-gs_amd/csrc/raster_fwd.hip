@@ -455,9 +455,29 @@ bin_count_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_
   }
 }
 
-// 16 bins (columns) per workgroup, 64 row groups: thread (g, c) owns rows [g R, (g + 1) R) of column c (R = 4 with the
-// headline's 245 rows); 128 workgroups at 1080p
+// 16 bins (columns) per workgroup, 64 row groups: thread (g, c) owns positions [g R, (g + 1) R) of column c's rank order
+// (R = 4 with the headline's 245 rows); 128 workgroups at 1080p
 constexpr int RANK_COLS = 16, RANK_GROUPS = 64;
+// Rank ORDER of the scatter workgroups inside a bin's slab: XCD-major (workgroup w runs on XCD w mod 8), so that the ~31
+// workgroups of one XCD own ONE contiguous stretch of every slab and its partial lines are completed inside that XCD's L2
+// instead of being written back piecemeal from eight of them. k-th in rank order -> workgroup (matrix row).
+#ifndef SFGS_RANK_XCD
+#define SFGS_RANK_XCD 1
+#endif
+__device__ __forceinline__ int rank_row(int k, int NWG) {
+#if SFGS_RANK_XCD
+  const int q = NWG >> 3, r = NWG & 7;               // XCDs x < r have q + 1 workgroups, the others q
+  int x = 0, first = 0;                              // (compares instead of integer divisions)
+#pragma unroll
+  for (int t = 1; t < 8; ++t) {
+    const int st = min(t, r) * (q + 1) + max(t - r, 0) * q;   // rank position of XCD t's first workgroup
+    if (k >= st) { x = t; first = st; }
+  }
+  return (k - first) * 8 + x;
+#else
+  return k;
+#endif
+}
 __global__ void __launch_bounds__(RANK_COLS * RANK_GROUPS)
 bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_hits,
                 uint32_t* __restrict__ sc_base, uint32_t* __restrict__ coarse_count) {
@@ -474,7 +494,7 @@ bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uin
     unsigned tc[4], th[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const size_t at = (size_t)min(w + u, w1 - 1) * NCB + bin;
+      const size_t at = (size_t)rank_row(min(w + u, w1 - 1), NWG) * NCB + bin;
       tc[u] = sc_cnt[at]; th[u] = sc_hits[at];
     }
 #pragma unroll
@@ -488,11 +508,11 @@ bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uin
   for (int w = w0; w < w1; w += 4) {
     unsigned tc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) tc[u] = sc_cnt[(size_t)min(w + u, w1 - 1) * NCB + bin];
+    for (int u = 0; u < 4; ++u) tc[u] = sc_cnt[(size_t)rank_row(min(w + u, w1 - 1), NWG) * NCB + bin];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (w + u < w1) {
-        if (live) sc_base[(size_t)(w + u) * NCB + bin] = run;
+        if (live) sc_base[(size_t)rank_row(w + u, NWG) * NCB + bin] = run;
         run += tc[u];
       }
   }
