@@ -201,7 +201,7 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 }
 
 template <int B>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(64 * CWG_WAVES, 4)
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
@@ -211,13 +211,15 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad,
                      const unsigned long long* __restrict__ hdr) {
   constexpr int ROW = BwdLds<B>::ROW;
-  __shared__ BwdLds<B> lds_all[4];
-  const unsigned sb = xcd_remap(blockIdx.x, nblk);
-  // readfirstlane: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  __shared__ BwdLds<B> lds_all[CWG_WAVES];
+  // wave-uniform: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
+  unsigned sb;
+  int wave, lw;
+  composite_wave_role((unsigned)nblk, sb, wave, lw);
+  const int lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
-  BwdLds<B>& lds = lds_all[wave];
+  BwdLds<B>& lds = lds_all[lw];
   if (lane < 3) lds.recs[B * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy entry (see phase 1)
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;
@@ -820,8 +822,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                        (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
                        (unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
-    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk, tv.tile_range,
-                       bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
+    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX,
+                       nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
                        dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);

@@ -1301,19 +1301,21 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
 // wave stores one 8-byte word per pixel and 64-entry batch (image blob, `hitmask`): the backward then walks each
 // pixel's own blended entries instead of re-testing every (pixel, entry) pair of the list (raster_bwd.hip).
 template <bool TRAIN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * CWG_WAVES)
 composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const float4* __restrict__ rec,
                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
                      uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out,
                      uint2* __restrict__ hitmask, uint32_t* __restrict__ tile_kmax, uint16_t* __restrict__ tile_dead,
                      const unsigned long long* __restrict__ hdr) {
-  __shared__ float4 stage[4][64 * 3];
-  __shared__ __attribute__((aligned(8))) unsigned char rowlist[4][4][64];
-  const unsigned sb = xcd_remap(blockIdx.x, nblk);
-  // readfirstlane: tells the compiler the wave index (hence the tile, its list range and every loop bound below)
-  // is wave-uniform -> scalar loads, SGPR loop counters and s_cbranch instead of exec-mask loops
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  __shared__ float4 stage[CWG_WAVES][64 * 3];
+  __shared__ __attribute__((aligned(8))) unsigned char rowlist[CWG_WAVES][4][64];
+  // wave-uniform (readfirstlane / blockIdx): the tile, its list range and every loop bound below are scalars -> scalar
+  // loads, SGPR loop counters and s_cbranch instead of exec-mask loops
+  unsigned sb;
+  int wave, lw;
+  composite_wave_role((unsigned)nblk, sb, wave, lw);
+  const int lane = threadIdx.x & 63;
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   const int W = kf.W, H = kf.H;
@@ -1329,7 +1331,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
   PixelFwd ps;
   pixel_fwd_init(ps, inside);
-  float4* st = stage[wave];
+  float4* st = stage[lw];
   // Software pipeline over batches of 64 list entries: the (dependent) id -> record gathers of batch i+1
   // are issued before batch i is composited, so their latency hides behind ~1600 VALU instructions.
   float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
@@ -1366,7 +1368,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const unsigned long long b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
     const unsigned long long b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
     // per-row compact entry lists (bytes) in LDS
-    unsigned char* Lw = &rowlist[wave][0][0];
+    unsigned char* Lw = &rowlist[lw][0][0];
     const int row = lane >> 4;
     const unsigned char* Lr = Lw + row * 64;
     if constexpr (!TRAIN) {
@@ -1854,11 +1856,11 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   { ProfScope ps_(KID_COMPOSITE_FWD, stream);
     if (image) {
       const ImageView iv = image_view(image, W, H, dup_capacity);
-      hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk,
+      hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX, nblk,
                          tv.tile_range, bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T,
                          iv.dacc, iv.hitmask, iv.tile_kmax, iv.tile_dead, tv.hdr);
     } else {
-      hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, kf, TX8, TY8, SX, nblk,
+      hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX, nblk,
                          tv.tile_range, bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, (uint32_t*)nullptr,
                          (float*)nullptr, (float*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr, tv.hdr);
     } }

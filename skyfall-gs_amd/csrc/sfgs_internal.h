@@ -315,6 +315,25 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
   return base + idx;
 }
 
+// Waves per workgroup of the two compositing kernels (compile-time experiment knob; the shipped value is 4 = one 16x16
+// super-tile per workgroup). With 1 every 8x8 tile is a workgroup of its own: the four waves of a super-tile never
+// synchronise anyway, and a one-wave workgroup gives its LDS and wave slot back the moment ITS list is done instead of
+// when the longest of four lists is (2: half a super-tile). Workgroups stay XCD-contiguous in super-tile order.
+#ifndef SFGS_COMPOSITE_WG_WAVES
+#define SFGS_COMPOSITE_WG_WAVES 4
+#endif
+constexpr int CWG_WAVES = SFGS_COMPOSITE_WG_WAVES;
+static_assert(CWG_WAVES == 4 || CWG_WAVES == 2 || CWG_WAVES == 1, "compositing workgroups: 4, 2 or 1 of a super-tile's tiles");
+// super-tile `sb`, wave-in-super-tile `wave` and wave-in-workgroup `lw` (its slice of the workgroup's LDS) of the calling
+// wave; all wave-uniform: the tile, its list range and every loop bound derived from them become SGPRs
+__device__ __forceinline__ void composite_wave_role(unsigned nblk, unsigned& sb, int& wave, int& lw) {
+  constexpr unsigned PER = 4 / CWG_WAVES;   // workgroups per super-tile
+  const unsigned l = xcd_remap(blockIdx.x, nblk * PER);
+  lw = CWG_WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  sb = l / PER;
+  wave = (int)(l % PER) * CWG_WAVES + lw;
+}
+
 // ---- per-Gaussian SH coefficient rows: 3K floats, 16-byte vector accesses when the row size allows -----------
 template <int CNT>
 __device__ __forceinline__ void load_row(const float* __restrict__ src, float (&dst)[CNT]) {
