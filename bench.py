@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--settle-steps", type=int, default=40,
+                    help="untimed steps between the warm-up's bookkeeping (which idles the GPU for a few ms) and the timed "
+                         "region: the timed steps start from the sustained clock state a training loop runs at")
     ap.add_argument("--prewarm-steps", type=int, default=50,
                     help="untimed steps BEFORE the W warm-up steps (the same count on every rank): the device needs ~30 ms of "
                          "sustained load to reach its sustained clock state (tools/diag_ramp.py: 1.35 -> 1.25 ms/step over "
@@ -257,6 +260,16 @@ def main():
     dom = max(warm, key=lambda k: warm[k]["ms_per_step"]) if warm else None
     dom_names = [n for n in warm_prof if (n.startswith("sort_tiles") and dom == "sort_tiles") or n == dom]
     L.profile_select(dom_names if dom_names else None)
+    # The bookkeeping above (event calibration, reading the warm-up's events back) leaves the GPU idle for a few
+    # milliseconds, and the device's power management answers idle time with a clock ramp that lasts ~30 steps
+    # (tools/diag_transient.py: after 20 ms of idle the next steps take 1.23, 1.14, 1.09, 1.07 ms per ten, 1.065 without
+    # the idle). A training loop never idles like that, so run a fixed number of untimed steps again and go from them
+    # STRAIGHT into the bracketing barrier + synchronize and the K timed steps.
+    L.profile_enable(False)
+    for _ in range(max(args.settle_steps, 0)):
+        step()
+    L.profile_enable(True)
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -340,7 +353,7 @@ def main():
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
                        "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
                        "collective_backend": backend if dist is not None else None,
-                       "prewarm_steps": args.prewarm_steps, "order": args.order},
+                       "prewarm_steps": args.prewarm_steps, "settle_steps": args.settle_steps, "order": args.order},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
