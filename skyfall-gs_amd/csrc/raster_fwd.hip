@@ -999,6 +999,163 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
   else sort_tile_in_registers<8>(tr.x, L, lane, items, sorted_id, sorted_dup);
 }
 
+// K3+K4a fused (round 3): SELECT + SORT, no per-tile item round trip through memory.
+// fine_bin expands the coarse items of a bin into 16-byte per-tile items in memory (111 MB written at the headline
+// scene) which the sort kernel reads straight back. Here a workgroup takes one ROW of four tiles of a coarse bin (wave =
+// tile): it reads the bin's slab once (21 KB on average; the bin's four workgroups are XCD-contiguous and share the L2),
+// hands every coarse item to the wave-private LDS lists of the row's tiles its mask names (12 bytes per entry: key =
+// depth bits << 32 | id, payload = duplicate index = the item's first index + the mask bits below the tile's; positions
+// from LDS atomics -- the order inside a list does not matter before the sort), then every wave sorts its list with the
+// register network and writes ids / duplicate indices in their final order. The tile's first slot inside the bin's slot
+// range (the plan's scan, bin_slots_needed) comes from one atomic per tile on the bin's OWN counter line (word 3: a cursor
+// in units of slots, 16 atomics per line; placement only -- which tile of a bin sits where never reaches a result). Lists
+// beyond REG_SORT_SMALL entries (rare) are written out as unsorted items by a second scan of the tile's wave and left to
+// the long-list kernels, exactly as fine_bin leaves them. The longest list of the frame is collected per bin (word 4 of
+// the line) and reduced by list_stats.
+constexpr int SS_CAP = REG_SORT_SMALL;
+struct alignas(16) SelectSortLds {
+  unsigned long long key[SS_CAP];
+  uint32_t pay[SS_CAP];
+};
+
+__global__ void __launch_bounds__(256)
+select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coarse_count,
+                   const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long slot_capacity,
+                   uint2* __restrict__ tile_range, uint4* __restrict__ items, uint32_t* __restrict__ long_tiles,
+                   unsigned long long* __restrict__ hdr, uint32_t* __restrict__ sorted_id,
+                   uint32_t* __restrict__ sorted_dup) {
+  __shared__ SelectSortLds lds_all[COARSE];
+  __shared__ unsigned s_cnt[COARSE];
+  // workgroup = one row of four tiles of a coarse bin (wave = tile); the four workgroups of a bin are neighbours on one XCD
+  const unsigned lb = xcd_remap(blockIdx.x, (unsigned)NCB * COARSE);
+  const int cb = (int)(lb / COARSE), q = (int)(lb % COARSE);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tx = (cb % CX) * COARSE + wave, ty = (cb / CX) * COARSE + q;
+  if (ty >= TY8) return;                             // the whole row lies below the image (uniform per workgroup)
+  const int t = ty * TX8 + tx;
+  const int bit = q * COARSE + wave;                 // this tile's bit of the coarse items' masks
+  uint32_t* line = coarse_count + (size_t)cb * CC_STRIDE;
+  const unsigned n = min(line[0], coarse_capacity);
+  if (n == 0) { if (lane == 0 && tx < TX8) tile_range[t] = make_uint2(0u, 0u); return; }   // uniform per workgroup
+  const uint4* slab = slabs + (size_t)cb * coarse_capacity;
+  SelectSortLds& lds = lds_all[wave];
+  // ---- scan: the workgroup reads the slab ONCE (R items per thread and round trip, unconditional loads from clamped
+  // indices) and hands every item to the lists of the row's tiles it touches. Positions come from LDS atomics: the order
+  // inside a list is irrelevant here, the sort below fixes it ((depth, id) keys are unique within a tile).
+  if (tid < COARSE) s_cnt[tid] = 0u;
+  __syncthreads();
+  constexpr int R = 8;
+  const unsigned rowmask = 0xfu << (q * COARSE);
+  for (unsigned i0 = 0; i0 < n; i0 += 256u * R) {
+    uint4 it[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) it[k] = slab[min(i0 + 256u * k + tid, n - 1u)];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      unsigned m = i0 + 256u * k + tid < n ? it[k].w & rowmask : 0u;
+      while (m) {
+        const int b = __builtin_ctz(m);
+        m &= m - 1;
+        const unsigned pos = atomicAdd(&s_cnt[b - q * COARSE], 1u);
+        if (pos < (unsigned)SS_CAP) {
+          SelectSortLds& dst = lds_all[b - q * COARSE];
+          dst.key[pos] = ((unsigned long long)it[k].y << 32) | it[k].x;
+          dst.pay[pos] = it[k].z + (unsigned)__popc(it[k].w & ((1u << b) - 1u));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tx >= TX8) return;                             // a tile right of the image: no item has its bit
+  const unsigned below = (1u << bit) - 1u;
+  const unsigned c = __builtin_amdgcn_readfirstlane((int)s_cnt[wave]);
+  // ---- the tile's slots: a stretch of the bin's range (scanned by the plan from the bin's tile hits) ---------------
+  const unsigned long long bin_base = line[2];
+  const unsigned need = bin_slots_needed(line[1]);
+  const bool dropped = bin_base + need > slot_capacity;   // the caller's slot capacity is too small (see fine_bin)
+  unsigned off = 0;
+  if (lane == 0) {
+    if (dropped) hdr[HDR_OVERFLOW] = 1ull;
+    else if (c) {
+      off = atomicAdd(&line[3], (c + LIST_ALIGN - 1) & ~(unsigned)(LIST_ALIGN - 1));
+      atomicMax(&line[4], c);
+    }
+  }
+  if (dropped || c == 0) { if (lane == 0) tile_range[t] = make_uint2(0u, 0u); return; }
+  if (c <= (unsigned)SS_CAP) {
+    // sort first, then address: the returning atomic is only needed by the stores behind the sort
+    const int L = (int)c;
+    auto finish = [&](auto epl_tag) {
+      constexpr int EPL = decltype(epl_tag)::value;
+      unsigned long long key[EPL];
+      unsigned pay[EPL];
+#pragma unroll
+      for (int r = 0; r < EPL; ++r) {
+        const int i = r * 64 + lane;
+        const unsigned long long k = lds.key[min(i, SS_CAP - 1)];
+        const unsigned p = lds.pay[min(i, SS_CAP - 1)];
+        key[r] = i < L ? k : ~0ull;
+        pay[r] = i < L ? p : 0u;
+      }
+      wave_bitonic_sort<EPL>(key, pay, lane);
+      const unsigned s = (unsigned)bin_base + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+      if (lane == 0) tile_range[t] = make_uint2(s, c);
+#pragma unroll
+      for (int r = 0; r < EPL; ++r) {
+        const int e = lane * EPL + r;
+        if (e < L) {
+          sorted_id[s + e] = (unsigned)(key[r] & 0xffffffffull);
+          sorted_dup[s + e] = pay[r];
+        }
+      }
+    };
+    if (L <= 64) finish(std::integral_constant<int, 1>{});
+    else if (L <= 128) finish(std::integral_constant<int, 2>{});
+    else if (L <= 256) finish(std::integral_constant<int, 4>{});
+    else finish(std::integral_constant<int, 8>{});
+    return;
+  }
+  // ---- long list: unsorted 16-byte items for the long-list kernels, like fine_bin ------------------------------------
+  const unsigned s = (unsigned)bin_base + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+  if (lane == 0) {
+    tile_range[t] = make_uint2(s, c);
+    long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)t;
+  }
+  unsigned done = 0;
+  for (unsigned i0 = 0; i0 < n; i0 += 64u) {
+    const uint4 it = slab[min(i0 + lane, n - 1u)];
+    const bool hit = i0 + lane < n && ((it.w >> bit) & 1u);
+    const unsigned long long b = __ballot(hit);
+    const unsigned pos = done + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    if (hit) items[s + pos] = make_uint4(it.x, it.y, it.z + (unsigned)__popc(it.w & below), 0u);
+    done += (unsigned)__popcll(b);
+  }
+}
+
+// longest list of the frame = max over the bins' maxima (select_sort_kernel), and the list statistics for the next
+// frame's plan (SfgsFrame.feedback). Run by the first workgroup of the (always launched) long-list kernel: 256 threads.
+__device__ void list_stats(int NCB, const uint32_t* __restrict__ coarse_count, unsigned long long* hdr,
+                           unsigned long long* __restrict__ feedback) {
+  __shared__ unsigned ls_part[4];
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < NCB; i += 256) m = max(m, coarse_count[(size_t)i * CC_STRIDE + 4]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+  if ((threadIdx.x & 63) == 0) ls_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long mx = max(max(ls_part[0], ls_part[1]), max(ls_part[2], ls_part[3]));
+    hdr[HDR_MAX_LIST] = mx;
+    if (feedback) {
+      feedback[FB_VALID] = 1ull;
+      feedback[FB_LONG_TILES] = hdr[HDR_LONG_COUNT];
+      feedback[FB_MAX_LIST] = mx;
+    }
+  }
+  __syncthreads();
+}
+
 // K4a': the same register network with EPL = 16 keys per lane for lists of 513..1024 entries (low-elevation views, dense
 // frames). A kernel of its own: 99 VGPRs would otherwise cut the occupancy of the common short lists. One wave per tile,
 // persistent over the device-side list of long tiles. (Longer lists: the bucketed sort of sort_tiles_long_kernel.)
@@ -1031,10 +1188,13 @@ template <int CAP>
 __global__ void __launch_bounds__(256, 3)   // three workgroups per CU: what the 52 KB of LDS allow
 sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
                        const uint2* __restrict__ tile_range, uint4* items, uint32_t* __restrict__ sorted_id,
-                       uint32_t* __restrict__ sorted_dup) {
+                       uint32_t* __restrict__ sorted_dup, int stats_bins, const uint32_t* __restrict__ coarse_count,
+                       unsigned long long* hdr_w, unsigned long long* __restrict__ feedback) {
   __shared__ unsigned long long k[CAP];
   __shared__ uint32_t pl[CAP];
   constexpr int NT = 256;
+  // behind select_sort_kernel (stats_bins > 0): the frame's list statistics are final now
+  if (stats_bins > 0 && blockIdx.x == 0) list_stats(stats_bins, coarse_count, hdr_w, feedback);
   const unsigned n_long = (unsigned)hdr[HDR_LONG_COUNT];
   const int tid = threadIdx.x;
   // ---- bucketed sort (lists of up to 2 CAP entries): O(n) partition by depth, then small register sorts ----------------
@@ -1489,6 +1649,11 @@ static int check_frame(const SfgsFrame* f) {
   return SFGS_OK;
 }
 
+static bool sort_split() {
+  const char* e = getenv("SFGS_SORT");
+  return e && !strcmp(e, "split");
+}
+
 static bool binning_direct() {
   const char* e = getenv("SFGS_BINNING");
   return e && !strcmp(e, "direct");
@@ -1822,23 +1987,38 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
   const KFrame kf = make_kframe(frame);
   const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
-  { ProfScope ps_(KID_FINE_BIN, stream);
-    hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
-                       tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.tile_range,
-                       bv.items, tv.long_tiles, tv.hdr); }
-  SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
-  if (num_duplicates != 0) {  // < 0: unknown (render enqueued before the counters were read)
+  // SFGS_SORT=split: fine_bin + sort as two kernels with the per-tile items in memory between them (the path before the
+  // fused select_sort_kernel; bit-identical lists, kept for the tests and A/B runs)
+  const bool fused = !sort_split();
+  if (fused) {
     { ProfScope ps_(KID_SORT_SMALL, stream);
-      hipLaunchKernelGGL(sort_tiles_reg_kernel, dim3((T8 + 3) / 4), dim3(256), 0, stream, T8, tv.tile_range, bv.items,
-                         bv.sorted_id, bv.sorted_dup, (const unsigned long long*)tv.hdr,
-                         (unsigned long long*)frame->feedback); }
-    SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
+      hipLaunchKernelGGL(select_sort_kernel, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
+                         tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity,
+                         tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id, bv.sorted_dup); }
+    SFGS_POST_LAUNCH("select_sort", stream, frame->debug);
+  } else {
+    { ProfScope ps_(KID_FINE_BIN, stream);
+      hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
+                         tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.tile_range,
+                         bv.items, tv.long_tiles, tv.hdr); }
+    SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
+  }
+  if (num_duplicates != 0) {  // < 0: unknown (render enqueued before the counters were read)
+    if (!fused) {
+      { ProfScope ps_(KID_SORT_SMALL, stream);
+        hipLaunchKernelGGL(sort_tiles_reg_kernel, dim3((T8 + 3) / 4), dim3(256), 0, stream, T8, tv.tile_range, bv.items,
+                           bv.sorted_id, bv.sorted_dup, (const unsigned long long*)tv.hdr,
+                           (unsigned long long*)frame->feedback); }
+      SFGS_POST_LAUNCH("sort_tiles_small", stream, frame->debug);
+    }
+    const int stats_bins = fused ? (int)NCB : 0;
     if (frame->launch_hints & SFGS_HINT_FEW_LONG_LISTS) {
       // the caller expects (next to) no list beyond 512 entries: ONE catch-all launch -- the LDS kernel takes every long
       // list, whatever its size class -- instead of three that each cost ~5 us of queue time when they find nothing
       ProfScope ps_(KID_SORT_LDS, stream);
       hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_SMALL,
-                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup);
+                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup, stats_bins,
+                         tv.coarse_count, tv.hdr, (unsigned long long*)frame->feedback);
     } else {
     // size classes: 513..1024 -> register network with 16 keys per lane; longer -> bucketed sort (a 32-key register
     // network used to take 1025..2048: 195 VGPRs, one more launch, and slower than the buckets -- city 0.179 -> 0.152 ms)
@@ -1848,7 +2028,8 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
     SFGS_POST_LAUNCH("sort_tiles_reg_long", stream, frame->debug);
     { ProfScope ps_(KID_SORT_LDS, stream);
       hipLaunchKernelGGL(sort_tiles_long_kernel<SORT_CAP>, dim3(std::min(T8, 768)), dim3(256), 0, stream, REG_SORT_MAX,
-                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup); }
+                         tv.long_tiles, tv.hdr, tv.tile_range, bv.items, bv.sorted_id, bv.sorted_dup, stats_bins,
+                         tv.coarse_count, tv.hdr, (unsigned long long*)frame->feedback); }
     }
     SFGS_POST_LAUNCH("sort_tiles_long", stream, frame->debug);
   }

@@ -43,7 +43,7 @@ def main():
     nv = lib.wm_run(C.byref(fr), a.n, p(m), p(s), p(r), p(o), tx0, tx0 + a.window, ty0, ty0 + a.window, p(out), 128)
     names = ["n_tiles", "sumL", "sumK", "hits", "dense16", "sp16", "sp32", "sp64", "spInf", "q16", "q64", "strip16",
              "dead_entries", "live_entries", "behind", "task_nonzero", "task_total", "D_all", "all16_batches",
-             "live16_batches"]
+             "live16_batches", "f64_bbox", "f64_xy", "f64_exact", "f64_ideal", "f32_bbox", "f32_xy", "f32_exact", "f32_ideal"]
     v = dict(zip(names, out[:nv]))
     T = v["n_tiles"]
     print(f"tiles {T:.0f}  mean list {v['sumL']/T:.1f}  mean kmax {v['sumK']/T:.1f}  D_all {v['D_all']:.0f}")
@@ -53,6 +53,8 @@ def main():
         print(f"  phase-1 steps {k:8s}: {v[k]/K:.3f} of kmax")
     print(f"dead entries (< kmax, no accepted pixel): {v['dead_entries']/K:.3f}; entries behind kmax: {v['behind']/v['sumL']:.3f} of L")
     print(f"phase-2 (entry,row-pair) tasks non-zero: {v['task_nonzero']/v['task_total']:.3f}")
+    for k in ("f64_bbox", "f64_xy", "f64_exact", "f64_ideal", "f32_bbox", "f32_xy", "f32_exact", "f32_ideal"):
+        print(f"  forward strip-list steps {k:10s}: {v[k]/v['sumK']:.3f} of kmax")
     print(f"16-batches after dropping dead entries: {v['live16_batches']/v['all16_batches']:.3f}")
     h = out[nv:nv + 65]
     cum = np.cumsum(h) / h.sum()

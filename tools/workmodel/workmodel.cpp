@@ -63,6 +63,7 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
   double task_nonzero = 0, task_total = 0;                // (entry, row-pair) tasks of phase 2
   double hist_hits[65] = {0};
   double live16_batches = 0, all16_batches = 0;           // batches (of 16) after dropping dead entries
+  double fstrip64[4] = {0, 0, 0, 0}, fstrip32[4] = {0, 0, 0, 0};   // forward strip-list steps (see below)
   for (int ty = 0; ty < wy; ++ty)
     for (int tx = 0; tx < wx; ++tx) {
       auto& l = lists[(size_t)ty * wx + tx];
@@ -125,9 +126,55 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
         return steps;
       };
       q16 += quad(16, false); q64 += quad(64, false); strip16 += quad(16, true);
+      // FORWARD strip lists (batches of B entries over the whole list walked, i.e. up to kmax; four 8x2 strips in
+      // lockstep): `bbox` = the product's test (the entry's alpha >= 1/255 y-extent reaches the strip's two rows),
+      // `xy` = y-extent AND x-extent against the tile's 8 columns, `exact` = the alpha >= 1/255 ellipse reaches the
+      // strip's rectangle (the binning's own test on a 8x2 rectangle), `ideal` = at least one pixel of the strip blended it
+      auto reach = [&](const SplatRec& r, float x0, float x1, float y0, float y1) {   // ellipse vs pixel-centre rectangle
+        const float thr = alpha_threshold_log2(r.op);
+        // closest point of the rectangle to the centre in the metric of the conic: minimise over the rectangle by
+        // coordinate descent on the convex quadratic (exact for axis-aligned boxes within a few rounds)
+        float x = std::min(std::max(r.mx, x0), x1), y = std::min(std::max(r.my, y0), y1);
+        for (int it = 0; it < 8; ++it) {
+          // p2(dx, dy) = qa dx^2 + qb dx dy + qc dy^2 (negative definite): maximise
+          const float dy = y - r.my;
+          float dx = -r.qb * dy / (2.f * r.qa);
+          x = std::min(std::max(r.mx + dx, x0), x1);
+          dx = x - r.mx;
+          float dyo = -r.qb * dx / (2.f * r.qc);
+          y = std::min(std::max(r.my + dyo, y0), y1);
+        }
+        const float dx = x - r.mx, dy = y - r.my;
+        return r.qa * dx * dx + r.qb * dx * dy + r.qc * dy * dy >= thr;
+      };
+      auto fwd = [&](int B, int mode) {
+        double steps = 0;
+        const float X0 = (float)((tx0 + tx) * 8), Y0 = (float)((ty0 + ty) * 8);
+        for (int b0 = 0; b0 < kmax; b0 += B) {
+          int cnt[4] = {0, 0, 0, 0};
+          for (int k = b0; k < std::min(kmax, b0 + B); ++k) {
+            const SplatRec& r = recs[(unsigned)(l[k] & 0xffffffffull)];
+            for (int q = 0; q < 4; ++q) {
+              const float y0 = Y0 + 2.f * q, y1 = y0 + 1.f;
+              bool in;
+              if (mode == 3) in = ((emask[k] >> (16 * q)) & 0xffffull) != 0;
+              else {
+                in = !(r.my + r.ey < y0) && !(r.my - r.ey > y1);
+                if (mode >= 1) in = in && !(r.mx + r.ex < X0) && !(r.mx - r.ex > X0 + 7.f);
+                if (mode == 2) in = in && reach(r, X0, X0 + 7.f, y0, y1);
+              }
+              if (in) ++cnt[q];
+            }
+          }
+          steps += *std::max_element(cnt, cnt + 4);
+        }
+        return steps;
+      };
+      for (int m = 0; m < 4; ++m) { fstrip64[m] += fwd(64, m); fstrip32[m] += fwd(32, m); }
     }
   double vals[] = {n_tiles, sumL, sumK, hits, dense16, sp16, sp32, sp64, spInf, q16, q64, strip16, dead_entries,
-                   live_entries, behind, task_nonzero, task_total, (double)D_all, all16_batches, live16_batches};
+                   live_entries, behind, task_nonzero, task_total, (double)D_all, all16_batches, live16_batches,
+                   fstrip64[0], fstrip64[1], fstrip64[2], fstrip64[3], fstrip32[0], fstrip32[1], fstrip32[2], fstrip32[3]};
   int nv = (int)(sizeof(vals) / sizeof(vals[0]));
   for (int i = 0; i < nv && i < n_out; ++i) out[i] = vals[i];
   for (int i = 0; i < 65 && nv + i < n_out; ++i) out[nv + i] = hist_hits[i];
