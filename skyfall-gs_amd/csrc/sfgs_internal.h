@@ -179,6 +179,8 @@ struct TilesView {
   uint32_t* coarse_count;   // [NCB * CC_STRIDE] one 128-byte line per coarse bin: word 0 = items appended (keeps counting
                             //   past capacity), word 1 = tile hits of those items (words 0-1 are ONE 64-bit atomic
                             //   counter), word 2 = the bin's first list slot (scanned by the plan from the hits)
+                            //   word 3 = slots handed out to the bin's tiles so far (select_sort_kernel: one atomic
+                            //   per tile), word 4 = the bin's longest tile list (reduced by list_stats)
   uint2* tile_range;        // [T8] (first list slot, list length) of every 8x8 tile
   uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]
