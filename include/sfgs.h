@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 9
+#define SFGS_ABI_VERSION 10
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -87,6 +87,11 @@ typedef struct SfgsFrame {
  *                   frame was binned WITHOUT those splats: redo plan + render without the hint.
  *   FEW_LONG_LISTS  render: ONE catch-all kernel sorts every list longer than 512 entries instead of three size-class
  *                   kernels. Always correct; slower when many lists are long.
+ *   SHORT_LISTS     render: the caller expects per-tile lists of a few hundred entries at most and coarse bins of a few
+ *                   thousand items (what the previous frame's plan / feedback reported): fine binning and the sort of the
+ *                   short lists run as ONE kernel that never writes per-tile items to memory (select_sort_kernel). Always
+ *                   correct -- both routes build bit-identical lists --; slower than the two-kernel route when lists
+ *                   or bins are long.
  *   NO_PREFILL      backward: do not launch the dead-entry prefill kernel (its decision then reads "no"). Always correct.
  *   NO_BIG_CHUNKS   backward: do not launch the chunk pre-reduction. Only valid when THIS frame's plan reported
  *                   num_big_chunks == 0. */
@@ -94,6 +99,7 @@ typedef struct SfgsFrame {
 #define SFGS_HINT_FEW_LONG_LISTS 2u
 #define SFGS_HINT_NO_PREFILL 4u
 #define SFGS_HINT_NO_BIG_CHUNKS 8u
+#define SFGS_HINT_SHORT_LISTS 16u
 
 /* Per-Gaussian inputs = keyword arguments of GaussianRasterizer.__call__
  * (gaussian_renderer/__init__.py:132-140). All float32, contiguous, device memory.

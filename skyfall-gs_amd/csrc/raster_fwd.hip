@@ -1123,13 +1123,18 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
     long_tiles[atomicAdd(&hdr[HDR_LONG_COUNT], 1ull)] = (unsigned)t;
   }
   unsigned done = 0;
-  for (unsigned i0 = 0; i0 < n; i0 += 64u) {
-    const uint4 it = slab[min(i0 + lane, n - 1u)];
-    const bool hit = i0 + lane < n && ((it.w >> bit) & 1u);
-    const unsigned long long b = __ballot(hit);
-    const unsigned pos = done + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-    if (hit) items[s + pos] = make_uint4(it.x, it.y, it.z + (unsigned)__popc(it.w & below), 0u);
-    done += (unsigned)__popcll(b);
+  for (unsigned i0 = 0; i0 < n; i0 += 64u * R) {   // R loads of the wave in flight per round trip
+    uint4 lt[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) lt[k] = slab[min(i0 + 64u * k + lane, n - 1u)];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const bool hit = i0 + 64u * k + lane < n && ((lt[k].w >> bit) & 1u);
+      const unsigned long long b = __ballot(hit);
+      const unsigned pos = done + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      if (hit) items[s + pos] = make_uint4(lt[k].x, lt[k].y, lt[k].z + (unsigned)__popc(lt[k].w & below), 0u);
+      done += (unsigned)__popcll(b);
+    }
   }
 }
 
@@ -1649,9 +1654,13 @@ static int check_frame(const SfgsFrame* f) {
   return SFGS_OK;
 }
 
-static bool sort_split() {
+// Route of the render stage's fine binning + short-list sort: SFGS_SORT=fused | split forces one (tests, A/B runs);
+// otherwise the caller's SHORT_LISTS hint picks the fused kernel. Both routes build bit-identical lists.
+static bool sort_fused(uint32_t launch_hints) {
   const char* e = getenv("SFGS_SORT");
-  return e && !strcmp(e, "split");
+  if (e && !strcmp(e, "split")) return false;
+  if (e && !strcmp(e, "fused")) return true;
+  return (launch_hints & SFGS_HINT_SHORT_LISTS) != 0;
 }
 
 static bool binning_direct() {
@@ -1987,9 +1996,10 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
   const KFrame kf = make_kframe(frame);
   const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
-  // SFGS_SORT=split: fine_bin + sort as two kernels with the per-tile items in memory between them (the path before the
-  // fused select_sort_kernel; bit-identical lists, kept for the tests and A/B runs)
-  const bool fused = !sort_split();
+  // Two routes to the sorted per-tile lists (bit-identical results): select_sort_kernel (no per-tile items in memory, one
+  // launch less: faster for lists of a few hundred entries and bins of a few thousand items -- the caller's SHORT_LISTS
+  // hint) or fine_bin + the sort kernels with the items in memory between them (long lists, crowded bins)
+  const bool fused = sort_fused(frame->launch_hints);
   if (fused) {
     { ProfScope ps_(KID_SORT_SMALL, stream);
       hipLaunchKernelGGL(select_sort_kernel, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,

@@ -62,6 +62,11 @@ _cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin c
 # (SfgsFrame.feedback); SFGS_HINTS=0 in the environment switches the mechanism off (tests compare both).
 _hint_state = {}  # (device index, stream) -> dict(fb=tensor, huge=int, long=int, prefilled=int, bwd=int)
 HINT_NO_HUGE_SPLATS, HINT_FEW_LONG_LISTS, HINT_NO_PREFILL, HINT_NO_BIG_CHUNKS = 1, 2, 4, 8
+HINT_SHORT_LISTS = 16
+# SHORT_LISTS (fine binning + short-list sort as one kernel) pays while the lists stay short and the coarse bins small:
+# measured on the regime set it wins whenever no list exceeds the register sort (512 entries) and loses
+# once lists take its long-list path (a second scan of the slab per long tile)
+SHORT_LIST_MAX, SHORT_BIN_MAX = 512, 8192
 PREFILL_PROBE_EVERY = 32   # backward passes between two launches of the dead-entry prefill kernel while it keeps saying no
 
 
@@ -222,10 +227,12 @@ class _Rasterize(torch.autograd.Function):
                 hs = _hint_state.get(hkey)
                 if hs is None:   # first frame on this stream: no hints yet, everything is launched
                     hs = _hint_state[hkey] = dict(fb=torch.zeros(8, dtype=torch.int64, device=dev), huge=1, long=1,
-                                                  prefilled=1, bwd=0, prefill_ran=False)
+                                                  prefilled=1, bwd=0, prefill_ran=False, maxlist=1 << 30, cmax=1 << 30)
             fwd_hints = 0
             if hs is not None:
                 fwd_hints = (HINT_NO_HUGE_SPLATS if hs["huge"] == 0 else 0) | (HINT_FEW_LONG_LISTS if hs["long"] == 0 else 0)
+                if hs["long"] == 0 and hs["maxlist"] <= SHORT_LIST_MAX and hs["cmax"] <= SHORT_BIN_MAX:
+                    fwd_hints |= HINT_SHORT_LISTS
             feedback = hs["fb"] if hs is not None else None
             tries, pool_grown = 0, False
             while True:
@@ -288,9 +295,11 @@ class _Rasterize(torch.autograd.Function):
             if hs is not None:
                 if cnt.prev_valid:   # the previous frame's render / backward stages, as this frame's plan found them
                     hs["long"] = int(cnt.prev_long_tiles)
+                    hs["maxlist"] = int(cnt.prev_max_tile_list)
                     if hs["prefill_ran"]:
                         hs["prefilled"] = int(cnt.prev_prefilled)
                 hs["huge"] = int(cnt.num_huge_splats)
+                hs["cmax"] = cmax
                 hs["prefill_ran"] = False
             _cap_hint[(dev.index, W, H)] = (cap if pool_grown else
                                             max(slots(int(D * 1.25) + 1024), min(cap, slots(2 * D + 1024))),

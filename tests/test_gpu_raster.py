@@ -379,8 +379,8 @@ def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
 @pytest.mark.parametrize("case", ["precomp_small", "sh1_ragged", "cfg2_like", "big_splats", "screen_filling", "lists_800",
                                   "lists_2k", "lists_6k", "lists_10k", "cfg2_200k_1080p", "uhd_two_bin_rounds"])
 def test_fused_select_sort_equals_fine_bin_plus_sort(case, monkeypatch):
-    """select_sort_kernel (one wave per tile selects its entries from the coarse bin's slab, sorts them in registers and
-    writes the final lists; the default) and the two-kernel route with the per-tile items in memory between them
+    """select_sort_kernel (a workgroup hands a coarse bin's items to the LDS lists of a row of tiles, every wave sorts its
+    tile in registers and writes the final lists; the route the SHORT_LISTS hint selects, forced here) and the two-kernel route with the per-tile items in memory between them
     (SFGS_SORT=split: fine_bin + sort_tiles_reg) build the same lists -- same members, same (depth, id) order, same
     duplicate indices; only WHERE a tile's list sits inside its bin's slot range may differ -- so images, radii,
     counters (incl. the longest list) and every gradient are equal bit for bit. Long lists (> 512) take the second scan
@@ -388,6 +388,7 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, monkeypatch):
     c = CASES.get(case) or BINNING_CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=5, **c["kw"])
     gc, gd = upstream_grads(c["W"], c["H"], 2)
+    monkeypatch.setenv("SFGS_SORT", "fused")
     a = run_hip(frame, g, gc, gd)
     monkeypatch.setenv("SFGS_SORT", "split")
     b = run_hip(frame, g, gc, gd)
