@@ -1140,11 +1140,17 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
 
 // longest list of the frame = max over the bins' maxima (select_sort_kernel), and the list statistics for the next
 // frame's plan (SfgsFrame.feedback). Run by the first workgroup of the (always launched) long-list kernel: 256 threads.
-__device__ void list_stats(int NCB, const uint32_t* __restrict__ coarse_count, unsigned long long* hdr,
+__device__ void list_stats(int NCB, uint32_t* __restrict__ coarse_count, unsigned long long* hdr,
                            unsigned long long* __restrict__ feedback) {
   __shared__ unsigned ls_part[4];
   unsigned m = 0;
-  for (int i = threadIdx.x; i < NCB; i += 256) m = max(m, coarse_count[(size_t)i * CC_STRIDE + 4]);
+  for (int i = threadIdx.x; i < NCB; i += 256) {
+    m = max(m, coarse_count[(size_t)i * CC_STRIDE + 4]);
+    // leave the bins' slot cursors and maxima as the plan left them (zero): a caller may run the render stage on the same
+    // plan again, and select_sort_kernel must then hand out the same slot ranges
+    coarse_count[(size_t)i * CC_STRIDE + 3] = 0u;
+    coarse_count[(size_t)i * CC_STRIDE + 4] = 0u;
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
   if ((threadIdx.x & 63) == 0) ls_part[threadIdx.x >> 6] = m;
@@ -1193,7 +1199,7 @@ template <int CAP>
 __global__ void __launch_bounds__(256, 3)   // three workgroups per CU: what the 52 KB of LDS allow
 sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const unsigned long long* __restrict__ hdr,
                        const uint2* __restrict__ tile_range, uint4* items, uint32_t* __restrict__ sorted_id,
-                       uint32_t* __restrict__ sorted_dup, int stats_bins, const uint32_t* __restrict__ coarse_count,
+                       uint32_t* __restrict__ sorted_dup, int stats_bins, uint32_t* __restrict__ coarse_count,
                        unsigned long long* hdr_w, unsigned long long* __restrict__ feedback) {
   __shared__ unsigned long long k[CAP];
   __shared__ uint32_t pl[CAP];
