@@ -138,3 +138,18 @@ def test_operator_argument_validation_without_gpu():
         fused_ssim(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8))
     with pytest.raises(ValueError):
         distCUDA2(torch.zeros(10, 3))
+
+
+def test_launch_hint_bits_match_the_c_header():
+    """The wrapper's HINT_* constants are the header's SFGS_HINT_* bits (distinct single bits), and the SHORT_LISTS route
+    is only asked for inside what the fused kernel's register sort takes (lists of at most 512 entries)."""
+    import diff_gauss
+    hdr = open(os.path.join(ROOT, "include", "sfgs.h")).read()
+    bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SFGS_HINT_([A-Z_]+)\s+(\d+)u", hdr)}
+    assert bits == {"NO_HUGE_SPLATS": diff_gauss.HINT_NO_HUGE_SPLATS, "FEW_LONG_LISTS": diff_gauss.HINT_FEW_LONG_LISTS,
+                    "NO_PREFILL": diff_gauss.HINT_NO_PREFILL, "NO_BIG_CHUNKS": diff_gauss.HINT_NO_BIG_CHUNKS,
+                    "SHORT_LISTS": diff_gauss.HINT_SHORT_LISTS}
+    vals = sorted(bits.values())
+    assert all(v & (v - 1) == 0 for v in vals) and len(set(vals)) == len(vals)
+    assert diff_gauss.SHORT_LIST_MAX <= 512
+    assert int(re.search(r"#define\s+SFGS_ABI_VERSION\s+(\d+)", hdr).group(1)) == L.ABI_VERSION
