@@ -523,17 +523,35 @@ bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uin
   }
 }
 
+// the plan's two single-workgroup epilogues (defined below: counters for the host; list-slot bases of the bins)
+__device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__ coarse_count,
+                               const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
+                               unsigned long long* __restrict__ hdr, const unsigned long long* __restrict__ feedback,
+                               const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out);
+
+// plan_roles = 2: the launch's first two workgroups run the plan's epilogues (plan_scan_role) next to the scatter
+// workgroups instead of a launch of their own behind them -- everything they read is final before this kernel starts (the
+// bins' totals come from bin_rank, the per-block statistics from preprocess), and the one thing the scatter may still
+// add, the overflow flag of a bin beyond its capacity, the host derives from the fullest bin's count anyway.
 __global__ void __launch_bounds__(SCATTER_NT)
 bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
                    const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_base,
-                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long* __restrict__ hdr) {
+                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long* __restrict__ hdr,
+                   int plan_roles, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
+                   const unsigned long long* __restrict__ block_dref, const unsigned long long* __restrict__ feedback,
+                   const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out) {
+  if ((int)blockIdx.x < plan_roles) {   // uniform per workgroup
+    plan_scan_role((int)blockIdx.x, NCB, NB, coarse_count, block_nvis, block_dref, hdr, feedback, dup_pool, host_out);
+    return;
+  }
+  const int wg = (int)blockIdx.x - plan_roles;   // scatter workgroup
   __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
   __shared__ unsigned s_red[SCATTER_NT / 64 + 1];
   __shared__ unsigned s_delta[SCATTER_BINS];   // bin's first slab rank - its first sorted position
   __shared__ unsigned s_cur[SCATTER_BINS];     // the bin's cursor in the sorted order
   __shared__ unsigned short s_idx[SCATTER_IDX];   // pair index at every sorted position
   const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * SCATTER_BLOCKS, nblk = min(SCATTER_BLOCKS, NB - b0);
+  const int b0 = wg * SCATTER_BLOCKS, nblk = min(SCATTER_BLOCKS, NB - b0);
   const unsigned total = scatter_prefix(block_items, b0, nblk, s_prefix);
   if (total == 0u) return;
   for (int r0 = 0; r0 < NCB; r0 += SCATTER_BINS) {
@@ -544,8 +562,8 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = tid + u * SCATTER_NT;
-      c[u] = i < nbins ? sc_cnt[(size_t)blockIdx.x * NCB + r0 + i] : 0u;
-      base[u] = i < nbins ? sc_base[(size_t)blockIdx.x * NCB + r0 + i] : 0u;
+      c[u] = i < nbins ? sc_cnt[(size_t)wg * NCB + r0 + i] : 0u;
+      base[u] = i < nbins ? sc_base[(size_t)wg * NCB + r0 + i] : 0u;
     }
     unsigned round_total;
     unsigned p = block_excl_scan_u32<SCATTER_NT>(c[0] + c[1] + c[2] + c[3], &round_total, s_red);
@@ -727,12 +745,12 @@ __global__ void __launch_bounds__(1024) bin_base_scan_kernel(int NCB, uint32_t* 
 // ------------------------------------------------------------------------------------------------
 // K2: single workgroup: counters for the host (visible count, reference duplicate total, fullest coarse bin).
 constexpr int SCAN_NT = 1024;
-__global__ void __launch_bounds__(SCAN_NT)
-plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
-                 const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
-                 const unsigned long long* __restrict__ feedback, const unsigned long long* __restrict__ dup_pool,
-                 unsigned long long* __restrict__ host_out) {
-  if (blockIdx.x == 1) { bin_base_scan(NCB, coarse_count, hdr); return; }   // second workgroup, concurrently
+static_assert(SCAN_NT == SCATTER_NT, "the plan's epilogues can ride in the scatter launch");
+__device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__ coarse_count,
+                               const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
+                               unsigned long long* __restrict__ hdr, const unsigned long long* __restrict__ feedback,
+                               const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out) {
+  if (role == 1) { bin_base_scan(NCB, coarse_count, hdr); return; }   // second workgroup, concurrently
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
   unsigned long long nvis = 0, dref = 0, cmax = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
@@ -775,6 +793,15 @@ plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uin
     host_out[13] = feedback ? feedback[FB_PREFILLED] : 0ull;
     host_out[14] = 0ull; host_out[15] = 0ull;
   }
+}
+
+// the same two roles as a launch of their own (one-pass binning, SFGS_PLAN_SCAN=separate)
+__global__ void __launch_bounds__(SCAN_NT)
+plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
+                 const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
+                 const unsigned long long* __restrict__ feedback, const unsigned long long* __restrict__ dup_pool,
+                 unsigned long long* __restrict__ host_out) {
+  plan_scan_role((int)blockIdx.x, NCB, NB, coarse_count, block_nvis, block_dref, hdr, feedback, dup_pool, host_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1669,6 +1696,11 @@ static bool sort_fused(uint32_t launch_hints) {
   return (launch_hints & SFGS_HINT_SHORT_LISTS) != 0;
 }
 
+static bool plan_scan_separate() {   // SFGS_PLAN_SCAN=separate: the plan's epilogues as a launch of their own (A/B, tests)
+  const char* e = getenv("SFGS_PLAN_SCAN");
+  return e && !strcmp(e, "separate");
+}
+
 static bool binning_direct() {
   const char* e = getenv("SFGS_BINNING");
   return e && !strcmp(e, "direct");
@@ -1751,6 +1783,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   // two-pass binning (pair list + bin_scatter_kernel) unless the coarse-bin index does not fit the pair's 16 bits (images
   // beyond 65 536 coarse bins = 8 192 x 8 192 pixels) or SFGS_BINNING=direct asks for the one-pass path (A/B, tests)
   const bool two_pass = NCB <= 65536 && !binning_direct();
+  int plan_roles = 0;   // 2: the plan's epilogues ride in the scatter launch (two-pass binning)
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
 #define SFGS_LAUNCH_PRE_(K, D, RAW)                                                                                    \
@@ -1780,12 +1813,16 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
       { ProfScope ps_(KID_BIN_RANK, stream);
         hipLaunchKernelGGL(bin_rank_kernel, dim3(((int)NCB + RANK_COLS - 1) / RANK_COLS), dim3(RANK_COLS * RANK_GROUPS), 0,
                            stream, NWG, (int)NCB, tv.sc_cnt, tv.sc_hits, tv.sc_base, tv.coarse_count); }
+      plan_roles = plan_scan_separate() ? 0 : 2;
       { ProfScope ps_(KID_BIN_SCATTER, stream);
-        hipLaunchKernelGGL(bin_scatter_kernel, dim3(NWG), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, gv.pairs,
-                           gv.block_items, tv.sc_cnt, tv.sc_base, bv.slabs, (unsigned)coarse_capacity, tv.hdr); }
+        hipLaunchKernelGGL(bin_scatter_kernel, dim3(NWG + plan_roles), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, gv.pairs,
+                           gv.block_items, tv.sc_cnt, tv.sc_base, bv.slabs, (unsigned)coarse_capacity, tv.hdr, plan_roles,
+                           tv.coarse_count, tv.block_nvis, tv.block_dref, (const unsigned long long*)frame->feedback,
+                           (const unsigned long long*)tv.dup_pool, (unsigned long long*)counters_pinned_host); }
     }
     SFGS_POST_LAUNCH("bin_scatter", stream, frame->debug);
   }
+  if (plan_roles == 0)
   { ProfScope ps_(KID_PLAN_SCAN, stream);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
                        tv.block_dref, tv.hdr,
