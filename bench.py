@@ -281,13 +281,28 @@ def main():
     L.profile_select(None)
 
     per_rank_ms = [elapsed / args.steps * 1e3]
-    if dist is not None:
-        allr = [torch.zeros(1, device=coll_dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(allr, torch.tensor([elapsed], device=coll_dev, dtype=torch.float64))
-        per_rank_ms = [float(t_.item()) / args.steps * 1e3 for t_ in allr]
-        elapsed = max(float(t_.item()) for t_ in allr)
-
     cnt = last_counters()
+    per_rank_counts = [[cnt["num_visible"], cnt["num_duplicates_ref"], cnt["num_duplicates"]]]
+    rccl = None
+    if dist is not None:
+        # one gather: every rank's own clock and its scene's counters (the driver checks "RCCL saw N ranks" against these)
+        mine = torch.tensor([elapsed, cnt["num_visible"], cnt["num_duplicates_ref"], cnt["num_duplicates"]],
+                            device=coll_dev, dtype=torch.float64)
+        allr = [torch.zeros(4, device=coll_dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(x) for x in t_.tolist()] for t_ in allr]
+        per_rank_ms = [r_[0] / args.steps * 1e3 for r_ in rows]
+        per_rank_counts = [[int(x) for x in r_[1:]] for r_ in rows]
+        elapsed = max(r_[0] for r_ in rows)
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "version": ver,
+                "ranks_reporting": len(rows),
+                "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "MASTER_ADDR")}}
     Nvis, D_ref, D_eff, P = cnt["num_visible"], cnt["num_duplicates_ref"], cnt["num_duplicates"], W * H
     ms_step = elapsed / args.steps * 1e3
     if args.forward_only:
@@ -310,13 +325,14 @@ def main():
     # HBM traffic of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs,
     # gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md) of THIS workload, committed under profiles/ by
     # tools/collect_profiles.sh. bench.py cannot collect PMCs on itself; null when the workload differs.
-    traffic = load_traffic(N, W, H, args.forward_only)
+    traffic, traffic_source = load_traffic(N, W, H, args.forward_only)
     roofline = None
     if dom is not None:
         dur = per_kernel[dom]["ms_per_step"] * 1e-3
         ach = kb.get(dom, 0) / dur / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(dom),
+                    "traffic_source": traffic_source if traffic.get(dom) is not None else None,
                     "avg_launch_ms": round(per_kernel[dom]["ms_per_step"], 4),
                     "algorithmic_bytes_per_launch": int(kb.get(dom, 0))}
         if dom.startswith("composite"):
@@ -356,6 +372,8 @@ def main():
                        "prewarm_steps": args.prewarm_steps, "settle_steps": args.settle_steps, "order": args.order},
             "roofline": roofline, "roofline_step": roofline_step, "cpu_baseline": cpu_baseline,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+            "per_rank_counts": {"columns": ["N_vis", "D_ref_16x16", "D_binned_8x8"], "rows": per_rank_counts},
+            "rccl": rccl,
             "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
         }
         if idu is not None:
@@ -366,20 +384,43 @@ def main():
 
 
 def load_traffic(N, W, H, forward_only):
-    """{kernel: HBM bytes per launch} measured by tools/collect_profiles.sh for the default workload."""
+    """({kernel: HBM bytes per launch}, provenance). bench.py cannot collect PMC counters on itself: the figures are READ
+    from the newest committed profiles/r*_traffic.json (separate rocprofv3 --pmc passes of this command on another box,
+    tools/collect_profiles.sh) and the JSON line says so: file, the commit the passes were taken at (the file's
+    "_meta" entry), and whether raster_*.hip changed since. ({}, None) when the workload is not the profiled one."""
     out = {}
     if (N, W, H) != (2_000_000, 1920, 1080):
-        return out
+        return out, None
+    src = None
     try:
         import glob
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
-        for k, v in json.load(open(path)).items():
+        import subprocess
+        def round_key(p):
+            b = os.path.basename(p)   # r<round>_v<pass>_traffic.json
+            import re
+            m = re.match(r"r(\d+)_v(\d+)", b)
+            return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), key=round_key)[-1]
+        data = json.load(open(path))
+        meta = data.pop("_meta", {}) if isinstance(data.get("_meta"), dict) else {}
+        for k, v in data.items():
             key = k.replace("_kernel", "").split("<")[0]
             key = "sort_tiles" if key.startswith("sort_tiles") else key
             out[key] = out.get(key, 0) + int(v["hbm_bytes_per_launch"])
+        src = {"kind": "file, not measured in this run", "file": os.path.relpath(path, ROOT),
+               "collected_at_commit": meta.get("commit"), "fetch_correction": meta.get("fetch_correction",
+               "FETCH_SIZE x2 for every kernel (MI355X_MICROARCH.md; established for wide streaming reads)")}
+        try:
+            if meta.get("commit"):
+                r = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", meta["commit"], "--",
+                                    "skyfall-gs_amd/csrc/raster_fwd.hip", "skyfall-gs_amd/csrc/raster_bwd.hip"],
+                                   capture_output=True, timeout=10)
+                src["kernels_changed_since"] = {0: False, 1: True}.get(r.returncode)   # None: no git here (GPU box)
+        except Exception:
+            src["kernels_changed_since"] = None
     except Exception:
         pass
-    return out
+    return out, src
 
 
 def run_cpu_baseline(n, W, H):

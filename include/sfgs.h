@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 10
+#define SFGS_ABI_VERSION 11
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -160,7 +160,12 @@ typedef struct SfgsRasterCounters {
   int64_t num_visible;         /* N_vis: count(radii > 0)                                                   */
   int64_t max_tile_list;       /* longest per-tile list (valid when read after sfgs_raster_forward_render)  */
   int64_t overflow;            /* != 0: dup_capacity or coarse_capacity was too small: redo the plan with
-                                  dup_capacity >= num_duplicates and coarse_capacity >= max_coarse_bin     */
+                                  dup_capacity >= sfgs_raster_slot_capacity(W, H, num_duplicates) and
+                                  coarse_capacity >= max_coarse_bin. If both ALREADY hold, one of the 8 duplicate-index
+                                  pools (each owns dup_capacity / 8 indices; a workgroup draws from pool id % 8) ran
+                                  over because a few workgroups own most of the frame's duplicates: double
+                                  dup_capacity. A caller should also treat max_coarse_bin > coarse_capacity as
+                                  overflow (the library ORs it in; belt and braces)                         */
   int64_t max_coarse_bin;      /* items in the fullest 32x32-pixel coarse bin                               */
   int64_t num_huge_splats;     /* splats reaching >= 64 coarse bins (their walk is a kernel of its own)        */
   int64_t num_big_chunks;      /* 1024-record chunks of Gaussians with > 2048 duplicates (backward pre-reduction) */
@@ -223,7 +228,9 @@ int sfgs_raster_read_counters_pinned(const void* tiles, void* pinned_host_64, Sf
  * filled `bins` (same capacities), or -1 when the caller enqueues the render BEFORE reading the
  * counters (no mid-frame host sync): an overflowing plan is memory-safe -- it drops the items that
  * did not fit -- so the caller may read the counters after the render and redo both stages on
- * overflow. `image` may be NULL when no backward will follow. One render per plan. Asynchronous. */
+ * overflow. `image` may be NULL when no backward will follow. A plan is SINGLE-USE: the render stage consumes
+ * header words of the `tiles` blob (long-list count, longest list) that only a new plan resets; rendering the same plan
+ * twice is undefined. Asynchronous. */
 int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* geom, void* tiles,
                                void* bins, size_t bins_bytes, int64_t dup_capacity,
                                int64_t coarse_capacity, int64_t num_duplicates, float* out_color,
@@ -243,6 +250,39 @@ int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const i
                          int64_t coarse_capacity, int64_t num_duplicates, const void* image, const float* dL_dcolor,
                          const float* dL_ddepth, const float* dL_dalpha, void* dupgrad,
                          size_t dupgrad_bytes, const SfgsGaussianGrads* grads, void* stream);
+
+/* ---- One call per stage on ONE scratch allocation (ABI 11) -----------------------------------------------------------
+ * The four blobs above as consecutive 256-byte aligned regions of a single caller-owned allocation: the caller asks for
+ * the layout once per (N, W, H, capacities) and hands the library one pointer per frame; the library carves it up
+ * (still allocates nothing, keeps no state). `with_image` != 0: the frame will be differentiated (image blob included).
+ * slot_overhead: sfgs_raster_slot_capacity(W, H, d) == d + slot_overhead (saves the caller a call per frame). */
+typedef struct SfgsScratchLayout {
+  uint32_t struct_size;
+  uint32_t reserved;
+  size_t geom_offset, tiles_offset, bins_offset, image_offset;
+  size_t total_bytes;      /* size of the allocation (through `bins` without an image, through `image` with one) */
+  size_t dupgrad_bytes;    /* separate scratch of the backward (not part of the allocation)                       */
+  int64_t coarse_bins;
+  int64_t slot_overhead;
+} SfgsScratchLayout;
+int sfgs_raster_scratch_layout(int32_t N, int32_t W, int32_t H, int64_t dup_capacity, int64_t coarse_capacity,
+                               int32_t with_image, SfgsScratchLayout* out);
+
+/* sfgs_raster_forward_plan, hipEventRecord(plan_done_event, stream), sfgs_raster_forward_render(num_duplicates = -1) as
+ * ONE call: replaces the autograd forward behind gaussian_renderer/__init__.py:132-140 with a single host -> library
+ * transition per frame. plan_done_event: a hipEvent_t (NULL: none); the caller waits on it, decodes
+ * counters_pinned_host_128 and redoes the call with larger capacities if the plan overflowed -- the render stage is
+ * already running meanwhile. out_* as in sfgs_raster_forward_render. */
+int sfgs_raster_forward(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* scratch,
+                        size_t scratch_bytes, int64_t dup_capacity, int64_t coarse_capacity, int32_t with_image,
+                        void* counters_pinned_host_128, void* plan_done_event, float* out_color, float* out_depth,
+                        float* out_alpha, void* stream);
+/* sfgs_raster_backward on the same allocation (laid out with with_image != 0). */
+int sfgs_raster_backward_scratch(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
+                                 const void* scratch, size_t scratch_bytes, int64_t dup_capacity,
+                                 int64_t coarse_capacity, int64_t num_duplicates, const float* dL_dcolor,
+                                 const float* dL_ddepth, const float* dL_dalpha, void* dupgrad, size_t dupgrad_bytes,
+                                 const SfgsGaussianGrads* grads, void* stream);
 
 /* fused_ssim: mean SSIM (11x11 Gaussian window, sigma 1.5, zero "same" padding, C1=0.01^2,
  * C2=0.03^2 == utils/loss_utils.py:23-63) of img1,img2 [B,C,H,W] float32.

@@ -24,10 +24,25 @@
 // composite_bwd so that its cost INSIDE the kernel (with the overlap the other waves provide) can be read off a timing:
 //   1 no zero fill of UW   2 no phase 1 (no pixel has a blended entry)   4 no phase-2 slot loop   8 no record stores
 //  16 no record gathers (every batch reuses the first one's records)
-// -DSFGS_BWD_SPARSE_CLEAR: experiment -- UW is zeroed once; after phase 2 every pixel lane clears the slots it wrote
-// (its own blended entries) instead of the wave zero-filling all 16 x 65 pairs per batch.
 #ifndef SFGS_BWD_ABLATE
 #define SFGS_BWD_ABLATE 0
+#endif
+// Round-4 experiment knobs (tools/ablate_bwd.sh; profiles/r4_bwd_*_ab.txt hold what each measured):
+//   -DSFGS_BWD_LDS_PAD=<bytes>  extra LDS per wave: lowers the resident waves per CU without touching the code -- the
+//                               slope d(time) / d(waves) says what MORE waves could buy at most
+//   -DSFGS_BWD_PRIO=1|2         s_setprio: 1 = phase 1 (the dependent exp / rcp chains) runs at raised priority, 2 = phase 2
+//   -DSFGS_BWD_ZEROFILL         the round-3 scheme: the wave zero-fills the 16 x 65 (u, w) matrix before every batch and phase
+//                               2 reads it with plain ds_read_b64. Shipped since round 4: phase 2 fetches its pairs with
+//                               ds_wrxchg_rtn_b64 (exchange with zero), which leaves the matrix zeroed for the next batch --
+//                               17 LDS stores per batch less, 98 -> 93 VGPRs (profiles/r4_bwd_ab.txt: 0.397 -> 0.383 ms)
+#ifndef SFGS_BWD_LDS_PAD
+#define SFGS_BWD_LDS_PAD 0
+#endif
+#ifndef SFGS_BWD_PRIO
+#define SFGS_BWD_PRIO 0
+#endif
+#if !defined(SFGS_BWD_ZEROFILL)
+#define SFGS_BWD_XCHG 1
 #endif
 
 namespace sfgs {
@@ -57,6 +72,9 @@ struct alignas(16) BwdLds {
   // phase 2 are both bank-conflict free on the 64-bank LDS.
   float2 UW[(B + 1) * ROW];
   float4 recs[(B + 1) * 3];   // staged records of the batch; record B is all zeros (the dummy entry: alpha = 0)
+#if SFGS_BWD_LDS_PAD > 0
+  float4 pad[SFGS_BWD_LDS_PAD / 16];   // occupancy experiment only
+#endif
 };
 
 // value of lane I of the caller's 16-lane row, broadcast to the whole row (DPP row_newbcast; folds into
@@ -78,6 +96,13 @@ __device__ __forceinline__ float swap32_add(float a, float b) {
 __device__ __forceinline__ float swap16_add(float a, float b) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// SFGS_BWD_XCHG: read a (u, w) pair and leave zeros behind (ds_wrxchg_rtn_b64)
+__device__ __forceinline__ float2 uw_take(const float2* p) {
+  const unsigned long long v = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(const_cast<float2*>(p)), 0ull,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
 struct Phase2Acc {
@@ -173,21 +198,38 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 #define SFGS_P1_K 2
 #endif
   constexpr int K = SFGS_P1_K;
+  // pm is LEFT-ALIGNED (bit 31 = entry B - 1): v_ffbh gives fb = B - 1 - j directly (0xffffffff for an exhausted lane,
+  // i.e. j = B, the dummy entry), both LDS addresses are ONE v_mad_i32_i24 of fb each and the bit is cleared with a shift
+  // and a v_bfi (2 instructions where xor / min / bfe took 3; round 4)
+  static_assert(B == 16, "left-aligned 16-bit batch masks");
+  // LDS byte offsets (the low 32 bits of a generic LDS address) of record B - 1 and of this pixel's slot in row B - 1;
+  // both live in VGPRs across the loop (v_mad_i32_i24 takes one scalar operand: left to itself the compiler
+  // re-materialises the wave's LDS base with a v_mov in every iteration)
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) v4f* lds_c4;
+  typedef const __attribute__((address_space(3))) v2f* lds_c2;
+  typedef __attribute__((address_space(3))) v2f* lds_p2;
+  unsigned recs_top = (unsigned)(uintptr_t)&lds.recs[(B - 1) * 3];
+  unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(B - 1) * ROW + lane];
+  asm volatile("" : "+v"(recs_top), "+v"(uw_top));
   do {
-    unsigned j[K];
+    int fb[K];
     float4 r0[K], r1[K];
     float2 r2[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      unsigned fb;
-      asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pm));            // 0xffffffff for pm == 0
-      j[q] = min(fb ^ 31u, (unsigned)B);                          // -> B (the dummy entry) for pm == 0
-      pm = __builtin_amdgcn_ubfe(pm, 0u, j[q]);                   // clear bit j and everything above it
+      unsigned f;
+      asm("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(pm));            // 0xffffffff (= -1) for pm == 0
+      fb[q] = (int)f;
+      pm &= ~(0x80000000u >> (f & 31u));                        // pm == 0: clears bit 0, which is never set
     }
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      r0[q] = lds.recs[j[q] * 3]; r1[q] = lds.recs[j[q] * 3 + 1];
-      r2[q] = *reinterpret_cast<const float2*>(&lds.recs[j[q] * 3 + 2]);
+      const unsigned rp = recs_top + (unsigned)__mul24(fb[q], -48);
+      const v4f a = *(lds_c4)(uintptr_t)rp, b = *(lds_c4)(uintptr_t)(rp + 16u);
+      const v2f c = *(lds_c2)(uintptr_t)(rp + 32u);
+      r0[q] = make_float4(a.x, a.y, a.z, a.w); r1[q] = make_float4(b.x, b.y, b.z, b.w); r2[q] = make_float2(c.x, c.y);
     }
     SplatEval e[K];
 #pragma unroll
@@ -196,7 +238,10 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 #pragma unroll
     for (int q = 0; q < K; ++q) pixel_bwd_scalars<HAS_BG>(ps, e[q], r2[q].y, r1[q].z, r1[q].w, r2[q].x, u[q], w[q]);
 #pragma unroll
-    for (int q = 0; q < K; ++q) lds.UW[j[q] * ROW + lane] = make_float2(u[q], w[q]);
+    for (int q = 0; q < K; ++q) {
+      v2f uw; uw.x = u[q]; uw.y = w[q];
+      *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], -8 * ROW)) = uw;
+    }
   } while (__ballot(pm != 0u) != 0ull);
 }
 
@@ -209,7 +254,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, const uint2* __restrict__ hitmask,
                      const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad,
-                     const unsigned long long* __restrict__ hdr) {
+                     const unsigned long long* __restrict__ hdr, int not_prefilled) {
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[CWG_WAVES];
   // wave-uniform: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
@@ -258,7 +303,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 
   // list entries behind every pixel's last contributor receive zero gradient -- unless dupgrad_prefill_kernel found so
   // many of them in this frame that it zeroed the whole record array with streaming stores instead
-  if ((unsigned)hdr[HDR_PREFILLED] == 0u) {
+  // (not_prefilled: the caller did not launch the prefill kernel for THIS backward -- the header word may still hold the
+  // decision of an earlier backward over the same forward state, e.g. retain_graph)
+  if (not_prefilled || (unsigned)hdr[HDR_PREFILLED] == 0u) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (unsigned k = kmax + lane; k < L; k += 64) {
       float4* dst = dupgrad + (size_t)sorted_dup[s + k] * DG_F4;
@@ -300,7 +347,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   // prefetch loads: the s_waitcnt vmcnt(0) the compiler places at the loop's back edge (for the prefetched registers)
   // then only sees memory operations that had a whole batch of arithmetic to complete. Issued at the end of their own
   // iteration, the stores were waited for every batch (measured: the kernel had a 0.08 ms floor of pure store latency).
-#if defined(SFGS_BWD_SPARSE_CLEAR)
+#if defined(SFGS_BWD_XCHG)
   for (int i = lane; i < B * ROW; i += 64) lds.UW[i] = make_float2(0.f, 0.f);
 #endif
   float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats grp, 4 + grp, 8 + grp
@@ -315,12 +362,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       mw = mw_next;
       if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
     }
-    // this pixel's blended entries of the batch: bit j <=> entry b0 + j
-    unsigned pm = (((bi & 2) ? mw.y : mw.x) >> (16 * (bi & 1))) & 0xffffu;
+    // this pixel's blended entries of the batch: bit 16 + j <=> entry b0 + j
+    unsigned pm = (((bi & 2) ? mw.y : mw.x) << (16 * (1 - (bi & 1)))) & 0xffff0000u;   // left-aligned (phase1_walk)
     if (SFGS_BWD_ABLATE & 2) pm = 0u;
-#if defined(SFGS_BWD_SPARSE_CLEAR)
-    const unsigned pm_batch = pm;
-#endif
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
     if (bi >= 1) {  // batches below the last one are always full
       if (!(SFGS_BWD_ABLATE & 16))
@@ -342,7 +386,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
       }
     }
-#if !defined(SFGS_BWD_SPARSE_CLEAR)
+#if !defined(SFGS_BWD_XCHG)
     if (!(SFGS_BWD_ABLATE & 1))
     {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2.
        // (ds_write_addtid_b32 would do this at twice the LDS store rate -- the kernel drops from 0.49 to 0.46 ms -- but
@@ -363,9 +407,18 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // then a no-op because last_alpha becomes 0; its (u, w) goes to the dummy row). No exec masking, no state copies:
     // the loop body is one straight basic block.
     if (__ballot(pm != 0u) != 0ull) {
+#if SFGS_BWD_PRIO == 1
+      __builtin_amdgcn_s_setprio(2);
+#endif
       if (has_bg) phase1_walk<B, true>(lds, ps, pm, sx, sy, lane);
       else phase1_walk<B, false>(lds, ps, pm, sx, sy, lane);
+#if SFGS_BWD_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
+#if SFGS_BWD_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
@@ -391,7 +444,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         // straight line, four pixels per LDS round trip (the asm fences keep the compiler from hoisting all sixteen
         // 8-byte loads above the arithmetic, which would cost ~30 VGPRs and the fourth wave per SIMD)
 #define SFGS_P2(I) phase2_grid_step<I>(pg, uw##I.x, uw##I.y, ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
+#if defined(SFGS_BWD_XCHG)
+#define SFGS_P2_LOAD(A, Bq, C, D) const float2 uw##A = uw_take(UWrow + A), uw##Bq = uw_take(UWrow + Bq), uw##C = uw_take(UWrow + C), uw##D = uw_take(UWrow + D);
+#else
 #define SFGS_P2_LOAD(A, Bq, C, D) const float2 uw##A = UWrow[A], uw##Bq = UWrow[Bq], uw##C = UWrow[C], uw##D = UWrow[D];
+#endif
 #define SFGS_P2_DO(A, Bq, C, D) SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D);
 #define SFGS_P2_FENCE asm volatile("" ::: "memory");
         if (SFGS_BWD_ABLATE & 4) {
@@ -422,7 +479,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
       } else {
         pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if defined(SFGS_BWD_XCHG)
+#define SFGS_P2(I) { const float2 t_ = uw_take(UWrow + I); phase2_step<I>(pa, t_.x, t_.y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3); }
+#else
 #define SFGS_P2(I) phase2_step<I>(pa, UWrow[I].x, UWrow[I].y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
+#endif
 #pragma nounroll
         for (int c = 0; c < 4; ++c) {
           switch (c) {
@@ -435,24 +496,6 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #undef SFGS_P2
       }
     }
-#if defined(SFGS_BWD_SPARSE_CLEAR)
-    {  // every lane has read its phase-2 slots (in-order LDS); clear the slots THIS pixel wrote
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      unsigned pc = pm_batch;
-      while (__ballot(pc != 0u) != 0ull) {
-        unsigned fb;
-        asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pc));
-        const unsigned j1 = min(fb ^ 31u, (unsigned)B);
-        pc = __builtin_amdgcn_ubfe(pc, 0u, j1);
-        asm("v_ffbh_u32 %0, %1" : "=v"(fb) : "v"(pc));
-        const unsigned j2 = min(fb ^ 31u, (unsigned)B);
-        pc = __builtin_amdgcn_ubfe(pc, 0u, j2);
-        lds.UW[j1 * ROW + lane] = make_float2(0.f, 0.f);
-        lds.UW[j2 * ROW + lane] = make_float2(0.f, 0.f);
-      }
-    }
-#endif
     // Combine the four partial lanes (ej, row 0..3) of every entry in a fixed order (deterministic). The record's 12
     // floats are linear in the sums, so every lane forms them from its PARTIAL sums first; then two rounds of the gfx950
     // half-wave / row SWAPS reduce two (then four) values per instruction pair and leave float 4 k + row of the record
@@ -482,6 +525,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       pq0 = q[0]; pq1 = q[1]; pq2 = q[2]; p_dup = my_dup;
     }
     p_valid = (unsigned)ej < cnt;
+#if SFGS_BWD_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_wave_barrier();
   }
   if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {
@@ -824,7 +870,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
     hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX,
                        nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr); }
+                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr,
+                       (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0); }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
@@ -843,4 +890,25 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   }
   SFGS_POST_LAUNCH("preprocess_bwd", stream, frame->debug);
   return SFGS_OK;
+}
+
+namespace sfgs { int scratch_layout(int32_t N, int32_t W, int32_t H, int64_t D, int64_t ccap, bool with_image, SfgsScratchLayout* out); }
+
+extern "C" int sfgs_raster_backward_scratch(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
+                                            const void* scratch, size_t scratch_bytes, int64_t dup_capacity,
+                                            int64_t coarse_capacity, int64_t num_duplicates, const float* dL_dcolor,
+                                            const float* dL_ddepth, const float* dL_dalpha, void* dupgrad,
+                                            size_t dupgrad_sz, const SfgsGaussianGrads* grads, void* stream_) {
+  SFGS_REQUIRE(frame && frame->struct_size == sizeof(SfgsFrame), SFGS_E_ARG, "SfgsFrame.struct_size mismatch");
+  SFGS_REQUIRE(g && g->struct_size == sizeof(SfgsGaussians), SFGS_E_ARG, "SfgsGaussians.struct_size mismatch");
+  SFGS_REQUIRE(scratch != nullptr, SFGS_E_ARG, "scratch is NULL");
+  SfgsScratchLayout lay;
+  if (int rc = scratch_layout(g->count, frame->image_width, frame->image_height, dup_capacity, coarse_capacity, true, &lay))
+    return rc;
+  SFGS_REQUIRE(scratch_bytes >= lay.total_bytes, SFGS_E_CAPACITY, "scratch: %zu bytes given, %zu needed", scratch_bytes,
+               lay.total_bytes);
+  const char* base = (const char*)scratch;
+  return sfgs_raster_backward(frame, g, radii, base + lay.geom_offset, base + lay.tiles_offset, base + lay.bins_offset,
+                              dup_capacity, coarse_capacity, num_duplicates, base + lay.image_offset, dL_dcolor, dL_ddepth,
+                              dL_dalpha, dupgrad, dupgrad_sz, grads, stream_);
 }

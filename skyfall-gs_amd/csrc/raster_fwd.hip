@@ -527,12 +527,15 @@ bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uin
 __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__ coarse_count,
                                const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
                                unsigned long long* __restrict__ hdr, const unsigned long long* __restrict__ feedback,
-                               const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out);
+                               const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out,
+                               unsigned coarse_capacity);
 
-// plan_roles = 2: the launch's first two workgroups run the plan's epilogues (plan_scan_role) next to the scatter
+// plan_roles = 2: the launch's LAST two workgroups run the plan's epilogues (plan_scan_role) next to the scatter
 // workgroups instead of a launch of their own behind them -- everything they read is final before this kernel starts (the
 // bins' totals come from bin_rank, the per-block statistics from preprocess), and the one thing the scatter may still
-// add, the overflow flag of a bin beyond its capacity, the host derives from the fullest bin's count anyway.
+// add, the overflow flag of a bin beyond its capacity, role 0 derives from the fullest bin's count itself. (At the END of
+// the grid: scatter workgroup w must be workgroup w of the launch, i.e. run on XCD w mod 8 -- rank_row's slab order
+// relies on it)
 __global__ void __launch_bounds__(SCATTER_NT)
 bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
                    const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_base,
@@ -540,11 +543,13 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
                    int plan_roles, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                    const unsigned long long* __restrict__ block_dref, const unsigned long long* __restrict__ feedback,
                    const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out) {
-  if ((int)blockIdx.x < plan_roles) {   // uniform per workgroup
-    plan_scan_role((int)blockIdx.x, NCB, NB, coarse_count, block_nvis, block_dref, hdr, feedback, dup_pool, host_out);
+  const int n_scatter = (int)gridDim.x - plan_roles;
+  if ((int)blockIdx.x >= n_scatter) {   // uniform per workgroup
+    plan_scan_role((int)blockIdx.x - n_scatter, NCB, NB, coarse_count, block_nvis, block_dref, hdr, feedback, dup_pool,
+                   host_out, coarse_capacity);
     return;
   }
-  const int wg = (int)blockIdx.x - plan_roles;   // scatter workgroup
+  const int wg = (int)blockIdx.x;   // scatter workgroup
   __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
   __shared__ unsigned s_red[SCATTER_NT / 64 + 1];
   __shared__ unsigned s_delta[SCATTER_BINS];   // bin's first slab rank - its first sorted position
@@ -749,7 +754,8 @@ static_assert(SCAN_NT == SCATTER_NT, "the plan's epilogues can ride in the scatt
 __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__ coarse_count,
                                const uint32_t* __restrict__ block_nvis, const unsigned long long* __restrict__ block_dref,
                                unsigned long long* __restrict__ hdr, const unsigned long long* __restrict__ feedback,
-                               const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out) {
+                               const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out,
+                               unsigned coarse_capacity) {
   if (role == 1) { bin_base_scan(NCB, coarse_count, hdr); return; }   // second workgroup, concurrently
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
   unsigned long long nvis = 0, dref = 0, cmax = 0;
@@ -783,6 +789,9 @@ __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__
   if (threadIdx.x == 0 && host_out) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) host_out[i] = hdr[i];
+    // When this role rides in the scatter launch, scatter workgroups may still be about to flag a bin that runs past its
+    // slab: the bins' totals are final (bin_rank), so the published overflow word is completed from them
+    if (hdr[HDR_MAX_COARSE] > (unsigned long long)coarse_capacity) host_out[HDR_OVERFLOW] = 1ull;
     // words 8..15: this frame's optional-work counts, and the late statistics of the PREVIOUS frame (its render /
     // backward stages completed before this kernel started: same stream) -- what the caller picks launch hints from
     host_out[8] = hdr[HDR_BIG_COUNT];
@@ -800,8 +809,9 @@ __global__ void __launch_bounds__(SCAN_NT)
 plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                  const unsigned long long* __restrict__ block_dref, unsigned long long* __restrict__ hdr,
                  const unsigned long long* __restrict__ feedback, const unsigned long long* __restrict__ dup_pool,
-                 unsigned long long* __restrict__ host_out) {
-  plan_scan_role((int)blockIdx.x, NCB, NB, coarse_count, block_nvis, block_dref, hdr, feedback, dup_pool, host_out);
+                 unsigned long long* __restrict__ host_out, unsigned coarse_capacity) {
+  plan_scan_role((int)blockIdx.x, NCB, NB, coarse_count, block_nvis, block_dref, hdr, feedback, dup_pool, host_out,
+                 coarse_capacity);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1173,10 +1183,8 @@ __device__ void list_stats(int NCB, uint32_t* __restrict__ coarse_count, unsigne
   unsigned m = 0;
   for (int i = threadIdx.x; i < NCB; i += 256) {
     m = max(m, coarse_count[(size_t)i * CC_STRIDE + 4]);
-    // leave the bins' slot cursors and maxima as the plan left them (zero): a caller may run the render stage on the same
-    // plan again, and select_sort_kernel must then hand out the same slot ranges
-    coarse_count[(size_t)i * CC_STRIDE + 3] = 0u;
-    coarse_count[(size_t)i * CC_STRIDE + 4] = 0u;
+    // (a plan is single-use, include/sfgs.h: the bins' slot cursors, their maxima and the header's long-list words are
+    // only reset by the next plan's memset)
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
@@ -1827,7 +1835,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
     hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(SCAN_NT), 0, stream, (int)NCB, NB, tv.coarse_count, tv.block_nvis,
                        tv.block_dref, tv.hdr,
                        (const unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
-                       (unsigned long long*)counters_pinned_host); }
+                       (unsigned long long*)counters_pinned_host, (unsigned)coarse_capacity); }
   SFGS_POST_LAUNCH("plan_scan", stream, frame->debug);
   return SFGS_OK;
 }
@@ -2100,4 +2108,55 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
     } }
   SFGS_POST_LAUNCH("composite_fwd", stream, frame->debug);
   return SFGS_OK;
+}
+
+// ---- one scratch allocation, one call per stage (ABI 11) --------------------------------------------------------------
+namespace sfgs {
+int scratch_layout(int32_t N, int32_t W, int32_t H, int64_t D, int64_t ccap, bool with_image, SfgsScratchLayout* out) {
+  SFGS_REQUIRE(N >= 0 && W > 0 && H > 0 && D >= 0 && ccap >= 0, SFGS_E_ARG, "bad sizes N=%d W=%d H=%d D=%lld coarse_capacity=%lld",
+               N, W, H, (long long)D, (long long)ccap);
+  SFGS_REQUIRE(D < (1ll << 32) && ccap < (1ll << 31), SFGS_E_UNSUPPORTED, "more than 2^32 duplicates");
+  size_t tb = 0;
+  tiles_view(nullptr, W, H, N, &tb);
+  const size_t a = 256;
+  out->geom_offset = 0;
+  out->tiles_offset = align_up(std::max<size_t>(geom_bytes(N), 1), a);
+  out->bins_offset = out->tiles_offset + align_up(tb, a);
+  out->image_offset = out->bins_offset + align_up(std::max<size_t>(bins_bytes(D, coarse_bins(W, H), ccap), 1), a);
+  out->total_bytes = out->image_offset + (with_image ? align_up(image_bytes(W, H, D), a) : 0);
+  out->dupgrad_bytes = dupgrad_bytes(D);
+  out->coarse_bins = coarse_bins(W, H);
+  out->slot_overhead = sfgs_raster_slot_capacity(W, H, 0);
+  return SFGS_OK;
+}
+}  // namespace sfgs
+
+extern "C" int sfgs_raster_scratch_layout(int32_t N, int32_t W, int32_t H, int64_t dup_capacity, int64_t coarse_capacity,
+                                          int32_t with_image, SfgsScratchLayout* out) {
+  SFGS_REQUIRE(out && out->struct_size == sizeof(SfgsScratchLayout), SFGS_E_ARG, "SfgsScratchLayout.struct_size mismatch");
+  return scratch_layout(N, W, H, dup_capacity, coarse_capacity, with_image != 0, out);
+}
+
+extern "C" int sfgs_raster_forward(const SfgsFrame* frame, const SfgsGaussians* g, int32_t* radii, void* scratch,
+                                   size_t scratch_bytes, int64_t dup_capacity, int64_t coarse_capacity, int32_t with_image,
+                                   void* counters_pinned_host, void* plan_done_event, float* out_color, float* out_depth,
+                                   float* out_alpha, void* stream_) {
+  if (int rc = check_frame(frame)) return rc;
+  SFGS_REQUIRE(g != nullptr && scratch != nullptr, SFGS_E_ARG, "NULL argument");
+  SfgsScratchLayout lay;
+  if (int rc = scratch_layout(g->count, frame->image_width, frame->image_height, dup_capacity, coarse_capacity,
+                              with_image != 0, &lay)) return rc;
+  SFGS_REQUIRE(scratch_bytes >= lay.total_bytes, SFGS_E_CAPACITY, "scratch: %zu bytes given, %zu needed", scratch_bytes,
+               lay.total_bytes);
+  SFGS_REQUIRE(((uintptr_t)scratch & 255u) == 0, SFGS_E_ARG, "scratch must be 256-byte aligned");
+  char* base = (char*)scratch;
+  const size_t geom_sz = lay.tiles_offset, tiles_sz = lay.bins_offset - lay.tiles_offset,
+               bins_sz = lay.image_offset - lay.bins_offset, image_sz = lay.total_bytes - lay.image_offset;
+  if (int rc = sfgs_raster_forward_plan(frame, g, radii, base + lay.geom_offset, geom_sz, base + lay.tiles_offset, tiles_sz,
+                                        base + lay.bins_offset, bins_sz, dup_capacity, coarse_capacity,
+                                        counters_pinned_host, stream_)) return rc;
+  if (plan_done_event) SFGS_CHECK_HIP(hipEventRecord((hipEvent_t)plan_done_event, (hipStream_t)stream_));
+  return sfgs_raster_forward_render(frame, g->count, base + lay.geom_offset, base + lay.tiles_offset, base + lay.bins_offset,
+                                    bins_sz, dup_capacity, coarse_capacity, -1, out_color, out_depth, out_alpha,
+                                    with_image ? base + lay.image_offset : nullptr, image_sz, stream_);
 }

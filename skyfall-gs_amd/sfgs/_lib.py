@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -39,6 +39,13 @@ class SfgsRasterSizes(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("geom_bytes", C.c_size_t), ("tiles_bytes", C.c_size_t),
                 ("bins_bytes", C.c_size_t), ("image_bytes", C.c_size_t), ("dupgrad_bytes", C.c_size_t),
                 ("coarse_bins", C.c_int64)]
+
+
+class SfgsScratchLayout(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("geom_offset", C.c_size_t),
+                ("tiles_offset", C.c_size_t), ("bins_offset", C.c_size_t), ("image_offset", C.c_size_t),
+                ("total_bytes", C.c_size_t), ("dupgrad_bytes", C.c_size_t), ("coarse_bins", C.c_int64),
+                ("slot_overhead", C.c_int64)]
 
 
 class SfgsAdamTensor(C.Structure):
@@ -85,6 +92,11 @@ SYMBOLS = {
     "sfgs_raster_read_counters_pinned": (C.c_int, [_V, _V, C.POINTER(SfgsRasterCounters), _V]),
     "sfgs_raster_forward_render": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _SZ, _I64, _I64, _I64, _V, _V, _V,
                                               _V, _SZ, _V]),
+    "sfgs_raster_scratch_layout": (C.c_int, [_I32, _I32, _I32, _I64, _I64, _I32, C.POINTER(SfgsScratchLayout)]),
+    "sfgs_raster_forward": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _I64, _I64, _I32, _V, _V,
+                                       _V, _V, _V, _V]),
+    "sfgs_raster_backward_scratch": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _I64, _I64, _I64,
+                                                _V, _V, _V, _V, _SZ, C.POINTER(SfgsGaussianGrads), _V]),
     "sfgs_raster_plan_export": (C.c_int, [C.POINTER(SfgsFrame), _I32, _V, _V, _V, _I64, _I64, _I64, _V, _V, _V, _V]),
     "sfgs_raster_plan_merge": (C.c_int, [C.POINTER(SfgsFrame), _I32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I64, _V, _SZ, _V, _SZ, _V, _SZ,

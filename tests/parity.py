@@ -2,8 +2,9 @@
 import numpy as np
 
 RGB_DEPTH_RTOL = 1e-4      # relative L-inf (normalised by max |ref| of the image), float32
-BORDERLINE_FRAC = 1e-4     # <= 0.01 % of pixels may differ more: a splat within an ulp of the 1/255 or
-                           # T < 1e-4 thresholds flips between exp implementations
+BORDERLINE_FRAC = 2e-5     # pixels that may differ more: a splat within an ulp of the 1/255 or T < 1e-4 thresholds
+                           # flips between exp implementations (SURVEY A.7 allows 1e-4; observed <= 7e-6 at 1080p)
+BORDERLINE_FLOOR = 4       # ... but at least this many pixels (one borderline splat covers a handful on a small image)
 GRAD_RTOL_L2 = 1e-3        # relative L2 per gradient tensor
 GRAD_RTOL_MAX = 2e-3       # relative L-inf (normalised by max |ref|)
 
@@ -29,7 +30,7 @@ def assert_image_close(name, got, ref, rtol=RGB_DEPTH_RTOL, borderline_min=1):
     """borderline_min: pixels one borderline splat may flip on a small image (the 0.01 % rule of SURVEY A.7 is a
     statement about large images; one such splat covers a handful of pixels)."""
     r = image_report(name, got, ref, rtol, nan_flips=borderline_min if borderline_min > 1 else 0)
-    assert r["bad"] <= max(borderline_min, int(BORDERLINE_FRAC * r["total"])) or r["max_rel"] <= rtol, r
+    assert r["bad"] <= max(borderline_min, BORDERLINE_FLOOR, int(BORDERLINE_FRAC * r["total"])) or r["max_rel"] <= rtol, r
     assert r["max_rel"] < 5e-2, r   # a flipped borderline splat moves a pixel by <= alpha*T*|c| ~ 1/255
     return r
 
