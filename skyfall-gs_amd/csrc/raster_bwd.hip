@@ -44,6 +44,14 @@
 #if !defined(SFGS_BWD_ZEROFILL)
 #define SFGS_BWD_XCHG 1
 #endif
+//   -DSFGS_BWD_ROWSYM=1         phase 2 (grid case) forms the raw moments of a pixel row from symmetric pairs (phase2_grid_row)
+//   -DSFGS_P1_TAIL=1            phase 1: two entries per iteration while any lane has two left, then ONE single-entry step
+#ifndef SFGS_BWD_ROWSYM
+#define SFGS_BWD_ROWSYM 0
+#endif
+#ifndef SFGS_P1_TAIL
+#define SFGS_P1_TAIL 0
+#endif
 
 namespace sfgs {
 
@@ -171,6 +179,42 @@ __device__ __forceinline__ void phase2_grid_step(Phase2Grid& a, float u, float w
   }
 }
 
+// One pixel ROW (8 pixels) of a lane's group at once (-DSFGS_BWD_ROWSYM, round 4): the columns are symmetric about the
+// tile centre (cx_i = -cx_{7-i}), so with P_i = u_i + u_{7-i}, M_i = u_i - u_{7-i} (i = 0..3) the three raw moments are
+//   S = sum P_i,   X = sum cx_i M_i,   XX = sum cx_i^2 P_i          -- 8 + 3 + 4 + 4 = 19 instructions instead of 24.
+// The |.| sums and the colour sums stay per pixel (phase2_grid_step's forms).
+template <int R>
+__device__ __forceinline__ void phase2_grid_row(Phase2Grid& a, const float2 (&uw)[8], float ncA, float ncB, float kx,
+                                                float ky, float g0, float g1, float g2, float g3) {
+  const float P0 = uw[0].x + uw[7].x, P1 = uw[1].x + uw[6].x, P2 = uw[2].x + uw[5].x, P3 = uw[3].x + uw[4].x;
+  const float M0 = uw[0].x - uw[7].x, M1 = uw[1].x - uw[6].x, M2 = uw[2].x - uw[5].x, M3 = uw[3].x - uw[4].x;
+  const float S = (P0 + P1) + (P2 + P3);
+  const float X = fmaf(-3.5f, M0, fmaf(-2.5f, M1, fmaf(-1.5f, M2, -0.5f * M3)));
+  const float XX = fmaf(12.25f, P0, fmaf(6.25f, P1, fmaf(2.25f, P2, 0.25f * P3)));
+  if constexpr (R == 0) { a.S0 = S; a.X0 = X; a.XX0 = XX; } else { a.S1 = S; a.X1 = X; a.XX1 = XX; }
+#define SFGS_ROWPX(I)                                                                                                  \
+  {                                                                                                                    \
+    constexpr float cx = (float)(I) - 3.5f;                                                                            \
+    const float lx = fmaf(ncA, cx, kx), ly = fmaf(ncB, cx, ky);                                                        \
+    const float u = uw[I].x, w = uw[I].y;                                                                              \
+    if constexpr (R == 0 && (I) == 0) {                                                                                \
+      a.ax = fabsf(u) * fabsf(lx); a.ay = fabsf(u) * fabsf(ly);                                                        \
+      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.r) : "v"(g0), "v"(w), "n"(R * 8 + (I))); \
+      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.g) : "v"(g1), "v"(w), "n"(R * 8 + (I))); \
+      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.b) : "v"(g2), "v"(w), "n"(R * 8 + (I))); \
+      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.d) : "v"(g3), "v"(w), "n"(R * 8 + (I))); \
+    } else {                                                                                                           \
+      a.ax = fmaf(fabsf(u), fabsf(lx), a.ax); a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);                                  \
+      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(R * 8 + (I))); \
+      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(R * 8 + (I))); \
+      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(R * 8 + (I))); \
+      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(R * 8 + (I))); \
+    }                                                                                                                  \
+  }
+  SFGS_ROWPX(0) SFGS_ROWPX(1) SFGS_ROWPX(2) SFGS_ROWPX(3) SFGS_ROWPX(4) SFGS_ROWPX(5) SFGS_ROWPX(6) SFGS_ROWPX(7)
+#undef SFGS_ROWPX
+}
+
 // raw moments -> the sums about the mean that Phase2Acc carries (mxl = m_x - tile centre x, dy_r = m_y - y of row r)
 __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, float mxl, float dy0, float dy1) {
   Phase2Acc o;
@@ -188,61 +232,76 @@ __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, flo
 
 // Phase 1 of one batch (see the kernel's header comment): every lane walks its own blended entries, most significant
 // bit first; exhausted lanes step on the dummy entry B.
-template <int B, bool HAS_BG>
-__device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsigned pm, float sx, float sy, int lane) {
-  constexpr int ROW = BwdLds<B>::ROW;
-  // SFGS_P1_K entries per iteration: their record reads, exponentials and reciprocals are independent and overlap; only
-  // the short transmittance / "colour behind" recurrences chain them
-  // do-while: the caller only enters with at least one blended entry in the wave (a batch without any skips the phase)
-#ifndef SFGS_P1_K
-#define SFGS_P1_K 2
-#endif
-  constexpr int K = SFGS_P1_K;
-  // pm is LEFT-ALIGNED (bit 31 = entry B - 1): v_ffbh gives fb = B - 1 - j directly (0xffffffff for an exhausted lane,
-  // i.e. j = B, the dummy entry), both LDS addresses are ONE v_mad_i32_i24 of fb each and the bit is cleared with a shift
-  // and a v_bfi (2 instructions where xor / min / bfe took 3; round 4)
-  static_assert(B == 16, "left-aligned 16-bit batch masks");
-  // LDS byte offsets (the low 32 bits of a generic LDS address) of record B - 1 and of this pixel's slot in row B - 1;
-  // both live in VGPRs across the loop (v_mad_i32_i24 takes one scalar operand: left to itself the compiler
-  // re-materialises the wave's LDS base with a v_mov in every iteration)
+//
+// One iteration = K entries per lane: their record reads, exponentials and reciprocals are independent and overlap; only
+// the short transmittance / "colour behind" recurrences chain them.
+// pm is LEFT-ALIGNED (bit 31 = entry B - 1): v_ffbh gives fb = B - 1 - j directly (0xffffffff for an exhausted lane,
+// i.e. j = B, the dummy entry), both LDS addresses are ONE v_mad_i32_i24 of fb each and the bit is cleared with a shift
+// and a v_bfi (2 instructions where xor / min / bfe took 3; round 4).
+// recs_top / uw_top: LDS byte offsets (the low 32 bits of a generic LDS address) of record B - 1 and of this pixel's slot
+// in row B - 1; both live in VGPRs across the loop (v_mad_i32_i24 takes one scalar operand: left to itself the compiler
+// re-materialises the wave's LDS base with a v_mov in every iteration).
+template <int K, int ROW, bool HAS_BG>
+__device__ __forceinline__ void phase1_iter(PixelBwd& ps, unsigned& pm, unsigned recs_top, unsigned uw_top, float sx,
+                                            float sy) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) v4f* lds_c4;
   typedef const __attribute__((address_space(3))) v2f* lds_c2;
   typedef __attribute__((address_space(3))) v2f* lds_p2;
+  int fb[K];
+  float4 r0[K], r1[K];
+  float2 r2[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    unsigned f;
+    asm("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(pm));            // 0xffffffff (= -1) for pm == 0
+    fb[q] = (int)f;
+    pm &= ~(0x80000000u >> (f & 31u));                        // pm == 0: clears bit 0, which is never set
+  }
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const unsigned rp = recs_top + (unsigned)__mul24(fb[q], -48);
+    const v4f a = *(lds_c4)(uintptr_t)rp, b = *(lds_c4)(uintptr_t)(rp + 16u);
+    const v2f c = *(lds_c2)(uintptr_t)(rp + 32u);
+    r0[q] = make_float4(a.x, a.y, a.z, a.w); r1[q] = make_float4(b.x, b.y, b.z, b.w); r2[q] = make_float2(c.x, c.y);
+  }
+  SplatEval e[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) e[q] = eval_splat(r0[q].x, r0[q].y, r0[q].z, r0[q].w, r1[q].x, r1[q].y, sx, sy);
+  float u[K], w[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) pixel_bwd_scalars<HAS_BG>(ps, e[q], r2[q].y, r1[q].z, r1[q].w, r2[q].x, u[q], w[q]);
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    v2f uw; uw.x = u[q]; uw.y = w[q];
+    *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], -8 * ROW)) = uw;
+  }
+}
+
+template <int B, bool HAS_BG>
+__device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsigned pm, float sx, float sy, int lane) {
+  constexpr int ROW = BwdLds<B>::ROW;
+#ifndef SFGS_P1_K
+#define SFGS_P1_K 2
+#endif
+  constexpr int K = SFGS_P1_K;
+  static_assert(B == 16, "left-aligned 16-bit batch masks");
   unsigned recs_top = (unsigned)(uintptr_t)&lds.recs[(B - 1) * 3];
   unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(B - 1) * ROW + lane];
   asm volatile("" : "+v"(recs_top), "+v"(uw_top));
+  // the caller only enters with at least one blended entry in the wave (a batch without any skips the phase)
+#if SFGS_P1_TAIL
+  // pairs while ANY lane still has two entries; the odd last round is a single-entry step (half the instructions) instead of
+  // a pair whose second entry is a dummy in every lane
+  static_assert(K == 2, "SFGS_P1_TAIL pairs entries");
+  while (__ballot((pm & (pm - 1u)) != 0u) != 0ull) phase1_iter<2, ROW, HAS_BG>(ps, pm, recs_top, uw_top, sx, sy);
+  if (__ballot(pm != 0u) != 0ull) phase1_iter<1, ROW, HAS_BG>(ps, pm, recs_top, uw_top, sx, sy);
+#else
   do {
-    int fb[K];
-    float4 r0[K], r1[K];
-    float2 r2[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      unsigned f;
-      asm("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(pm));            // 0xffffffff (= -1) for pm == 0
-      fb[q] = (int)f;
-      pm &= ~(0x80000000u >> (f & 31u));                        // pm == 0: clears bit 0, which is never set
-    }
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      const unsigned rp = recs_top + (unsigned)__mul24(fb[q], -48);
-      const v4f a = *(lds_c4)(uintptr_t)rp, b = *(lds_c4)(uintptr_t)(rp + 16u);
-      const v2f c = *(lds_c2)(uintptr_t)(rp + 32u);
-      r0[q] = make_float4(a.x, a.y, a.z, a.w); r1[q] = make_float4(b.x, b.y, b.z, b.w); r2[q] = make_float2(c.x, c.y);
-    }
-    SplatEval e[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) e[q] = eval_splat(r0[q].x, r0[q].y, r0[q].z, r0[q].w, r1[q].x, r1[q].y, sx, sy);
-    float u[K], w[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) pixel_bwd_scalars<HAS_BG>(ps, e[q], r2[q].y, r1[q].z, r1[q].w, r2[q].x, u[q], w[q]);
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      v2f uw; uw.x = u[q]; uw.y = w[q];
-      *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], -8 * ROW)) = uw;
-    }
+    phase1_iter<K, ROW, HAS_BG>(ps, pm, recs_top, uw_top, sx, sy);
   } while (__ballot(pm != 0u) != 0ull);
+#endif
 }
 
 template <int B>
@@ -297,7 +356,6 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   static_assert(B == 16, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 rows");
   // wave-uniform (same for the whole frame): with a black background the bg term of dL/dalpha vanishes identically
   const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
-  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
   const unsigned kmax = tile_kmax[t];   // max of `last` over the tile's pixels (written by the forward; scalar load)
 
@@ -425,11 +483,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // Every lane runs the 16 steps (a DPP source lane must be active); lanes of entries beyond cnt read
     // zero U/Wm rows and their sums are discarded below.
     Phase2Acc pa;
-    float op, cA, cB, cC;
+    float cA, cB, cC;
     {
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
       const float mx = r0.x, my = r0.y;
-      cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x; op = r1.y;
+      cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x;
       const float2* UWrow = &lds.UW[ej * ROW + grp * B];
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
       // rolled loops over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
@@ -454,6 +512,23 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         if (SFGS_BWD_ABLATE & 4) {
           const float2 uw = UWrow[0];
           pg = {uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y};
+        } else if (SFGS_BWD_ROWSYM) {
+          // a pixel row at a time: all 8 pairs of row 0 in flight, then row 1's while row 0 is consumed
+          SFGS_P2_LOAD(0, 1, 2, 3)
+          SFGS_P2_LOAD(4, 5, 6, 7)
+          SFGS_P2_FENCE
+          SFGS_P2_LOAD(8, 9, 10, 11)
+          SFGS_P2_LOAD(12, 13, 14, 15)
+          SFGS_P2_FENCE
+          {
+            const float2 row0[8] = {uw0, uw1, uw2, uw3, uw4, uw5, uw6, uw7};
+            phase2_grid_row<0>(pg, row0, ncA, ncB, kx0, ky0, g0, g1, g2, g3);
+          }
+          SFGS_P2_FENCE
+          {
+            const float2 row1[8] = {uw8, uw9, uw10, uw11, uw12, uw13, uw14, uw15};
+            phase2_grid_row<1>(pg, row1, ncA, ncB, kx1, ky1, g0, g1, g2, g3);
+          }
         } else {
           // software-pipelined by hand: the next four pairs are in flight while four are consumed (8 more live registers;
           // the kernel's occupancy is set by its LDS, 4 waves per SIMD = 128 VGPRs each). The fences pin the order: left
@@ -501,18 +576,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // half-wave / row SWAPS reduce two (then four) values per instruction pair and leave float 4 k + row of the record
     // in lane (ej, row) of register k: 9 v_permlane*_swap + 9 adds instead of 24 ds_bpermute + 24 adds, and each lane
     // stores three floats (the deferred store needs 3 registers instead of 12).
+    // The record holds the RAW sums (GradSums order): op and the conic, which turn them into dL/dmean2D, dL/dconic ...,
+    // are the same for all duplicates of a Gaussian, so preprocess_bwd applies them once to the summed record
+    // (raster_math.h: grad2d_from_sums) instead of this kernel once per (Gaussian, tile) pair -- 20 instructions per batch.
     {
-      const float sxm = -op * ddelx_dx, sym = -op * ddely_dy;
-      float O[12];
-      O[0] = sxm * (cA * pa.x + cB * pa.y);   // dL/dmean2D x (NDC units)
-      O[1] = sym * (cC * pa.y + cB * pa.x);   // dL/dmean2D y
-      O[2] = op * ddelx_dx * pa.ax;           // sum |.| x
-      O[3] = op * ddely_dy * pa.ay;           // sum |.| y
-      O[4] = -0.5f * op * pa.xx;              // dL/dconic A
-      O[5] = -op * pa.xy;                     // dL/dconic B
-      O[6] = -0.5f * op * pa.yy;              // dL/dconic C
-      O[7] = pa.u;                            // dL/d(op)
-      O[8] = pa.r; O[9] = pa.g; O[10] = pa.b; O[11] = pa.d;
+      const float O[12] = {pa.x, pa.y, pa.ax, pa.ay, pa.xx, pa.xy, pa.yy, pa.u, pa.r, pa.g, pa.b, pa.d};
       float q[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -754,10 +822,11 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
 #pragma unroll
   for (int i = 0; i < ROW; ++i) gshl[i] = 0.f;
   if (vis) {
-    Grad2D A;
-    A.gmx = acc.get(0); A.gmy = acc.get(1); A.absx = acc.get(2); A.absy = acc.get(3);
-    A.gA = acc.get(4); A.gB = acc.get(5); A.gC = acc.get(6); A.gop = acc.get(7);
-    A.grgb[0] = acc.get(8); A.grgb[1] = acc.get(9); A.grgb[2] = acc.get(10); A.gdepth = acc.get(11);
+    // the records hold raw sums; op and the conic are applied once, to the total (raster_math.h: grad2d_from_sums)
+    GradSums A;
+    A.x = acc.get(0); A.y = acc.get(1); A.ax = acc.get(2); A.ay = acc.get(3);
+    A.xx = acc.get(4); A.xy = acc.get(5); A.yy = acc.get(6); A.u = acc.get(7);
+    A.r = acc.get(8); A.g = acc.get(9); A.b = acc.get(10); A.d = acc.get(11);
     const float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
     float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
     const float4 qraw = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
@@ -777,9 +846,9 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     if constexpr (K > 0) {
       float shl[ROW];
       load_row<ROW>(shs + (size_t)ROW * g, shl);
-      preprocess_backward_one(f, p, s, q, opacity, shl, A, out, gshl);
+      preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl);
     } else {
-      preprocess_backward_one(f, p, s, q, opacity, nullptr, A, out, gshl);
+      preprocess_backward_sums(f, p, s, q, opacity, nullptr, A, out, gshl);
     }
     if constexpr (RAW) {   // ... and on through the activations (terms recomputed: cheaper than carrying 11 values)
       const float gs[3] = {out.scales[0], out.scales[1], out.scales[2]};

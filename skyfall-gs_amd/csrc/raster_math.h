@@ -555,12 +555,41 @@ struct GaussGrads {
 
 // sh / g_sh may be null (precomputed colours). g_sh [M_total,3] is fully written (zeros above the
 // active degree).
-SFGS_HD void preprocess_backward_one(const FrameParams& f, const float* p, const float* s, const float* q,
-                                     float opacity, const float* sh, const Grad2D& A, GaussGrads& out,
-                                     float* g_sh) {
+// The per-duplicate records composite_bwd writes (round 4) hold the RAW sums over the tile's pixels, about the splat's
+// mean: sum u dx, sum u dy, sum |u| |lx|, sum |u| |ly|, sum u dx^2, sum u dx dy, sum u dy^2, sum u, and the four
+// colour / depth sums (u = G dL/dalpha, lx = cA dx + cB dy, ly = cC dy + cB dx). The factors that turn them into Grad2D
+// -- op and the conic -- are the same for every duplicate of a Gaussian, so they are applied ONCE to the summed record
+// here instead of once per (Gaussian, tile) pair in the compositing kernel (20 instructions per 16-entry batch there).
+// The coefficients are formed exactly as make_record / composite_bwd form them (same float sequence).
+struct GradSums {
+  float x, y, ax, ay, xx, xy, yy, u, r, g, b, d;
+};
+
+SFGS_HD Grad2D grad2d_from_sums(const GradSums& S, const Projected& pr, float opacity, int W, int H) {
+  const float qa = -0.5f * LOG2E * pr.cA, qb = -LOG2E * pr.cB, qc = -0.5f * LOG2E * pr.cC;   // make_record
+  const float cA = -2.0f * LN2 * qa, cB = -LN2 * qb, cC = -2.0f * LN2 * qc;                   // the kernels' natural-log conic
+  const float op = opacity * pr.coef;
+  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+  const float sxm = -op * ddelx_dx, sym = -op * ddely_dy;
+  Grad2D A;
+  A.gmx = sxm * (cA * S.x + cB * S.y);
+  A.gmy = sym * (cC * S.y + cB * S.x);
+  A.absx = op * ddelx_dx * S.ax;
+  A.absy = op * ddely_dy * S.ay;
+  A.gA = -0.5f * op * S.xx;
+  A.gB = -op * S.xy;
+  A.gC = -0.5f * op * S.yy;
+  A.gop = S.u;
+  A.grgb[0] = S.r; A.grgb[1] = S.g; A.grgb[2] = S.b;
+  A.gdepth = S.d;
+  return A;
+}
+
+SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, const float* p, const float* s,
+                                    const float* q, float opacity, const float* sh, const Grad2D& A, GaussGrads& out,
+                                    float* g_sh) {
   const float* V = f.view;
   const float* PM = f.proj;
-  const Projected pr = project_gaussian(f, p, s, q);  // bit-identical to the forward
   float gp[3] = {0.f, 0.f, 0.f};
 
   out.means2D[0] = A.gmx; out.means2D[1] = A.gmy;
@@ -682,6 +711,22 @@ SFGS_HD void preprocess_backward_one(const FrameParams& f, const float* p, const
     gp[2] += (gd[2] - dir[2] * dot) / len;
   }
   out.means3D[0] = gp[0]; out.means3D[1] = gp[1]; out.means3D[2] = gp[2];
+}
+
+// from finished 2D gradients (tests/host_check, the oracle-style callers)
+SFGS_HD void preprocess_backward_one(const FrameParams& f, const float* p, const float* s, const float* q,
+                                     float opacity, const float* sh, const Grad2D& A, GaussGrads& out,
+                                     float* g_sh) {
+  const Projected pr = project_gaussian(f, p, s, q);  // bit-identical to the forward
+  preprocess_backward_pr(f, pr, p, s, q, opacity, sh, A, out, g_sh);
+}
+
+// from the summed per-duplicate records (preprocess_bwd_kernel)
+SFGS_HD void preprocess_backward_sums(const FrameParams& f, const float* p, const float* s, const float* q,
+                                      float opacity, const float* sh, const GradSums& S, GaussGrads& out,
+                                      float* g_sh) {
+  const Projected pr = project_gaussian(f, p, s, q);  // bit-identical to the forward
+  preprocess_backward_pr(f, pr, p, s, q, opacity, sh, grad2d_from_sums(S, pr, opacity, f.W, f.H), out, g_sh);
 }
 
 }  // namespace sfgs

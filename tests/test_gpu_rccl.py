@@ -66,3 +66,34 @@ def test_bench_force_dist_runs_the_collective_every_step():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["collective_backend"] == "nccl" and line["n_gpus"] == 1
     assert line["allreduce_ms_per_step"] is not None and line["allreduce_ms_per_step"] > 0
+
+
+def test_bench_two_ranks_emit_the_line_the_scale_parser_reads():
+    """`bench.py --gpus 2` end to end on the one GPU (ranks share it; collectives over gloo through SFGS_BENCH_BACKEND):
+    the spawn, the barrier-bracketed timing, the per-rank gather and the ONE JSON line whose fields the driver's
+    SCALE_rNN parser reads (BASELINE.json metric / unit, n_gpus, value = the two scenes' Gaussians over the slower
+    rank's time, the rccl block with the world size the collective layer saw)."""
+    env = dict(_env(), SFGS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "200000", "--width", "640",
+                        "--height", "360", "--steps", "5", "--warmup", "3", "--prewarm-steps", "2", "--settle-steps", "2",
+                        "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines   # rank 0 only
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 3 and line["scaling"] == "weak"
+    assert line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["ranks_reporting"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert len(line["per_rank_ms_per_step"]) == 2 and len(line["per_rank_counts"]["rows"]) == 2
+    # value = whole-job Gaussians per second: both ranks' scenes over the slower rank's step time
+    assert abs(line["value"] - 2 * 200000 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 1e-3
+    # each rank rendered its own scene (seed = rank): the visible counts differ
+    rows = line["per_rank_counts"]["rows"]
+    assert rows[0] != rows[1] and all(v > 0 for v in rows[0] + rows[1])
+    assert line["allreduce_ms_per_step"] is not None
