@@ -81,7 +81,10 @@ def main():
                          "24 966-float device all-reduce every step, as the N > 1 runs do")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-only", action="store_true", help="run only the CPU-baseline legs and print them")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    if not argv and "RANK" in os.environ and os.environ.get("SFGS_BENCH_ARGV"):
+        argv = json.loads(os.environ["SFGS_BENCH_ARGV"])   # a rank spawned by `python bench.py --gpus N ...` (see below)
+    args = ap.parse_args(argv)
     CFG = {"cfg2": dict(n=2_000_000, width=1920, height=1080, zrange=(250.0, 350.0), configs_index=1),
            "cfg3": dict(n=2_000_000, width=1024, height=1024, zrange=(250.0, 350.0), configs_index=2),
            "cfg4": dict(n=5_000_000, width=2560, height=1440, zrange=(500.0, 700.0), configs_index=3)}[args.config]
@@ -102,9 +105,12 @@ def main():
         port = s_.getsockname()[1]
         s_.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # this process's arguments travel in the environment: torchrun's own parser rejects script options that are
+        # prefixes of its options ("--n" is ambiguous between --nnodes, --nproc-per-node, ...) even behind the script name
+        os.environ["SFGS_BENCH_ARGV"] = json.dumps(sys.argv[1:])
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                                    f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
-                                   str(port), os.path.abspath(__file__)] + sys.argv[1:])
+                                   str(port), os.path.abspath(__file__)])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

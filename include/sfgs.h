@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 11
+#define SFGS_ABI_VERSION 12
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -125,6 +125,19 @@ typedef struct SfgsGaussians {
   int32_t raw_f64_mask;          /* bit 0: filter_3D is float64; bit 1: `opacities` points to float64 raw opacities
                                     (the reference's _opacity after its first reset_opacity, :483-501); 0 when
                                     filter_3D is NULL */
+  /* EVAL_SH-FOLDED COLOUR PATH (ABI 12; SURVEY 8f row 1, last part). render()'s Python colour paths -- the appearance
+   * MLP's toned coefficients and `convert_SHs_python` -- compute
+   *     colors_precomp = clamp_min(eval_sh(active_sh_degree, sh[N,3,K], dirs[N,3]) + 0.5, 0)
+   * (gaussian_renderer/__init__.py:112-118,121-125; utils/sh_utils.py:57-112) with torch kernels and hand the result over
+   * as colors_precomp. When sh_dirs is non-NULL, `shs` above is that CHANNEL-MAJOR [N,3,sh_coeffs] coefficient tensor and
+   * (shs_channel_major = 1) and sh_dirs the `dirs` argument ([N,3], used as given: eval_sh does not normalise it either), and preprocess /
+   * preprocess_bwd evaluate the expression themselves (degrees 0-3): no N x 3 intermediate, no eval_sh launch. The
+   * backward writes SfgsGaussianGrads.shs channel-major and the direction gradient to SfgsGaussianGrads.sh_dirs (it does
+   * NOT flow into grads.means3D: `dirs` is an input of its own, the caller's graph carries it on). */
+  const float* sh_dirs;          /* [N,3] or NULL = `shs` is [N,sh_coeffs,3] and the direction is normalize(means3D - campos) */
+  int32_t shs_channel_major;     /* with sh_dirs: 1 = `shs` is eval_sh's [N,3,sh_coeffs]; 0 = it is [N,sh_coeffs,3] (what
+                                    render()'s convert_SHs_python path passes to eval_sh is a transposed VIEW of the
+                                    model's [N,K,3] features: hand over the features themselves). 0 without sh_dirs */
 } SfgsGaussians;
 
 /* Gradient outputs of the backward pass (all device, float32, fully overwritten). */
@@ -137,7 +150,8 @@ typedef struct SfgsGaussianGrads {
   float* rotations;      /* [N,4] */
   float* opacities;      /* [N,1]; raw-parameter mode with raw_f64_mask bit 1: [N,1] float64 (cast the pointer) */
   float* colors_precomp; /* [N,3] or NULL */
-  float* shs;            /* [N,sh_coeffs,3] or NULL */
+  float* shs;            /* [N,sh_coeffs,3] or NULL ([N,3,sh_coeffs] with SfgsGaussians.shs_channel_major) */
+  float* sh_dirs;        /* [N,3]; non-NULL exactly when SfgsGaussians.sh_dirs is */
 } SfgsGaussianGrads;
 
 /* Sizes (bytes) of the caller-owned scratch blobs. */

@@ -725,15 +725,18 @@ struct DupAcc {
 // RAW (SfgsGaussians raw-parameter mode): `scales`, `rots`, `opac_` are the model's raw parameters; the activations are
 // recomputed here and the chain rule continues through them, so g_scales / g_rots / g_opac_ receive the RAW parameters'
 // gradients (what sfgs_prepass_backward would make of this kernel's non-raw outputs: the same functions, act_math.h).
-template <int K, int DEG, bool RAW>
+// CM != 0 (SfgsGaussians.sh_dirs): the view direction is given per Gaussian and its gradient goes to g_sh_dirs instead of
+// into g_means3D; CM == 1: coefficients and their gradients channel-major [N,3,K], CM == 2: [N,K,3].
+template <int K, int DEG, bool RAW, int CM>
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
-                      int raw_mask, const float* __restrict__ shs, const int* __restrict__ radii,
+                      int raw_mask, const float* __restrict__ shs, const float* __restrict__ sh_dirs,
+                      const int* __restrict__ radii,
                       const uint2* __restrict__ dup, const float4* __restrict__ dupgrad,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
                       float* __restrict__ g_rots, void* __restrict__ g_opac_, float* __restrict__ g_colors,
-                      float* __restrict__ g_shs) {
+                      float* __restrict__ g_shs, float* __restrict__ g_sh_dirs) {
   constexpr int PB_CHUNK = 128;   // records per staging chunk and wave: 6 KB of LDS
   static_assert((PB_CHUNK * DG_F4) % 64 == 0, "whole load rounds");
   __shared__ float4 pb_stage[PRE_BLOCK / 64][PB_CHUNK * DG_F4];
@@ -821,6 +824,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   float gshl[ROW];
 #pragma unroll
   for (int i = 0; i < ROW; ++i) gshl[i] = 0.f;
+  float gdir[3] = {0.f, 0.f, 0.f};
   if (vis) {
     // the records hold raw sums; op and the conic are applied once, to the total (raster_math.h: grad2d_from_sums)
     GradSums A;
@@ -846,7 +850,12 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     if constexpr (K > 0) {
       float shl[ROW];
       load_row<ROW>(shs + (size_t)ROW * g, shl);
-      preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl);
+      if constexpr (CM != 0) {
+        const float din[3] = {sh_dirs[3 * (size_t)g], sh_dirs[3 * (size_t)g + 1], sh_dirs[3 * (size_t)g + 2]};
+        preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl, CM == 1, din, gdir);
+      } else {
+        preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl);
+      }
     } else {
       preprocess_backward_sums(f, p, s, q, opacity, nullptr, A, out, gshl);
     }
@@ -877,6 +886,10 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   if constexpr (!RAW) static_cast<float*>(g_opac_)[g] = out.opacity;
   if constexpr (K > 0) {
     store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
+    if constexpr (CM != 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g_sh_dirs[3 * (size_t)g + i] = gdir[i];
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 3; ++i) g_colors[3 * (size_t)g + i] = out.rgb[i];
@@ -912,8 +925,9 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_REQUIRE(grads->means3D && grads->means2D && grads->scales && grads->rotations && grads->opacities, SFGS_E_ARG,
                "gradient output pointer is NULL");
   SFGS_REQUIRE((g->colors_precomp != nullptr) == (grads->colors_precomp != nullptr) &&
-                   (g->shs != nullptr) == (grads->shs != nullptr),
+                   (g->shs != nullptr) == (grads->shs != nullptr) && (g->sh_dirs != nullptr) == (grads->sh_dirs != nullptr),
                SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
+  SFGS_REQUIRE(!g->sh_dirs || g->shs, SFGS_E_ARG, "sh_dirs without shs");
   SFGS_REQUIRE(g->filter_3D ? (g->raw_f64_mask & ~3) == 0 : g->raw_f64_mask == 0, SFGS_E_ARG,
                "raw_f64_mask %d: bit 0 = filter_3D is float64, bit 1 = raw opacities are float64; 0 without filter_3D",
                g->raw_f64_mask);
@@ -947,12 +961,19 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
     if (!(frame->launch_hints & SFGS_HINT_NO_BIG_CHUNKS))   // the caller read num_big_chunks == 0 from this frame's plan
     hipLaunchKernelGGL(dupgrad_reduce_kernel, dim3(1024), dim3(256), 0, stream, tv.hdr, bv.big_chunks,
                        (unsigned)big_chunk_capacity(dup_capacity), gv.dup, (float4*)dupgrad);
-#define SFGS_LAUNCH_PBWD_(K, D, RAW)                                                                                   \
-  hipLaunchKernelGGL((preprocess_bwd_kernel<K, D, RAW>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,      \
+#define SFGS_LAUNCH_PBWD_(K, D, RAW, CM)                                                                               \
+  hipLaunchKernelGGL((preprocess_bwd_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,  \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask, g->shs,   \
-                     radii, gv.dup, (const float4*)dupgrad, grads->means3D, grads->means2D, grads->scales,             \
-                     grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs)
-#define SFGS_LAUNCH_PBWD(K, D) do { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true); else SFGS_LAUNCH_PBWD_(K, D, false); } while (0)
+                     g->sh_dirs, radii, gv.dup, (const float4*)dupgrad, grads->means3D, grads->means2D, grads->scales, \
+                     grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs, grads->sh_dirs)
+#define SFGS_LAUNCH_PBWD(K, D)                                                                                         \
+  do {                                                                                                                 \
+    if constexpr ((K) > 0) {                                                                                           \
+      if (g->sh_dirs && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 1); else SFGS_LAUNCH_PBWD_(K, D, false, 1); break; } \
+      if (g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 2); else SFGS_LAUNCH_PBWD_(K, D, false, 2); break; } \
+    }                                                                                                                  \
+    if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 0); else SFGS_LAUNCH_PBWD_(K, D, false, 0);                        \
+  } while (0)
     SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PBWD);
 #undef SFGS_LAUNCH_PBWD
 #undef SFGS_LAUNCH_PBWD_

@@ -120,12 +120,16 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 // with one atomic per block.
 // RAW: `scales`, `rots`, `opac` are the model's raw parameters and `filt` its 3D filter (SfgsGaussians raw-parameter
 // mode): the activations of act_math.h run here instead of in a pre-pass kernel that writes N-sized intermediates.
-template <int K, int DEG, bool RAW>  // K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree
+// CM != 0 (SfgsGaussians.sh_dirs): the view direction of a Gaussian is read from `sh_dirs` -- the eval_sh + 0.5 +
+// clamp_min of render()'s Python colour paths folded in (sh_to_rgb); CM == 1: `shs` is channel-major [N,3,K] (eval_sh's
+// layout), CM == 2: coefficient-major [N,K,3].
+template <int K, int DEG, bool RAW, int CM>  // K = SH coefficients stored per Gaussian (0: colors_precomp), DEG = active degree
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
                   int raw_mask,
-                  const float* __restrict__ colors, const float* __restrict__ shs, int* __restrict__ radii,
+                  const float* __restrict__ colors, const float* __restrict__ shs, const float* __restrict__ sh_dirs,
+                  int* __restrict__ radii,
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
@@ -184,7 +188,12 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         float shl[3 * K];
         load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
         unsigned cm; float dir[3], len;
-        sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len);
+        if constexpr (CM != 0) {
+          const float din[3] = {sh_dirs[3 * (size_t)g], sh_dirs[3 * (size_t)g + 1], sh_dirs[3 * (size_t)g + 2]};
+          sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len, CM == 1 ? 1 : 3, CM == 1 ? K : 1, din);
+        } else {
+          sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len);
+        }
       }
       r = make_record(pr, opacity_in, rgb);
       rec_out[REC_F4 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
@@ -1725,6 +1734,9 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
     SFGS_REQUIRE(g->filter_3D ? (g->raw_f64_mask & ~3) == 0 : g->raw_f64_mask == 0, SFGS_E_ARG,
                  "raw_f64_mask %d: bit 0 = filter_3D is float64, bit 1 = raw opacities are float64; 0 without filter_3D",
                  g->raw_f64_mask);
+    SFGS_REQUIRE(!g->sh_dirs || g->shs, SFGS_E_ARG, "sh_dirs (eval_sh-folded colour path) needs shs");
+    SFGS_REQUIRE(g->sh_dirs ? (g->shs_channel_major & ~1) == 0 : g->shs_channel_major == 0, SFGS_E_ARG,
+                 "shs_channel_major %d: 0 or 1, and 0 without sh_dirs", g->shs_channel_major);
     if (g->shs)
       SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) &&
                        (f->sh_coeffs == 1 || f->sh_coeffs == 4 || f->sh_coeffs == 9 || f->sh_coeffs == 16),
@@ -1794,13 +1806,20 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   int plan_roles = 0;   // 2: the plan's epilogues ride in the scatter launch (two-pass binning)
   if (NB > 0) {
     { ProfScope ps_(KID_PREPROCESS, stream);
-#define SFGS_LAUNCH_PRE_(K, D, RAW)                                                                                    \
-  hipLaunchKernelGGL((preprocess_kernel<K, D, RAW>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,          \
+#define SFGS_LAUNCH_PRE_(K, D, RAW, CM)                                                                                \
+  hipLaunchKernelGGL((preprocess_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,      \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask,           \
-                     g->colors_precomp, g->shs, radii, gv.rec, gv.dup, tv.coarse_count, bv.slabs,                      \
+                     g->colors_precomp, g->shs, g->sh_dirs, radii, gv.rec, gv.dup, tv.coarse_count, bv.slabs,          \
                      (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
                      gv.big_list, tv.hdr, tv.dup_pool, two_pass ? gv.pairs : nullptr, gv.block_items)
-#define SFGS_LAUNCH_PRE(K, D) do { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true); else SFGS_LAUNCH_PRE_(K, D, false); } while (0)
+#define SFGS_LAUNCH_PRE(K, D)                                                                                          \
+  do {                                                                                                                 \
+    if constexpr ((K) > 0) {                                                                                           \
+      if (g->sh_dirs && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 1); else SFGS_LAUNCH_PRE_(K, D, false, 1); break; } \
+      if (g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 2); else SFGS_LAUNCH_PRE_(K, D, false, 2); break; } \
+    }                                                                                                                  \
+    if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 0); else SFGS_LAUNCH_PRE_(K, D, false, 0);                          \
+  } while (0)
       SFGS_DISPATCH_SH(g->shs ? frame->sh_coeffs : 0, frame->sh_degree, SFGS_LAUNCH_PRE);
 #undef SFGS_LAUNCH_PRE
 #undef SFGS_LAUNCH_PRE_

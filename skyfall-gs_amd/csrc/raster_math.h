@@ -252,13 +252,23 @@ SFGS_HD void sh_basis_grad(int deg, float x, float y, float z, float* dBx, float
   }
 }
 
-// colour of one Gaussian from its SH coefficients [M,3] (coefficient-major), +0.5, clamp at 0.
+// colour of one Gaussian from its SH coefficients, +0.5, clamp at 0 (gaussian_renderer/__init__.py:115-118,124-125).
 // clamp_mask bit c set <=> channel c was clamped (its gradient is zero).
+// Coefficient (k, c) sits at sh[k * sk + c * sc]: (sk, sc) = (3, 1) is the rasterizer's own [K,3] layout
+// (`shs = pc.get_features`), (1, K) the CHANNEL-MAJOR [3,K] layout utils/sh_utils.py eval_sh takes (render()'s Python
+// colour paths, :112-118). dir_in != nullptr: the view direction is GIVEN (eval_sh's `dirs` argument, used as it is --
+// eval_sh does not normalise either); otherwise it is normalize(p - campos).
 SFGS_HD void sh_to_rgb(int deg, const float* sh, const float* p, const float* campos, float rgb[3],
-                       unsigned* clamp_mask, float dir[3], float* len_out) {
-  const float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
-  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-  const float x = dx / len, y = dy / len, z = dz / len;
+                       unsigned* clamp_mask, float dir[3], float* len_out, int sk = 3, int sc = 1,
+                       const float* dir_in = nullptr) {
+  float x, y, z, len = 1.f;
+  if (dir_in) {
+    x = dir_in[0]; y = dir_in[1]; z = dir_in[2];
+  } else {
+    const float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
+    len = sqrtf(dx * dx + dy * dy + dz * dz);
+    x = dx / len; y = dy / len; z = dz / len;
+  }
   dir[0] = x; dir[1] = y; dir[2] = z;
   *len_out = len;
   float Bk[16];
@@ -267,7 +277,7 @@ SFGS_HD void sh_to_rgb(int deg, const float* sh, const float* p, const float* ca
   unsigned mask = 0;
   for (int c = 0; c < 3; ++c) {
     float r = 0.f;
-    for (int k = 0; k < M; ++k) r += Bk[k] * sh[k * 3 + c];
+    for (int k = 0; k < M; ++k) r += Bk[k] * sh[k * sk + c * sc];
     r += 0.5f;
     if (r < 0.f) { mask |= 1u << c; r = 0.f; }
     rgb[c] = r;
@@ -585,9 +595,12 @@ SFGS_HD Grad2D grad2d_from_sums(const GradSums& S, const Projected& pr, float op
   return A;
 }
 
+// sh_cm / dir_in / g_dir: the eval_sh-folded colour path (sh_to_rgb above): channel-major coefficients and coefficient
+// gradients, the view direction given, its gradient returned in g_dir[3] instead of flowing into means3D.
 SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, const float* p, const float* s,
                                     const float* q, float opacity, const float* sh, const Grad2D& A, GaussGrads& out,
-                                    float* g_sh) {
+                                    float* g_sh, bool sh_cm = false, const float* dir_in = nullptr,
+                                    float* g_dir = nullptr) {
   const float* V = f.view;
   const float* PM = f.proj;
   float gp[3] = {0.f, 0.f, 0.f};
@@ -689,7 +702,8 @@ SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, c
   if (sh) {
     float rgb[3], dir[3], len;
     unsigned mask;
-    sh_to_rgb(f.sh_degree, sh, p, f.campos, rgb, &mask, dir, &len);
+    const int sk = sh_cm ? 1 : 3, sc = sh_cm ? f.sh_coeffs : 1;
+    sh_to_rgb(f.sh_degree, sh, p, f.campos, rgb, &mask, dir, &len, sk, sc, dir_in);
     float Bk[16], dBx[16], dBy[16], dBz[16];
     sh_basis(f.sh_degree, dir[0], dir[1], dir[2], Bk);
     sh_basis_grad(f.sh_degree, dir[0], dir[1], dir[2], dBx, dBy, dBz);
@@ -697,18 +711,22 @@ SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, c
     float gd[3] = {0.f, 0.f, 0.f};
     for (int ch = 0; ch < 3; ++ch) {
       const float gr = ((mask >> ch) & 1u) ? 0.f : A.grgb[ch];
-      for (int k = 0; k < f.sh_coeffs; ++k) g_sh[k * 3 + ch] = (k < M) ? Bk[k] * gr : 0.f;
+      for (int k = 0; k < f.sh_coeffs; ++k) g_sh[k * sk + ch * sc] = (k < M) ? Bk[k] * gr : 0.f;
       float ax = 0.f, ay = 0.f, az = 0.f;
       for (int k = 0; k < M; ++k) {
-        const float cf = sh[k * 3 + ch];
+        const float cf = sh[k * sk + ch * sc];
         ax += dBx[k] * cf; ay += dBy[k] * cf; az += dBz[k] * cf;
       }
       gd[0] += ax * gr; gd[1] += ay * gr; gd[2] += az * gr;
     }
-    const float dot = dir[0] * gd[0] + dir[1] * gd[1] + dir[2] * gd[2];
-    gp[0] += (gd[0] - dir[0] * dot) / len;
-    gp[1] += (gd[1] - dir[1] * dot) / len;
-    gp[2] += (gd[2] - dir[2] * dot) / len;
+    if (dir_in) {   // the direction was an input of its own: its gradient goes back to the caller's graph
+      g_dir[0] = gd[0]; g_dir[1] = gd[1]; g_dir[2] = gd[2];
+    } else {
+      const float dot = dir[0] * gd[0] + dir[1] * gd[1] + dir[2] * gd[2];
+      gp[0] += (gd[0] - dir[0] * dot) / len;
+      gp[1] += (gd[1] - dir[1] * dot) / len;
+      gp[2] += (gd[2] - dir[2] * dot) / len;
+    }
   }
   out.means3D[0] = gp[0]; out.means3D[1] = gp[1]; out.means3D[2] = gp[2];
 }
@@ -724,9 +742,11 @@ SFGS_HD void preprocess_backward_one(const FrameParams& f, const float* p, const
 // from the summed per-duplicate records (preprocess_bwd_kernel)
 SFGS_HD void preprocess_backward_sums(const FrameParams& f, const float* p, const float* s, const float* q,
                                       float opacity, const float* sh, const GradSums& S, GaussGrads& out,
-                                      float* g_sh) {
+                                      float* g_sh, bool sh_cm = false, const float* dir_in = nullptr,
+                                      float* g_dir = nullptr) {
   const Projected pr = project_gaussian(f, p, s, q);  // bit-identical to the forward
-  preprocess_backward_pr(f, pr, p, s, q, opacity, sh, grad2d_from_sums(S, pr, opacity, f.W, f.H), out, g_sh);
+  preprocess_backward_pr(f, pr, p, s, q, opacity, sh, grad2d_from_sums(S, pr, opacity, f.W, f.H), out, g_sh, sh_cm,
+                         dir_in, g_dir);
 }
 
 }  // namespace sfgs

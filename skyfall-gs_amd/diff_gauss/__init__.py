@@ -238,16 +238,19 @@ def _dp(t):
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings, filter_3D=None):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings, filter_3D=None,
+                sh_dirs=None, sh_degree=None, sh_channel_major=False):
         # filter_3D given: RAW-PARAMETER MODE (include/sfgs.h SfgsGaussians) -- opacities / scales / rotations are the
         # model's raw parameters (opacities possibly float64) and the gradients returned for them are the raw ones
+        # sh_dirs given: EVAL_SH-FOLDED COLOUR PATH -- shs holds eval_sh's coefficients ([N,3,K] when sh_channel_major,
+        # else [N,K,3]), sh_dirs its `dirs`, sh_degree the degree it was called with (sfgs.sh.DeferredColor)
         lib = L.load()
         dev = means3D.device
         di = dev.index
         N = int(means3D.shape[0])
         H, W = int(settings.image_height), int(settings.image_width)
-        sh_coeffs = 0 if shs is None else int(shs.shape[1])
-        need_bwd = any(ctx.needs_input_grad[:7])
+        sh_coeffs = 0 if shs is None else int(shs.shape[2] if sh_channel_major else shs.shape[1])
+        need_bwd = any(ctx.needs_input_grad[:7]) or (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9])
         band = getattr(settings, "tile_rows", None)
         if need_bwd and band:
             raise ValueError("tile_rows (band rendering) is a forward-only extension: the backward needs the whole "
@@ -262,6 +265,10 @@ class _Rasterize(torch.autograd.Function):
             frame = L.SfgsFrame.from_buffer_copy(proto)
             gs = L.SfgsGaussians(_SIZEOF_GS, N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                  opacities.data_ptr(), _dp(colors_precomp), _dp(shs))
+            if sh_dirs is not None:
+                gs.sh_dirs = sh_dirs.data_ptr()
+                gs.shs_channel_major = int(bool(sh_channel_major))
+                frame.sh_degree = int(sh_degree)
             if filter_3D is not None:
                 from sfgs.prepass import f64_mask
                 gs.filter_3D = filter_3D.data_ptr()
@@ -368,15 +375,16 @@ class _Rasterize(torch.autograd.Function):
             # everything the backward needs besides the saved tensors: the frame / Gaussian structs as this frame used them
             # (the saved tensors keep the pointers alive), capacities, counts
             ctx.st = (frame, gs, keep, cap, ccap, D, int(cnt.num_big_chunks), hkey, sh_coeffs, colors_precomp is not None,
-                      shs is not None, opacities.dtype, total, settings)
-            ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D)
+                      shs is not None, opacities.dtype, total, settings, bool(sh_channel_major))
+            ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D,
+                                  sh_dirs)
         return color, depth, norm, alpha, radii
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_norm, g_alpha, g_radii):
         lib = L.load()
-        means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D = ctx.saved_tensors
-        (frame0, gs, keep, cap, ccap, ndup, big_chunks, hkey, K, has_colors, has_shs, opac_dtype, total, settings) = ctx.st
+        means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D, sh_dirs = ctx.saved_tensors
+        (frame0, gs, keep, cap, ccap, ndup, big_chunks, hkey, K, has_colors, has_shs, opac_dtype, total, settings, sh_cm) = ctx.st
         dev = means3D.device
         di = dev.index
         N = int(means3D.shape[0])
@@ -410,6 +418,8 @@ class _Rasterize(torch.autograd.Function):
             if f32_opac:
                 sizes.append(pad(N))
             sizes.append(pad(ncol * N))
+            if sh_dirs is not None:
+                sizes.insert(len(sizes) - 1, pad(3 * N))    # dL/d(dirs) of the eval_sh-folded colour path
             flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
             parts = flat.split_with_sizes(sizes)
             g_rot = parts[0][:4 * N].view(N, 4)
@@ -420,9 +430,10 @@ class _Rasterize(torch.autograd.Function):
             g_opac = parts[4][:N].view(N, 1) if f32_opac else torch.empty(N, 1, dtype=opac_dtype, device=dev)
             g_last = parts[-1][:ncol * N]
             g_col = g_last.view(N, 3) if has_colors else None
-            g_shs = g_last.view(N, K, 3) if has_shs else None
+            g_dirs = parts[-2][:3 * N].view(N, 3) if sh_dirs is not None else None
+            g_shs = (g_last.view(N, 3, K) if sh_cm else g_last.view(N, K, 3)) if has_shs else None
             grads = L.SfgsGaussianGrads(_SIZEOF_GRADS, g_means3D.data_ptr(), g_means2D.data_ptr(), g_scales.data_ptr(),
-                                        g_rot.data_ptr(), g_opac.data_ptr(), _dp(g_col), _dp(g_shs))
+                                        g_rot.data_ptr(), g_opac.data_ptr(), _dp(g_col), _dp(g_shs), _dp(g_dirs))
             # one record per duplicate INDEX: the indices come from 8 disjoint ranges of [0, capacity) (no single allocator
             # word), so the array spans the capacity the frame was planned with; the gaps are never touched
             dg_bytes = _layout(lib, N, int(settings.image_width), int(settings.image_height), cap, ccap, True)[1] if ndup else 256
@@ -434,7 +445,7 @@ class _Rasterize(torch.autograd.Function):
         finally:
             if switch:
                 torch.cuda.set_device(prev_dev)
-        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None
+        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None, g_dirs, None, None
 
 
 def _f32grad(g):
@@ -470,14 +481,22 @@ class _HipBackend:
         if not t.is_cuda:
             raise ValueError(f"{name} must live on the GPU (got {t.device}); this rasterizer has no CPU path")
 
+    supports_sh_dirs = True   # the eval_sh-folded colour path: sh_fold = (degree, coefficients, dirs[N,3], channel_major)
+
     @staticmethod
-    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings):
+    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings, sh_fold=None):
+        if sh_fold is not None:
+            return _Rasterize.apply(means3D, means2D, sh_fold[1], None, opacities, scales, rotations, raster_settings,
+                                    None, sh_fold[2], sh_fold[0], sh_fold[3])
         return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
 
     @staticmethod
     def rasterize_raw(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation, filter_3D,
-                      raster_settings):
+                      raster_settings, sh_fold=None):
         """Raw-parameter mode: the activations + 3D filter of sfgs.prepass run inside preprocess / preprocess_bwd."""
+        if sh_fold is not None:
+            return _Rasterize.apply(means3D, means2D, sh_fold[1], None, raw_opacity, raw_scaling, raw_rotation,
+                                    raster_settings, filter_3D, sh_fold[2], sh_fold[0], sh_fold[3])
         return _Rasterize.apply(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation,
                                 raster_settings, filter_3D)
 
@@ -523,7 +542,18 @@ class GaussianRasterizer(nn.Module):
             opacities = opacities.reshape(N, 1)
         else:
             scales, opacities, rotations, filter_3D = raw      # validated by prepass (dtypes, shapes, device)
-        colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
+        # DeferredColor (sfgs.sh's patched eval_sh; render() added 0.5 and clamped it): the library evaluates
+        # clamp_min(eval_sh(deg, sh, dirs) + 0.5, 0) inside preprocess / preprocess_bwd. Anything else is materialised.
+        sh_fold = None
+        from sfgs import sh as _sh
+        if isinstance(colors_precomp, _sh.DeferredColor):
+            sh_fold = colors_precomp.folded_inputs() if getattr(_backend, "supports_sh_dirs", False) else None
+            if sh_fold is None:
+                colors_precomp = colors_precomp.materialise()
+            elif sh_fold[1].shape[0] != N or tuple(sh_fold[2].shape) != (N, 3) or sh_fold[1].device != means3D.device:
+                raise ValueError("colors_precomp (deferred eval_sh): first dimension / device must match means3D")
+        if sh_fold is None:
+            colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
         if shs is not None:
             shs = _f32c(shs, "shs")
             if shs.dim() != 3 or shs.shape[2] != 3:
@@ -532,14 +562,19 @@ class GaussianRasterizer(nn.Module):
             if shs.shape[1] < (deg + 1) ** 2 or shs.shape[1] not in (1, 4, 9, 16):
                 raise ValueError(f"shs has {shs.shape[1]} coefficients per Gaussian; expected (max_degree + 1)^2 in "
                                  f"(1, 4, 9, 16) and at least {(deg + 1) ** 2} for active degree {deg}")
-        for name, t in (("scales", scales), ("rotations", rotations), ("colors_precomp", colors_precomp), ("shs", shs)):
+        for name, t in (("scales", scales), ("rotations", rotations),
+                        ("colors_precomp", None if sh_fold is not None else colors_precomp), ("shs", shs)):
             if t is not None and (t.shape[0] != N or t.device != means3D.device):
                 raise ValueError(f"{name}: first dimension / device must match means3D")
         _settings_tensors(self.raster_settings, means3D.device)   # shapes / dtypes / devices of the 14-field tuple
+        kw = {} if sh_fold is None else {"sh_fold": sh_fold}
+        if sh_fold is not None:
+            colors_precomp = None
         if raw is not None:
             color, depth, norm, alpha, radii = _backend.rasterize_raw(means3D, means2D, shs, colors_precomp, opacities,
-                                                                      scales, rotations, filter_3D, self.raster_settings)
+                                                                      scales, rotations, filter_3D, self.raster_settings,
+                                                                      **kw)
         else:
-            color, depth, norm, alpha, radii = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities,
-                                                                   scales, rotations, self.raster_settings)
+            color, depth, norm, alpha, radii = _backend.rasterize(means3D, means2D, shs, colors_precomp, opacities,
+                                                                  scales, rotations, self.raster_settings, **kw)
         return color, depth, norm, alpha, radii, None

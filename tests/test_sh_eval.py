@@ -96,8 +96,38 @@ def test_views_leading_dims_and_install():
     mod.eval_sh = lambda *a: (_ for _ in ()).throw(AssertionError("not swapped"))
     fused.install(mod)
     try:
+        assert mod.eval_sh is fused.eval_sh_deferred          # default: the folded route (DeferredColor handles)
+        fused.install(mod, fold=False)
         assert mod.eval_sh is fused.eval_sh
     finally:
         fused.uninstall(mod)
     assert mod.eval_sh is not fused.eval_sh
     assert fused.eval_sh(3, torch.zeros(0, 3, 16, device=dev), torch.zeros(0, 3, device=dev)).shape == (0, 3)
+
+
+def test_deferred_handle_records_exactly_renders_two_statements():
+    """sfgs.sh.DeferredColor on the host (no kernel runs): `+ 0.5` and `clamp_min(0.0)` are RECORDED -- the statements of
+    gaussian_renderer/__init__.py:116-117,124-125 --, the metadata render() / the rasterizer ask for is answered without
+    materialising, and the coefficient layout is detected without a copy."""
+    from sfgs.sh import DeferredColor
+    a = torch.randn(10, 3, 4, requires_grad=True)
+    d = torch.randn(10, 3)
+    h = DeferredColor(1, a, d)
+    assert h.shape == (10, 3) and h.dtype == torch.float32 and h.requires_grad and h.dim() == 2 and len(h) == 10
+    assert h.folded_inputs() is None                                   # bare eval_sh: not render()'s expression
+    for c in (torch.clamp_min(h + 0.5, 0.0), (h + 0.5).clamp_min(0.0), torch.clamp_min(torch.add(h, 0.5), min=0.0)):
+        assert isinstance(c, DeferredColor) and c._sfgs_real is None
+        deg, coef, dirs, cm = c.folded_inputs()
+        assert deg == 1 and coef is a and dirs is d and cm is True
+        assert c.float() is c
+    assert torch.clamp_min(h + 0.25, 0.0).folded_inputs() is None      # other constants: recorded, never folded
+    assert torch.clamp_min(h + 0.5, 0.1).folded_inputs() is None
+    with torch.no_grad():
+        assert not DeferredColor(1, a, d).requires_grad
+    # convert_SHs_python hands eval_sh a transposed VIEW of the model's [N,K,3] features: recognised, no copy
+    feats = torch.randn(10, 4, 3)
+    view = feats.transpose(1, 2).view(-1, 3, 4)
+    deg, coef, dirs, cm = torch.clamp_min(DeferredColor(1, view, d) + 0.5, 0.0).folded_inputs()
+    assert cm is False and coef.shape == (10, 4, 3) and coef.data_ptr() == feats.data_ptr() and coef.is_contiguous()
+    # degree 4 / 25 coefficients stay with the stand-alone kernel
+    assert torch.clamp_min(DeferredColor(4, torch.randn(10, 3, 25), d) + 0.5, 0.0).folded_inputs() is None
