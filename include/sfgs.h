@@ -92,6 +92,9 @@ typedef struct SfgsFrame {
  *                   short lists run as ONE kernel that never writes per-tile items to memory (select_sort_kernel). Always
  *                   correct -- both routes build bit-identical lists --; slower than the two-kernel route when lists
  *                   or bins are long.
+ *   MEDIUM_LISTS    render: as SHORT_LISTS, for frames whose lists reach 513 .. 1 024 entries (what the feedback of the
+ *                   previous frame reported): the same kernel with twice the list capacity (48 KB of LDS per workgroup,
+ *                   the 16-key register network for the lists beyond 512). Always correct; implies the fused route.
  *   NO_PREFILL      backward: do not launch the dead-entry prefill kernel (its decision then reads "no"). Always correct.
  *   NO_BIG_CHUNKS   backward: do not launch the chunk pre-reduction. Only valid when THIS frame's plan reported
  *                   num_big_chunks == 0. */
@@ -100,6 +103,7 @@ typedef struct SfgsFrame {
 #define SFGS_HINT_NO_PREFILL 4u
 #define SFGS_HINT_NO_BIG_CHUNKS 8u
 #define SFGS_HINT_SHORT_LISTS 16u
+#define SFGS_HINT_MEDIUM_LISTS 32u
 
 /* Per-Gaussian inputs = keyword arguments of GaussianRasterizer.__call__
  * (gaussian_renderer/__init__.py:132-140). All float32, contiguous, device memory.
@@ -157,10 +161,12 @@ typedef struct SfgsGaussianGrads {
 /* Sizes (bytes) of the caller-owned scratch blobs. */
 typedef struct SfgsRasterSizes {
   uint32_t struct_size;
-  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, duplicate offsets, the binning's pair list  */
+  size_t geom_bytes;     /* f(N):   per-Gaussian 2D records, duplicate offsets (72 bytes per Gaussian)   */
   size_t tiles_bytes;    /* f(W,H,N): counters, per-tile counts/offsets, per-block scan partials, the
                             binning radix pass's [workgroup][coarse bin] matrices                 */
-  size_t bins_bytes;     /* f(D, coarse_capacity): coarse-bin slabs, per-tile duplicates, sorted lists */
+  size_t bins_bytes;     /* f(D, coarse_capacity, N): coarse-bin slabs, per-tile duplicates, sorted lists; during
+                            the plan the binning's pair list (96 bytes per Gaussian) lies on top of the per-tile
+                            arrays, which only the render stage writes */
   size_t image_bytes;    /* f(W,H,D): per-pixel last contributor, final T, raw depth, and one 8-byte
                             blended-entries mask per pixel and 64-entry list batch (for backward) */
   size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
@@ -187,6 +193,9 @@ typedef struct SfgsRasterCounters {
   int64_t prev_long_tiles;     /* previous frame: tiles with lists longer than 512 entries                     */
   int64_t prev_max_tile_list;  /* previous frame: longest list                                                 */
   int64_t prev_prefilled;      /* previous frame's backward: the prefill kernel ran and chose to fill          */
+  int64_t prev_tiles_over_512; /* previous frame: tiles with more than 512 entries, whichever route sorted them
+                                  (prev_long_tiles counts the tiles LEFT to the long-list kernels: under MEDIUM_LISTS
+                                  only those beyond 1 024): MEDIUM_LISTS pays when they are a sizeable part of the frame */
 } SfgsRasterCounters;
 
 int sfgs_abi_version(void);

@@ -25,6 +25,9 @@
 
 namespace sfgs {
 
+#ifndef SFGS_FWD_STRIP_EXACT
+#define SFGS_FWD_STRIP_EXACT 0   // composite_fwd: exact ellipse-vs-pixel-row strip test (A/B knob, round 4)
+#endif
 constexpr int REG_SORT_SMALL = 512;  // lists up to here: sort_tiles_reg_kernel (<= 8 keys per lane, 8 waves per SIMD)
 constexpr int REG_SORT_MAX = 1024;   // lists up to here: register network too (16 keys per lane), separate kernel
 
@@ -809,7 +812,8 @@ __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__
     host_out[11] = feedback ? feedback[FB_LONG_TILES] : 0ull;
     host_out[12] = feedback ? feedback[FB_MAX_LIST] : 0ull;
     host_out[13] = feedback ? feedback[FB_PREFILLED] : 0ull;
-    host_out[14] = 0ull; host_out[15] = 0ull;
+    host_out[14] = feedback ? feedback[FB_OVER_512] : 0ull;
+    host_out[15] = 0ull;
   }
 }
 
@@ -1033,6 +1037,7 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
     feedback[FB_VALID] = 1ull;                              // them for the next frame's plan (SfgsFrame.feedback)
     feedback[FB_LONG_TILES] = hdr[HDR_LONG_COUNT];
     feedback[FB_MAX_LIST] = hdr[HDR_MAX_LIST];
+    feedback[FB_OVER_512] = hdr[HDR_LONG_COUNT];           // this route lists exactly the tiles beyond 512 entries
   }
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= T8) return;
@@ -1058,19 +1063,24 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
 // beyond REG_SORT_SMALL entries (rare) are written out as unsorted items by a second scan of the tile's wave and left to
 // the long-list kernels, exactly as fine_bin leaves them. The longest list of the frame is collected per bin (word 4 of
 // the line) and reduced by list_stats.
-constexpr int SS_CAP = REG_SORT_SMALL;
+// SS_CAP = entries a tile's LDS list holds = the longest list sorted here: 512 (24 KB of LDS per workgroup, <= 8 keys
+// per lane: the SHORT_LISTS form) or 1 024 (round 4: 48 KB, three workgroups per CU, the 16-key network for the lists
+// beyond 512 -- the MEDIUM_LISTS form for frames whose lists reach 513..1 024 entries, e.g. the reference's 45 / 25 degree
+// IDU cameras (arguments/__init__.py:238-249), which otherwise fell back to fine_bin + two sort kernels).
+template <int SS_CAP>
 struct alignas(16) SelectSortLds {
   unsigned long long key[SS_CAP];
   uint32_t pay[SS_CAP];
 };
 
+template <int SS_CAP>
 __global__ void __launch_bounds__(256)
 select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coarse_count,
                    const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long slot_capacity,
                    uint2* __restrict__ tile_range, uint4* __restrict__ items, uint32_t* __restrict__ long_tiles,
                    unsigned long long* __restrict__ hdr, uint32_t* __restrict__ sorted_id,
                    uint32_t* __restrict__ sorted_dup) {
-  __shared__ SelectSortLds lds_all[COARSE];
+  __shared__ SelectSortLds<SS_CAP> lds_all[COARSE];
   __shared__ unsigned s_cnt[COARSE];
   // workgroup = one row of four tiles of a coarse bin (wave = tile); the four workgroups of a bin are neighbours on one XCD
   const unsigned lb = xcd_remap(blockIdx.x, (unsigned)NCB * COARSE);
@@ -1085,7 +1095,7 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
   const unsigned n = min(line[0], coarse_capacity);
   if (n == 0) { if (lane == 0 && tx < TX8) tile_range[t] = make_uint2(0u, 0u); return; }   // uniform per workgroup
   const uint4* slab = slabs + (size_t)cb * coarse_capacity;
-  SelectSortLds& lds = lds_all[wave];
+  SelectSortLds<SS_CAP>& lds = lds_all[wave];
   // ---- scan: the workgroup reads the slab ONCE (R items per thread and round trip, unconditional loads from clamped
   // indices) and hands every item to the lists of the row's tiles it touches. Positions come from LDS atomics: the order
   // inside a list is irrelevant here, the sort below fixes it ((depth, id) keys are unique within a tile).
@@ -1105,7 +1115,7 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
         m &= m - 1;
         const unsigned pos = atomicAdd(&s_cnt[b - q * COARSE], 1u);
         if (pos < (unsigned)SS_CAP) {
-          SelectSortLds& dst = lds_all[b - q * COARSE];
+          SelectSortLds<SS_CAP>& dst = lds_all[b - q * COARSE];
           dst.key[pos] = ((unsigned long long)it[k].y << 32) | it[k].x;
           dst.pay[pos] = it[k].z + (unsigned)__popc(it[k].w & ((1u << b) - 1u));
         }
@@ -1126,6 +1136,7 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
     else if (c) {
       off = atomicAdd(&line[3], (c + LIST_ALIGN - 1) & ~(unsigned)(LIST_ALIGN - 1));
       atomicMax(&line[4], c);
+      if (c > (unsigned)REG_SORT_SMALL) atomicAdd(&line[5], 1u);   // how many of the frame's lists need the 1 024 form
     }
   }
   if (dropped || c == 0) { if (lane == 0) tile_range[t] = make_uint2(0u, 0u); return; }
@@ -1159,7 +1170,8 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
     if (L <= 64) finish(std::integral_constant<int, 1>{});
     else if (L <= 128) finish(std::integral_constant<int, 2>{});
     else if (L <= 256) finish(std::integral_constant<int, 4>{});
-    else finish(std::integral_constant<int, 8>{});
+    else if (SS_CAP <= 512 || L <= 512) finish(std::integral_constant<int, 8>{});
+    else if constexpr (SS_CAP > 512) finish(std::integral_constant<int, 16>{});
     return;
   }
   // ---- long list: unsorted 16-byte items for the long-list kernels, like fine_bin ------------------------------------
@@ -1188,16 +1200,20 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
 // frame's plan (SfgsFrame.feedback). Run by the first workgroup of the (always launched) long-list kernel: 256 threads.
 __device__ void list_stats(int NCB, uint32_t* __restrict__ coarse_count, unsigned long long* hdr,
                            unsigned long long* __restrict__ feedback) {
-  __shared__ unsigned ls_part[4];
-  unsigned m = 0;
+  __shared__ unsigned ls_part[4], ls_over[4];
+  unsigned m = 0, over = 0;
   for (int i = threadIdx.x; i < NCB; i += 256) {
     m = max(m, coarse_count[(size_t)i * CC_STRIDE + 4]);
+    over += coarse_count[(size_t)i * CC_STRIDE + 5];
     // (a plan is single-use, include/sfgs.h: the bins' slot cursors, their maxima and the header's long-list words are
     // only reset by the next plan's memset)
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
-  if ((threadIdx.x & 63) == 0) ls_part[threadIdx.x >> 6] = m;
+  for (int d = 32; d >= 1; d >>= 1) {
+    m = max(m, (unsigned)__shfl_xor((int)m, d));
+    over += (unsigned)__shfl_xor((int)over, d);
+  }
+  if ((threadIdx.x & 63) == 0) { ls_part[threadIdx.x >> 6] = m; ls_over[threadIdx.x >> 6] = over; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long mx = max(max(ls_part[0], ls_part[1]), max(ls_part[2], ls_part[3]));
@@ -1206,6 +1222,7 @@ __device__ void list_stats(int NCB, uint32_t* __restrict__ coarse_count, unsigne
       feedback[FB_VALID] = 1ull;
       feedback[FB_LONG_TILES] = hdr[HDR_LONG_COUNT];
       feedback[FB_MAX_LIST] = mx;
+      feedback[FB_OVER_512] = (unsigned long long)ls_over[0] + ls_over[1] + ls_over[2] + ls_over[3];
     }
   }
   __syncthreads();
@@ -1561,6 +1578,9 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const unsigned cnt = min(64u, e - b);
     st[lane * 3] = n0; st[lane * 3 + 1] = n1; st[lane * 3 + 2] = n2;
     const float stage_my = n0.y, stage_ey = n2.w;
+#if SFGS_FWD_STRIP_EXACT
+    const float stage_mx = n0.x, stage_qa = n0.z, stage_qb = n0.w, stage_qc = n1.x, stage_op = n1.y;
+#endif
     if (b + 64 + lane < e) {  // prefetch: records of the next batch, ids of the one after
       n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2];
     }
@@ -1578,10 +1598,44 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const float my = stage_my, ey = stage_ey;   // this lane's STAGED entry (entry index = lane)
     const float ylo = (float)(ty * 8) - bound, yhi = (float)(ty * 8 + 1) + bound;
     const bool live = (unsigned)lane < cnt;
+#if SFGS_FWD_STRIP_EXACT
+    // Exact strip test (round 4; tools/workmodel: list steps 0.707 -> 0.643 of the list). Sample points on the pixel grid
+    // (the wave-uniform default): a strip is two pixel ROWS, and on a row y the exponent p2(dx, dy) is a concave parabola
+    // in dx, so its maximum over the tile's 8 columns is at the stationary point clamped to the row's x range -- the same
+    // evaluation, threshold and margins as the binning's tile test (raster_math.h: tile_can_contribute /
+    // alpha_threshold_log2: 0.1 % in alpha + 2e-3 in p2 against the per-pixel fmaf sequence), applied to an 8 x 1 instead of
+    // an 8 x 8 sample rectangle: an entry is dropped from a strip only if alpha < 1/255 on BOTH of its rows, i.e. only
+    // pairs the per-pixel test rejects anyway. Jittered sample points keep the y-extent test alone.
+    unsigned long long b0, b1, b2, b3;
+    if (bound == 0.f) {
+      const float thr = __builtin_amdgcn_logf(0.999f / 255.0f) - __builtin_amdgcn_logf(stage_op) - 2e-3f;   // v_log_f32 = log2
+      const float dxl = stage_mx - (float)(tx * 8 + 7), dxh = stage_mx - (float)(tx * 8);
+      const float inv2a = -0.5f * __builtin_amdgcn_rcpf(stage_qa);
+      const bool concave = stage_qa < 0.f && stage_mx == stage_mx;   // else (degenerate / NaN conic, NaN mean): keep every row
+      auto row_keeps = [&](int r) {
+        const float dy = my - (float)(ty * 8 + r);
+        const float t = stage_qb * dy;
+        const float dx = __builtin_amdgcn_fmed3f(t * inv2a, dxl, dxh);
+        const float p2 = fmaf(fmaf(stage_qa, dx, t), dx, (stage_qc * dy) * dy);
+        return !(p2 < thr) || !concave;              // NaN keeps the entry
+      };
+      const bool yk = !(my + ey < ylo) && !(my - ey > yhi + 6.f);   // the whole tile's y-extent test first
+      b0 = __ballot(live && yk && (row_keeps(0) || row_keeps(1)));
+      b1 = __ballot(live && yk && (row_keeps(2) || row_keeps(3)));
+      b2 = __ballot(live && yk && (row_keeps(4) || row_keeps(5)));
+      b3 = __ballot(live && yk && (row_keeps(6) || row_keeps(7)));
+    } else {
+      b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
+      b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
+      b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
+      b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
+    }
+#else
     const unsigned long long b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
     const unsigned long long b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
     const unsigned long long b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
     const unsigned long long b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
+#endif
     // per-row compact entry lists (bytes) in LDS
     unsigned char* Lw = &rowlist[lw][0][0];
     const int row = lane >> 4;
@@ -1706,11 +1760,14 @@ static int check_frame(const SfgsFrame* f) {
 
 // Route of the render stage's fine binning + short-list sort: SFGS_SORT=fused | split forces one (tests, A/B runs);
 // otherwise the caller's SHORT_LISTS hint picks the fused kernel. Both routes build bit-identical lists.
-static bool sort_fused(uint32_t launch_hints) {
+// Returns 0 (split), 512 or 1024 (the fused kernel's list capacity: SFGS_SORT=fused1024 / the MEDIUM_LISTS hint).
+static int sort_fused(uint32_t launch_hints) {
   const char* e = getenv("SFGS_SORT");
-  if (e && !strcmp(e, "split")) return false;
-  if (e && !strcmp(e, "fused")) return true;
-  return (launch_hints & SFGS_HINT_SHORT_LISTS) != 0;
+  if (e && !strcmp(e, "split")) return 0;
+  if (e && !strcmp(e, "fused")) return 512;
+  if (e && !strcmp(e, "fused1024")) return 1024;
+  if (launch_hints & SFGS_HINT_MEDIUM_LISTS) return 1024;
+  return (launch_hints & SFGS_HINT_SHORT_LISTS) ? 512 : 0;
 }
 
 static bool plan_scan_separate() {   // SFGS_PLAN_SCAN=separate: the plan's epilogues as a launch of their own (A/B, tests)
@@ -1755,7 +1812,7 @@ extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int
   tiles_view(nullptr, W, H, N, &tb);
   out->geom_bytes = geom_bytes(N);
   out->tiles_bytes = tb;
-  out->bins_bytes = bins_bytes(D, coarse_bins(W, H), coarse_capacity);
+  out->bins_bytes = bins_bytes_plan(D, coarse_bins(W, H), coarse_capacity, N);
   out->image_bytes = image_bytes(W, H, D);
   out->dupgrad_bytes = dupgrad_bytes(D);   // D = the duplicate capacity the frame was planned with (sparse index space)
   out->coarse_bins = coarse_bins(W, H);
@@ -1785,8 +1842,9 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   SFGS_REQUIRE(N == 0 || (radii && geom), SFGS_E_ARG, "radii / geom is NULL");
   SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0 && coarse_capacity < (1ll << 31),
                SFGS_E_ARG, "bad dup_capacity / coarse_capacity");
-  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
-               "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
+  SFGS_REQUIRE(bins_sz >= bins_bytes_plan(dup_capacity, NCB, coarse_capacity, N), SFGS_E_CAPACITY,
+               "bins blob: %zu bytes given, %zu needed (sfgs_raster_sizes; the plan keeps its pair list there)", bins_sz,
+               bins_bytes_plan(dup_capacity, NCB, coarse_capacity, N));
   SFGS_REQUIRE(bins, SFGS_E_ARG, "bins blob is NULL");
   const GeomView gv = geom_view(geom, N);
   const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
@@ -1811,7 +1869,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask,           \
                      g->colors_precomp, g->shs, g->sh_dirs, radii, gv.rec, gv.dup, tv.coarse_count, bv.slabs,          \
                      (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
-                     gv.big_list, tv.hdr, tv.dup_pool, two_pass ? gv.pairs : nullptr, gv.block_items)
+                     gv.big_list, tv.hdr, tv.dup_pool, two_pass ? bv.pairs : nullptr, gv.block_items)
 #define SFGS_LAUNCH_PRE(K, D)                                                                                          \
   do {                                                                                                                 \
     if constexpr ((K) > 0) {                                                                                           \
@@ -1835,14 +1893,14 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
     if (two_pass) {
       const int NWG = (int)scatter_groups(N);
       { ProfScope ps_(KID_BIN_COUNT, stream);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(NWG), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, gv.pairs,
+        hipLaunchKernelGGL(bin_count_kernel, dim3(NWG), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, bv.pairs,
                            gv.block_items, tv.sc_cnt, tv.sc_hits); }
       { ProfScope ps_(KID_BIN_RANK, stream);
         hipLaunchKernelGGL(bin_rank_kernel, dim3(((int)NCB + RANK_COLS - 1) / RANK_COLS), dim3(RANK_COLS * RANK_GROUPS), 0,
                            stream, NWG, (int)NCB, tv.sc_cnt, tv.sc_hits, tv.sc_base, tv.coarse_count); }
       plan_roles = plan_scan_separate() ? 0 : 2;
       { ProfScope ps_(KID_BIN_SCATTER, stream);
-        hipLaunchKernelGGL(bin_scatter_kernel, dim3(NWG + plan_roles), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, gv.pairs,
+        hipLaunchKernelGGL(bin_scatter_kernel, dim3(NWG + plan_roles), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, bv.pairs,
                            gv.block_items, tv.sc_cnt, tv.sc_base, bv.slabs, (unsigned)coarse_capacity, tv.hdr, plan_roles,
                            tv.coarse_count, tv.block_nvis, tv.block_dref, (const unsigned long long*)frame->feedback,
                            (const unsigned long long*)tv.dup_pool, (unsigned long long*)counters_pinned_host); }
@@ -2001,7 +2059,7 @@ static void unpack_counters(const unsigned long long* h, SfgsRasterCounters* out
   out->max_coarse_bin = (int64_t)h[HDR_MAX_COARSE];
   out->num_huge_splats = (int64_t)h[HDR_BIG_COUNT];
   out->num_big_chunks = (int64_t)h[HDR_BIG_CHUNKS];
-  out->prev_valid = out->prev_long_tiles = out->prev_max_tile_list = out->prev_prefilled = 0;
+  out->prev_valid = out->prev_long_tiles = out->prev_max_tile_list = out->prev_prefilled = out->prev_tiles_over_512 = 0;
 }
 
 extern "C" int sfgs_raster_counters_decode(const void* host_128, SfgsRasterCounters* out) {
@@ -2017,6 +2075,7 @@ extern "C" int sfgs_raster_counters_decode(const void* host_128, SfgsRasterCount
   out->prev_long_tiles = (int64_t)h[11];
   out->prev_max_tile_list = (int64_t)h[12];
   out->prev_prefilled = (int64_t)h[13];
+  out->prev_tiles_over_512 = (int64_t)h[14];
   return SFGS_OK;
 }
 
@@ -2069,12 +2128,20 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   // Two routes to the sorted per-tile lists (bit-identical results): select_sort_kernel (no per-tile items in memory, one
   // launch less: faster for lists of a few hundred entries and bins of a few thousand items -- the caller's SHORT_LISTS
   // hint) or fine_bin + the sort kernels with the items in memory between them (long lists, crowded bins)
-  const bool fused = sort_fused(frame->launch_hints);
+  const int fused_cap = sort_fused(frame->launch_hints);
+  const bool fused = fused_cap != 0;
   if (fused) {
     { ProfScope ps_(KID_SORT_SMALL, stream);
-      hipLaunchKernelGGL(select_sort_kernel, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
-                         tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity,
-                         tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id, bv.sorted_dup); }
+      if (fused_cap > 512)
+        hipLaunchKernelGGL(select_sort_kernel<1024>, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX,
+                           (int)NCB, tv.coarse_count, bv.slabs, (unsigned)coarse_capacity,
+                           (unsigned long long)dup_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id,
+                           bv.sorted_dup);
+      else
+        hipLaunchKernelGGL(select_sort_kernel<512>, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX,
+                           (int)NCB, tv.coarse_count, bv.slabs, (unsigned)coarse_capacity,
+                           (unsigned long long)dup_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id,
+                           bv.sorted_dup); }
     SFGS_POST_LAUNCH("select_sort", stream, frame->debug);
   } else {
     { ProfScope ps_(KID_FINE_BIN, stream);
@@ -2141,7 +2208,7 @@ int scratch_layout(int32_t N, int32_t W, int32_t H, int64_t D, int64_t ccap, boo
   out->geom_offset = 0;
   out->tiles_offset = align_up(std::max<size_t>(geom_bytes(N), 1), a);
   out->bins_offset = out->tiles_offset + align_up(tb, a);
-  out->image_offset = out->bins_offset + align_up(std::max<size_t>(bins_bytes(D, coarse_bins(W, H), ccap), 1), a);
+  out->image_offset = out->bins_offset + align_up(std::max<size_t>(bins_bytes_plan(D, coarse_bins(W, H), ccap, N), 1), a);
   out->total_bytes = out->image_offset + (with_image ? align_up(image_bytes(W, H, D), a) : 0);
   out->dupgrad_bytes = dupgrad_bytes(D);
   out->coarse_bins = coarse_bins(W, H);

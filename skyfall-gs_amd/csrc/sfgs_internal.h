@@ -102,7 +102,7 @@ __device__ __forceinline__ FrameParams load_frame(const KFrame& k) {
 // ---- blob layouts -------------------------------------------------------------------------------
 constexpr int PRE_BLOCK = 256;      // threads per block of the per-Gaussian kernels
 // SfgsFrame.feedback: 8 uint64 words of caller-owned persistent device memory (late statistics of the previous frame)
-enum { FB_VALID = 0, FB_LONG_TILES = 1, FB_MAX_LIST = 2, FB_PREFILLED = 3 };
+enum { FB_VALID = 0, FB_LONG_TILES = 1, FB_MAX_LIST = 2, FB_PREFILLED = 3, FB_OVER_512 = 4 };   // FB_OVER_512: tiles with > 512 entries
 // reserve `total` duplicate indices from pool `pool`; *fits = the pool still had room
 constexpr int HDR_WORDS = 64;       // uint64 words at the head of the tiles blob
 
@@ -134,16 +134,20 @@ struct GeomView {
   uint2* dup;       // [N] (first duplicate index, duplicate count) of every Gaussian
   uint4* big_list;  // [N] work list of big_walk_kernel: (Gaussian id, tile range x0 | x1 << 16, y0 | y1 << 16, 0);
                     //     HDR_BIG_COUNT entries, written only for splats that reach more than BIG_WALK coarse bins
-  uint4* pairs;     // [NB][PAIRS_PER_BLOCK] two-pass binning: the coarse items of preprocess workgroup b, densely from
-                    //     pairs[b][0] -- (Gaussian id, depth bits, first dup, tile mask | coarse bin << 16) -- written
-                    //     with plain stores (no atomics); bin_scatter_kernel moves them into the bins' slabs
-  uint32_t* block_items;  // [NB] how many
+  uint32_t* block_items;  // [NB] two-pass binning: how many coarse items preprocess workgroup b wrote to BinsView::pairs
 };
 constexpr int PAIRS_PER_BLOCK = PRE_BLOCK * 6;   // a thread emits at most BIG_WALK (= 6) items itself (raster_fwd.hip)
+// The binning's pair list (96 bytes of address space per Gaussian) lives in the BINS blob, on top of the per-tile item /
+// list arrays that only the render stage writes (BinsView::pairs; ADVICE r3: it used to be part of this blob, which the
+// caller keeps for the backward): 72 bytes per Gaussian here instead of 168.
+static inline size_t pairs_bytes(int64_t N) {
+  const int64_t NB = (N + PRE_BLOCK - 1) / PRE_BLOCK;
+  return align_up((size_t)NB * PAIRS_PER_BLOCK * 16, 256);
+}
 static inline size_t geom_bytes(int64_t N) {
   const int64_t NB = (N + PRE_BLOCK - 1) / PRE_BLOCK;
   return align_up((size_t)N * 16 * REC_F4, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N * 16, 256) +
-         align_up((size_t)NB * PAIRS_PER_BLOCK * 16, 256) + align_up((size_t)NB * 4, 256);
+         align_up((size_t)NB * 4, 256);
 }
 static inline GeomView geom_view(void* base, int64_t N) {
   GeomView g;
@@ -152,8 +156,8 @@ static inline GeomView geom_view(void* base, int64_t N) {
   g.rec = (float4*)p; p += align_up((size_t)N * 16 * REC_F4, 256);
   g.dup = (uint2*)p; p += align_up((size_t)N * 8, 256);
   g.big_list = (uint4*)p; p += align_up((size_t)N * 16, 256);
-  g.pairs = (uint4*)p; p += align_up((size_t)NB * PAIRS_PER_BLOCK * 16, 256);
   g.block_items = (uint32_t*)p;
+  (void)NB;
   return g;
 }
 
@@ -180,7 +184,8 @@ struct TilesView {
                             //   past capacity), word 1 = tile hits of those items (words 0-1 are ONE 64-bit atomic
                             //   counter), word 2 = the bin's first list slot (scanned by the plan from the hits)
                             //   word 3 = slots handed out to the bin's tiles so far (select_sort_kernel: one atomic
-                            //   per tile), word 4 = the bin's longest tile list (reduced by list_stats)
+                            //   per tile), word 4 = the bin's longest tile list (reduced by list_stats), word 5 = the bin's
+                            //   tiles with more than 512 entries (select_sort_kernel<1024>; summed by list_stats)
   uint2* tile_range;        // [T8] (first list slot, list length) of every 8x8 tile
   uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]
@@ -232,23 +237,36 @@ static inline size_t big_chunk_capacity(int64_t D) { return (size_t)(D / 512 + 6
 
 struct BinsView {
   uint4* slabs;          // [NCB][coarse_capacity] coarse items (Gaussian id, depth bits, first dup index, 16-bit tile mask)
+  uint2* big_chunks;     // [D / 512 + 64] (Gaussian id, chunk index) of the chunks described above
   uint4* items;          // [D] per-tile segments, unsorted: (Gaussian id, depth bits, dup index, 0)
   uint32_t* sorted_id;   // [D] per-tile lists of Gaussian ids, front to back
   uint32_t* sorted_dup;  // [D] the matching duplicate indices
-  uint2* big_chunks;     // [D / 512 + 64] (Gaussian id, chunk index) of the chunks described above
+  uint4* pairs;          // = items: [NB][PAIRS_PER_BLOCK] two-pass binning (PLAN stage only): the coarse items of preprocess
+                         //     workgroup b, densely from pairs[b][0] -- (Gaussian id, depth bits, first dup, tile mask |
+                         //     coarse bin << 16) -- written with plain stores; bin_scatter_kernel moves them into the slabs
+                         //     before anything of items / sorted_id / sorted_dup (render stage) is written. May reach
+                         //     beyond sorted_dup: bins_bytes_plan() sizes the blob for it.
 };
+// render / backward / export / merge: what the per-tile arrays need
 static inline size_t bins_bytes(int64_t D, int64_t NCB, int64_t coarse_cap) {
-  return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256) +
-         align_up(big_chunk_capacity(D) * 8, 256);
+  return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up(big_chunk_capacity(D) * 8, 256) +
+         align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
+}
+// the plan of N Gaussians (and therefore what sfgs_raster_sizes / sfgs_raster_scratch_layout report): room for the pair list
+static inline size_t bins_bytes_plan(int64_t D, int64_t NCB, int64_t coarse_cap, int64_t N) {
+  const size_t lists = align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
+  return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up(big_chunk_capacity(D) * 8, 256) +
+         (lists > pairs_bytes(N) ? lists : pairs_bytes(N));
 }
 static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coarse_cap) {
   BinsView b;
   char* p = (char*)base;
   b.slabs = (uint4*)p; p += align_up((size_t)NCB * coarse_cap * 16, 256);
+  b.big_chunks = (uint2*)p; p += align_up(big_chunk_capacity(D) * 8, 256);
   b.items = (uint4*)p; p += align_up((size_t)D * 16, 256);
   b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
-  b.sorted_dup = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
-  b.big_chunks = (uint2*)p;
+  b.sorted_dup = (uint32_t*)p;
+  b.pairs = b.items;
   return b;
 }
 

@@ -63,16 +63,24 @@ _cap_hint = {}   # (device index, W, H) -> (duplicate capacity, per-coarse-bin c
 _hint_state = {}  # (device index, stream) -> dict(fb=tensor, huge=int, long=int, prefilled=int, bwd=int)
 HINT_NO_HUGE_SPLATS, HINT_FEW_LONG_LISTS, HINT_NO_PREFILL, HINT_NO_BIG_CHUNKS = 1, 2, 4, 8
 HINT_SHORT_LISTS = 16
+HINT_MEDIUM_LISTS = 32
 # SHORT_LISTS (fine binning + short-list sort as one kernel) pays while the lists stay short and the coarse bins small:
 # measured on the regime set it wins whenever no list exceeds the register sort (512 entries) and loses
 # once lists take its long-list path (a second scan of the slab per long tile)
 SHORT_LIST_MAX, SHORT_BIN_MAX = 512, 8192
+MEDIUM_LIST_MAX = 1024     # MEDIUM_LISTS: the same kernel with room for lists of 513 .. 1 024 entries (low-elevation views)
+MEDIUM_TILE_SHARE = 4      # ... asked for when at least a quarter of the frame's tiles had more than 512 entries
 PREFILL_PROBE_EVERY = 32   # backward passes between two launches of the dead-entry prefill kernel while it keeps saying no
 
 
 def _hints_on():
     import os
     return os.environ.get("SFGS_HINTS", "1") != "0"
+
+
+def _medium_on():
+    import os
+    return os.environ.get("SFGS_MEDIUM_LISTS", "1") != "0"   # A/B switch: 0 = frames with lists of 513 .. 1 024 take the split route
 
 
 def _scratch_budget(dev):
@@ -290,12 +298,18 @@ class _Rasterize(torch.autograd.Function):
                 hs = _hint_state.get(hkey)
                 if hs is None:   # first frame on this stream: no hints yet, everything is launched
                     hs = _hint_state[hkey] = dict(fb=torch.zeros(8, dtype=torch.int64, device=dev), huge=1, long=1,
-                                                  prefilled=1, bwd=0, prefill_ran=False, maxlist=1 << 30, cmax=1 << 30)
+                                                  prefilled=1, bwd=0, prefill_ran=False, maxlist=1 << 30, cmax=1 << 30, over512=0)
             fwd_hints = 0
             if hs is not None:
                 fwd_hints = (HINT_NO_HUGE_SPLATS if hs["huge"] == 0 else 0) | (HINT_FEW_LONG_LISTS if hs["long"] == 0 else 0)
                 if hs["long"] == 0 and hs["maxlist"] <= SHORT_LIST_MAX and hs["cmax"] <= SHORT_BIN_MAX:
                     fwd_hints |= HINT_SHORT_LISTS
+                elif (SHORT_LIST_MAX < hs["maxlist"] <= MEDIUM_LIST_MAX and hs["cmax"] <= SHORT_BIN_MAX and _medium_on()
+                      and hs["over512"] * MEDIUM_TILE_SHARE >= ((W + 7) // 8) * ((H + 7) // 8)):
+                    # the 1 024-entry form runs every tile at half the occupancy: it pays when a sizeable part of the
+                    # frame's lists is that long (low-elevation view 1.676 -> 1.647 ms), not for a few stragglers
+                    # (orbit camera at 25 degrees, a handful of lists up to 852 entries: 1.30 -> 1.38 ms)
+                    fwd_hints |= HINT_SHORT_LISTS | HINT_MEDIUM_LISTS
                 frame.feedback = hs["fb"].data_ptr()
             pin, ev, pin_ptr, ev_handle, cnt = _pinned_counters(dev, stream)
             outs_ptr = outs.data_ptr()
@@ -347,6 +361,7 @@ class _Rasterize(torch.autograd.Function):
                 if cnt.prev_valid:   # the previous frame's render / backward stages, as this frame's plan found them
                     hs["long"] = int(cnt.prev_long_tiles)
                     hs["maxlist"] = int(cnt.prev_max_tile_list)
+                    hs["over512"] = int(cnt.prev_tiles_over_512)
                     if hs["prefill_ran"]:
                         hs["prefilled"] = int(cnt.prev_prefilled)
                 hs["huge"] = int(cnt.num_huge_splats)

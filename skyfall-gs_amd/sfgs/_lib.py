@@ -71,7 +71,8 @@ class SfgsRasterCounters(C.Structure):
     _fields_ = [("num_duplicates", C.c_int64), ("num_duplicates_ref", C.c_int64), ("num_visible", C.c_int64),
                 ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64),
                 ("num_huge_splats", C.c_int64), ("num_big_chunks", C.c_int64), ("prev_valid", C.c_int64),
-                ("prev_long_tiles", C.c_int64), ("prev_max_tile_list", C.c_int64), ("prev_prefilled", C.c_int64)]
+                ("prev_long_tiles", C.c_int64), ("prev_max_tile_list", C.c_int64), ("prev_prefilled", C.c_int64),
+                ("prev_tiles_over_512", C.c_int64)]
 
 
 # every symbol include/sfgs.h declares: name -> (restype, argtypes)

@@ -57,10 +57,12 @@ def _record(entry):
         pass
 
 
-# the route frame 3 must have taken: True = fused select_sort_kernel (no list beyond 512 entries), False = fine_bin + sorts
-EXPECT_SHORT_LISTS = {"cfg2_2M_1080p": True, "cfg3_idu_2M_1024sq": True, "cfg4_5M_1440p_depth": True,
-                      "cfg2_low_elevation_2M_1080p": False, "city_e25_2M_1080p": False}
+# the route frame 3 must have taken: "short" = fused select_sort_kernel<512> (no list beyond 512 entries), "medium" = its
+# 1 024-entry form (round 4: lists of 513 .. 1 024 entries, the low-elevation cameras), "split" = fine_bin + sort kernels
+EXPECT_ROUTE = {"cfg2_2M_1080p": "short", "cfg3_idu_2M_1024sq": "short", "cfg4_5M_1440p_depth": "short",
+                "cfg2_low_elevation_2M_1080p": "medium", "city_e25_2M_1080p": "split"}
 HINT_NO_HUGE_SPLATS, HINT_FEW_LONG_LISTS, HINT_NO_PREFILL, HINT_NO_BIG_CHUNKS, HINT_SHORT_LISTS = 1, 2, 4, 8, 16
+HINT_MEDIUM_LISTS = 32
 PARAMS = [(c, None) for c in CASES] + [("cfg2_2M_1080p", "fused"), ("cfg2_2M_1080p", "split")]
 
 
@@ -89,8 +91,10 @@ def test_full_size_oracle_parity(case, sort_route, monkeypatch):
     run_hip(frame, g, gc, gd, debug=False, full_counters=False)          # frame 2
     out = run_hip(frame, g, gc, gd, debug=False, full_counters=False)    # frame 3: the timed configuration
     fh, bh = out["counters"]["fwd_hints"], diff_gauss.last_backward_hints()
-    assert bool(fh & HINT_SHORT_LISTS) == EXPECT_SHORT_LISTS[case], (case, fh)
-    if EXPECT_SHORT_LISTS[case]:   # bench.py's steady state: every optional kernel hinted away
+    route = {0: "split", HINT_SHORT_LISTS: "short", HINT_SHORT_LISTS | HINT_MEDIUM_LISTS: "medium"}.get(
+        fh & (HINT_SHORT_LISTS | HINT_MEDIUM_LISTS))
+    assert route == EXPECT_ROUTE[case], (case, fh)
+    if route == "short":   # bench.py's steady state: every optional kernel hinted away
         assert fh == HINT_NO_HUGE_SPLATS | HINT_FEW_LONG_LISTS | HINT_SHORT_LISTS, (case, fh)
         assert bh == HINT_NO_PREFILL | HINT_NO_BIG_CHUNKS, (case, bh)
     out["counters"]["max_tile_list"] = first["counters"]["max_tile_list"]

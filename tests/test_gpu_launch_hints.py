@@ -87,3 +87,59 @@ def test_hints_never_change_a_result():
     # the sequence did exercise what it claims to
     by = {r["name"]: r["counters"] for r in got}
     assert by["long_lists#1"]["num_duplicates"] > 10 * by["calm#1"]["num_duplicates"]
+
+
+def test_medium_lists_hint_engages_and_changes_nothing():
+    """A frame whose longest list has 513 .. 1 024 entries (the reference's low-elevation IDU cameras): from the second
+    frame on the wrapper asks for the fused kernel's 1 024-entry form (SHORT_LISTS | MEDIUM_LISTS) instead of falling back
+    to fine_bin + two sort kernels; images, radii and gradients equal the hint-less run bit for bit."""
+    import diff_gauss
+    from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, collect_full_counters, last_counters
+    dev = torch.device("cuda:0")
+    w, h = 24, 24
+    frame, g = scene(900, w, h, seed=5, zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.03))
+    gc, gd = (t.to(dev) for t in upstream_grads(w, h, 2))
+
+    def run(n_frames):
+        out = []
+        for _ in range(n_frames):
+            settings = GaussianRasterizationSettings(
+                image_height=h, image_width=w, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"],
+                kernel_size=frame["kernel_size"], subpixel_offset=None, bg=frame["bg"].to(dev), scale_modifier=1.0,
+                viewmatrix=frame["view"].to(dev), projmatrix=frame["proj"].to(dev), sh_degree=0,
+                campos=frame["campos"].to(dev), prefiltered=False, debug=False)
+            t = {k: v.to(dev).requires_grad_(True) for k, v in g.items() if v is not None}
+            m2 = torch.zeros(900, 3, device=dev, requires_grad=True)
+            color, depth, _, alpha, radii, _ = GaussianRasterizer(settings)(
+                means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors_precomp"],
+                scales=t["scales"], rotations=t["rotations"])
+            torch.autograd.backward([color, torch.nan_to_num(depth)], [gc, gd])
+            out.append(dict(color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(),
+                            radii=radii.cpu().numpy(), m2=m2.grad.cpu().numpy(), counters=last_counters(),
+                            **{"g_" + k: v.grad.cpu().numpy() for k, v in t.items()}))
+        return out
+
+    old = os.environ.get("SFGS_HINTS")
+    try:
+        os.environ["SFGS_HINTS"] = "0"
+        diff_gauss._hint_state.clear()
+        collect_full_counters(True)
+        ref = run(1)
+        collect_full_counters(False)
+        assert 512 < ref[0]["counters"]["max_tile_list"] <= 1024
+        os.environ["SFGS_HINTS"] = "1"
+        diff_gauss._hint_state.clear()
+        got = run(3)
+    finally:
+        collect_full_counters(False)
+        if old is None:
+            os.environ.pop("SFGS_HINTS", None)
+        else:
+            os.environ["SFGS_HINTS"] = old
+    both = diff_gauss.HINT_SHORT_LISTS | diff_gauss.HINT_MEDIUM_LISTS
+    assert got[0]["counters"]["fwd_hints"] & both == 0                   # nothing learnt yet: the split route
+    assert got[2]["counters"]["fwd_hints"] & both == both                 # lists of 513 .. 1 024: the 1 024-entry fused kernel
+    for r in got:
+        for k in ref[0]:
+            if k != "counters":
+                np.testing.assert_array_equal(np.nan_to_num(r[k], nan=-1.0), np.nan_to_num(ref[0][k], nan=-1.0), err_msg=k)

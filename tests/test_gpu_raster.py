@@ -376,19 +376,21 @@ def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
 
 
+@pytest.mark.parametrize("route", ["fused", "fused1024"])
 @pytest.mark.parametrize("case", ["precomp_small", "sh1_ragged", "cfg2_like", "big_splats", "screen_filling", "lists_800",
                                   "lists_2k", "lists_6k", "lists_10k", "cfg2_200k_1080p", "uhd_two_bin_rounds"])
-def test_fused_select_sort_equals_fine_bin_plus_sort(case, monkeypatch):
+def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, monkeypatch):
     """select_sort_kernel (a workgroup hands a coarse bin's items to the LDS lists of a row of tiles, every wave sorts its
     tile in registers and writes the final lists; the route the SHORT_LISTS hint selects, forced here) and the two-kernel route with the per-tile items in memory between them
     (SFGS_SORT=split: fine_bin + sort_tiles_reg) build the same lists -- same members, same (depth, id) order, same
     duplicate indices; only WHERE a tile's list sits inside its bin's slot range may differ -- so images, radii,
     counters (incl. the longest list) and every gradient are equal bit for bit. Long lists (> 512) take the second scan
-    and the long-list kernels in the fused route."""
+    and the long-list kernels in the fused route. route fused1024 = the MEDIUM_LISTS form of the kernel (lists up to 1 024
+    entries stay in LDS and are sorted by the 16-key network: case lists_800)."""
     c = CASES.get(case) or BINNING_CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=5, **c["kw"])
     gc, gd = upstream_grads(c["W"], c["H"], 2)
-    monkeypatch.setenv("SFGS_SORT", "fused")
+    monkeypatch.setenv("SFGS_SORT", route)
     a = run_hip(frame, g, gc, gd)
     monkeypatch.setenv("SFGS_SORT", "split")
     b = run_hip(frame, g, gc, gd)

@@ -148,8 +148,8 @@ def test_launch_hint_bits_match_the_c_header():
     bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SFGS_HINT_([A-Z_]+)\s+(\d+)u", hdr)}
     assert bits == {"NO_HUGE_SPLATS": diff_gauss.HINT_NO_HUGE_SPLATS, "FEW_LONG_LISTS": diff_gauss.HINT_FEW_LONG_LISTS,
                     "NO_PREFILL": diff_gauss.HINT_NO_PREFILL, "NO_BIG_CHUNKS": diff_gauss.HINT_NO_BIG_CHUNKS,
-                    "SHORT_LISTS": diff_gauss.HINT_SHORT_LISTS}
+                    "SHORT_LISTS": diff_gauss.HINT_SHORT_LISTS, "MEDIUM_LISTS": diff_gauss.HINT_MEDIUM_LISTS}
     vals = sorted(bits.values())
     assert all(v & (v - 1) == 0 for v in vals) and len(set(vals)) == len(vals)
-    assert diff_gauss.SHORT_LIST_MAX <= 512
+    assert diff_gauss.SHORT_LIST_MAX <= 512 and diff_gauss.MEDIUM_LIST_MAX <= 1024   # what select_sort_kernel<512 / 1024> sort
     assert int(re.search(r"#define\s+SFGS_ABI_VERSION\s+(\d+)", hdr).group(1)) == L.ABI_VERSION
