@@ -71,7 +71,10 @@ __device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, co
 }
 
 constexpr int BIG_WALK = 6;  // coarse bins above which a splat's walk is done by a whole wave (big_walk_kernel)
-constexpr int BIG_WALK_BLOCKS = 256;    // persistent grid of big_walk_kernel: 1 024 waves = 1 per SIMD (an empty list costs one short dispatch)
+constexpr int BIG_WALK_BLOCKS = 1024;   // persistent grid of big_walk_kernel: 4 096 waves = 4 per SIMD, what its 120 VGPRs allow (round 4:
+                                        // with 1 per SIMD nothing hid the tile tests' dependent chains -- near-camera regime); the
+                                        // kernel is not launched at all under the NO_HUGE_SPLATS hint
+constexpr int BIG_WALK_CACHE = 2048;    // coarse-bin masks a wave keeps in LDS between its count and emit passes (16-bit each)
 static_assert(BIG_WALK <= 8, "the per-lane walk keeps one 16-bit mask per coarse bin in two 64-bit registers");
 
 struct WalkArgs { SplatRec r; BinRange br; float thr; int cx0, cx1, cy0, cy1; };
@@ -360,19 +363,30 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     const unsigned g_L = (unsigned)__shfl((int)g, L), depth_L = __shfl(depth_bits, L);
     unsigned dup = __shfl((unsigned)(base + ex), L);
     const int ncb = (a.cx1 - a.cx0) * (a.cy1 - a.cy0);
+    // ONE returning atomic instruction per splat (round 4). The walk takes up to 16 iterations of four coarse bins (a
+    // mid-size splat has < 64 of them); the item of (iteration it, group q) is appended by lane 16 q + it, which keeps the
+    // iteration's mask / bin / first duplicate index when its turn comes -- so all of the splat's <= 63 atomics are in
+    // flight TOGETHER and the wave waits for one round trip per splat instead of one per iteration (the near-camera
+    // regime -- 200 k splats of ~36 coarse bins -- spent most of this kernel's 2.4 ms in those waits, one rank at a time).
+    const int q = lane >> 4, turn = lane & 15;
+    const unsigned long long below_q = (1ull << (16 * q)) - 1ull;
+    unsigned m_mine = 0u, dp_mine = 0u;
+    int cb_mine = 0;
     for (int it = 0; it * 4 < ncb; ++it) {
       int cb;
       const unsigned long long bal = walk_ballot4(a, it, lane, f.W, f.H, bound, &cb, CX);
-      const int q = lane >> 4;
-      const unsigned m = (unsigned)(bal >> (16 * q)) & 0xffffu;
-      if ((lane & 15) == 0 && m) {  // the first lane of each 16-lane group appends its coarse bin's item
-        const unsigned before = (unsigned)__popcll(bal & ((1ull << (16 * q)) - 1ull));
-        const unsigned rank = (unsigned)atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)cb * CC_STRIDE]),
-                                                  1ull | ((unsigned long long)(unsigned)__popc(m) << 32));
-        if (rank < coarse_capacity) slabs[(size_t)cb * coarse_capacity + rank] = make_uint4(g_L, depth_L, dup + before, m);
-        else hdr[HDR_OVERFLOW] = 1ull;
+      if (turn == it) {
+        m_mine = (unsigned)(bal >> (16 * q)) & 0xffffu;
+        cb_mine = cb;
+        dp_mine = dup + (unsigned)__popcll(bal & below_q);
       }
       dup += (unsigned)__popcll(bal);
+    }
+    if (m_mine) {
+      const unsigned rank = (unsigned)atomicAdd(reinterpret_cast<unsigned long long*>(&coarse_count[(size_t)cb_mine * CC_STRIDE]),
+                                                1ull | ((unsigned long long)(unsigned)__popc(m_mine) << 32));
+      if (rank < coarse_capacity) slabs[(size_t)cb_mine * coarse_capacity + rank] = make_uint4(g_L, depth_L, dp_mine, m_mine);
+      else hdr[HDR_OVERFLOW] = 1ull;
     }
   }
   // per-block statistics (summed by plan_scan; no contended atomics)
@@ -651,6 +665,10 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
                 unsigned coarse_capacity, unsigned long long dup_capacity, uint2* __restrict__ big_chunks,
                 unsigned big_chunk_cap, unsigned long long* __restrict__ hdr, unsigned long long* __restrict__ dup_pool,
                 unsigned npools) {
+  // the count pass leaves every coarse bin's 16-bit tile mask in LDS for the emit pass (round 4: the 16 tile tests per bin
+  // were done twice); splats of more than BIG_WALK_CACHE coarse bins (images beyond ~2 K) recompute the tail
+  __shared__ uint16_t bw_masks[4][BIG_WALK_CACHE];
+  uint16_t* my_masks = bw_masks[threadIdx.x >> 6];
   const unsigned n_big = (unsigned)hdr[HDR_BIG_COUNT];
   const int lane = threadIdx.x & 63;
   const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
@@ -676,9 +694,15 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
     for (int i0 = 0; i0 < ncb; i0 += 64) {
       const int j = i0 + lane;
       unsigned c = 0;
-      if (j < ncb) c = (unsigned)__popc(coarse_hits(a.r, a.thr, a.br, a.cx0 + j % nx, a.cy0 + j / nx, W, H, bound));
+      if (j < ncb) {
+        const unsigned m = coarse_hits(a.r, a.thr, a.br, a.cx0 + j % nx, a.cy0 + j / nx, W, H, bound);
+        if (j < BIG_WALK_CACHE) my_masks[j] = (uint16_t)m;
+        c = (unsigned)__popc(m);
+      }
       total += wave_sum_u32(c);
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // reserve the duplicate indices
     unsigned long long base = 0ull;
     bool ok = true;
@@ -710,7 +734,7 @@ big_walk_kernel(KFrame kf, const uint4* __restrict__ big_list, const float4* __r
       int cb = 0;
       if (j < ncb) {
         const int cx = a.cx0 + j % nx, cy = a.cy0 + j / nx;
-        m = coarse_hits(a.r, a.thr, a.br, cx, cy, W, H, bound);
+        m = j < BIG_WALK_CACHE ? (unsigned)my_masks[j] : coarse_hits(a.r, a.thr, a.br, cx, cy, W, H, bound);
         cb = cy * CX + cx;
       }
       const unsigned c = (unsigned)__popc(m);
