@@ -215,6 +215,48 @@ __device__ __forceinline__ void phase2_grid_row(Phase2Grid& a, const float2 (&uw
 #undef SFGS_ROWPX
 }
 
+// ---- batches of EIGHT entries (composite_bwd_kernel<8>; VERDICT r3 item 1b: built to be MEASURED) ---------------------------
+// 8 entries x 8 pixel groups: lane = (entry ej = lane & 7, pixel row grp = lane >> 3), eight pixels per lane. The (u, w)
+// matrix is 9 x 65 pairs = 4.7 KB per wave (LDS no longer limits the occupancy: the registers do, at 5 waves per SIMD), but
+// a DPP row of 16 lanes now hosts TWO pixel rows, so the upstream gradients of pixel (grp, I) come from lane I of the row
+// for the even group and from lane 8 + I for the odd one: two bank-masked v_fmac_dpp per (pixel, channel) instead of one.
+struct Phase2Grid8 {
+  float S, X, XX, ax, ay, r, g, b, d;
+};
+
+template <int I>
+__device__ __forceinline__ void phase2_grid8_step(Phase2Grid8& a, float u, float w, float ncA, float ncB, float kx,
+                                                  float ky, float g0, float g1, float g2, float g3) {
+  constexpr float cx = (float)I - 3.5f;
+  const float lx = fmaf(ncA, cx, kx), ly = fmaf(ncB, cx, ky);
+  if constexpr (I == 0) {
+    a.S = u; a.X = u * cx; a.XX = u * (cx * cx);
+    a.ax = fabsf(u) * fabsf(lx); a.ay = fabsf(u) * fabsf(ly);
+  } else {
+    a.S += u; a.X = fmaf(u, cx, a.X); a.XX = fmaf(u, cx * cx, a.XX);
+    a.ax = fmaf(fabsf(u), fabsf(lx), a.ax); a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);
+  }
+  // even pixel rows sit in lanes 0..7 of their DPP row (banks 0, 1), odd ones in lanes 8..15 (banks 2, 3)
+#define SFGS_FMAC8(ACC, G)                                                                                              \
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3" : "+v"(ACC) : "v"(G), "v"(w), "n"(I));     \
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xc" : "+v"(ACC) : "v"(G), "v"(w), "n"(8 + I));
+  SFGS_FMAC8(a.r, g0) SFGS_FMAC8(a.g, g1) SFGS_FMAC8(a.b, g2) SFGS_FMAC8(a.d, g3)
+#undef SFGS_FMAC8
+}
+
+__device__ __forceinline__ Phase2Acc phase2_grid8_finish(const Phase2Grid8& a, float mxl, float dy0) {
+  Phase2Acc o;
+  const float t = mxl * a.S - a.X;   // sum u dx
+  o.u = a.S;
+  o.x = t;
+  o.y = dy0 * a.S;
+  o.xx = mxl * (t - a.X) + a.XX;
+  o.xy = dy0 * t;
+  o.yy = (dy0 * dy0) * a.S;
+  o.ax = a.ax; o.ay = a.ay; o.r = a.r; o.g = a.g; o.b = a.b; o.d = a.d;
+  return o;
+}
+
 // raw moments -> the sums about the mean that Phase2Acc carries (mxl = m_x - tile centre x, dy_r = m_y - y of row r)
 __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, float mxl, float dy0, float dy1) {
   Phase2Acc o;
@@ -286,7 +328,7 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 #define SFGS_P1_K 2
 #endif
   constexpr int K = SFGS_P1_K;
-  static_assert(B == 16, "left-aligned 16-bit batch masks");
+  static_assert(B == 16 || B == 8, "left-aligned batch masks of B bits");
   unsigned recs_top = (unsigned)(uintptr_t)&lds.recs[(B - 1) * 3];
   unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(B - 1) * ROW + lane];
   asm volatile("" : "+v"(recs_top), "+v"(uw_top));
@@ -305,7 +347,7 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 }
 
 template <int B>
-__global__ void __launch_bounds__(64 * CWG_WAVES, 4)
+__global__ void __launch_bounds__(64 * CWG_WAVES, B == 8 ? 5 : 4)   // B = 8: 4.7 KB of LDS per wave, 5 waves per SIMD by registers
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
@@ -353,7 +395,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
     pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
   }
-  static_assert(B == 16, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 rows");
+  static_assert(B == 16 || B == 8, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 row pairs, or 8 entries x 8 rows");
   // wave-uniform (same for the whole frame): with a black background the bg term of dL/dalpha vanishes identically
   const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
 
@@ -374,6 +416,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   if (kmax == 0) return;
 
   const int ej = lane & (B - 1), grp = lane / B;  // phase-2 role of this lane
+  const int orow = lane >> 4;   // which float of each record quarter this lane stores (its DPP row; = grp for B = 16)
   // wave-uniform: sample points on the pixel grid (max |subpixel_offset| of the plan == 0)?
   const bool on_grid = !(kf.subpix && (unsigned)hdr[HDR_SUBPIX_BOUND] != 0u);
   const float ocx = (float)(tx * 8) + 3.5f, ocy = (float)(ty * 8) + 3.5f;  // tile centre
@@ -397,7 +440,8 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   }
   // hit-mask words of the tile's 64-entry groups (one uint2 per pixel and group), fetched one group ahead
   static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
-  int g_cur = (nbatch - 1) >> 2;
+  constexpr int BPG = 64 / B;   // batches per 64-entry hit-mask group
+  int g_cur = (nbatch - 1) / BPG;
   uint2 mw = hitmask[(size_t)s + 64u * (unsigned)g_cur + lane];
   uint2 mw_next = make_uint2(0u, 0u);
   if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
@@ -415,13 +459,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const unsigned b0 = (unsigned)bi * B;
     const unsigned cnt = min((unsigned)B, kmax - b0);
     const unsigned my_dup = dup_cur;
-    if ((bi >> 2) != g_cur) {
-      g_cur = bi >> 2;
+    if ((bi / BPG) != g_cur) {
+      g_cur = bi / BPG;
       mw = mw_next;
       if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
     }
-    // this pixel's blended entries of the batch: bit 16 + j <=> entry b0 + j
-    unsigned pm = (((bi & 2) ? mw.y : mw.x) << (16 * (1 - (bi & 1)))) & 0xffff0000u;   // left-aligned (phase1_walk)
+    // this pixel's blended entries of the batch, LEFT-ALIGNED (phase1_walk): bit 32 - B + j <=> entry b0 + j
+    const int moff = (bi % BPG) * B;   // the batch's first bit in the group's 64-bit word (wave-uniform)
+    unsigned pm = (((moff & 32) ? mw.y : mw.x) >> (moff & 31)) << (32 - B);
     if (SFGS_BWD_ABLATE & 2) pm = 0u;
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
     if (bi >= 1) {  // batches below the last one are always full
@@ -438,9 +483,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     }
     if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {  // the previous batch's gradient records
       if constexpr (DG_F4 == 4) {   // one 16-byte quarter per lane: the entry's four lanes fill a 64-byte sector
-        dupgrad[(size_t)p_dup * 4 + grp] = make_float4(pq0, pq1, pq2, 0.f);
+        dupgrad[(size_t)p_dup * 4 + orow] = make_float4(pq0, pq1, pq2, 0.f);
       } else {
-        float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
+        float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + orow;
         dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
       }
     }
@@ -488,8 +533,27 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
       const float mx = r0.x, my = r0.y;
       cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x;
-      const float2* UWrow = &lds.UW[ej * ROW + grp * B];
+      const float2* UWrow = &lds.UW[ej * ROW + grp * B];   // the lane's B pixels: rows 2 grp, 2 grp + 1 (B = 16) / row grp (B = 8)
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
+      if constexpr (B == 8) {
+        // (batches of 8 are an on-grid-only experiment: the host launches <8> only without a subpixel_offset tensor)
+        const float mxl = mx - ocx, dy0 = (my - ocy) - ((float)grp - 3.5f);
+        const float kx = fmaf(cA, mxl, cB * dy0), ky = fmaf(cC, dy0, cB * mxl);
+        const float ncA = -cA, ncB = -cB;
+        const float2 uw0 = uw_take(UWrow + 0), uw1 = uw_take(UWrow + 1), uw2 = uw_take(UWrow + 2), uw3 = uw_take(UWrow + 3);
+        const float2 uw4 = uw_take(UWrow + 4), uw5 = uw_take(UWrow + 5), uw6 = uw_take(UWrow + 6), uw7 = uw_take(UWrow + 7);
+        Phase2Grid8 p8;
+        p8.r = 0.f; p8.g = 0.f; p8.b = 0.f; p8.d = 0.f;
+        phase2_grid8_step<0>(p8, uw0.x, uw0.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<1>(p8, uw1.x, uw1.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<2>(p8, uw2.x, uw2.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<3>(p8, uw3.x, uw3.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<4>(p8, uw4.x, uw4.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<5>(p8, uw5.x, uw5.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<6>(p8, uw6.x, uw6.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        phase2_grid8_step<7>(p8, uw7.x, uw7.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
+        pa = phase2_grid8_finish(p8, mxl, dy0);
+      } else
       // rolled loops over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
       // compiler from hoisting all 32 LDS loads above the arithmetic, which costs ~30 VGPRs
       if (on_grid) {
@@ -589,10 +653,12 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         const float s13 = swap32_add(O[4 * k + 1], O[4 * k + 3]);
         // rows: row 0 = O[4k], row 1 = O[4k+1], row 2 = O[4k+2], row 3 = O[4k+3], each summed over the four rows
         q[k] = swap16_add(s02, s13);
+        if constexpr (B == 8)   // ... and over the two pixel rows that share a DPP row (lanes i and i + 8)
+          q[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q[k]), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
       }
       pq0 = q[0]; pq1 = q[1]; pq2 = q[2]; p_dup = my_dup;
     }
-    p_valid = (unsigned)ej < cnt;
+    p_valid = (unsigned)ej < cnt && (B == 16 || (grp & 1) == 0);   // B = 8: the even row's lanes store the (duplicated) sums
 #if SFGS_BWD_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -600,9 +666,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   }
   if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {
     if constexpr (DG_F4 == 4) {
-      dupgrad[(size_t)p_dup * 4 + grp] = make_float4(pq0, pq1, pq2, 0.f);
+      dupgrad[(size_t)p_dup * 4 + orow] = make_float4(pq0, pq1, pq2, 0.f);
     } else {
-      float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + grp;
+      float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + orow;
       dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
     }
   }
@@ -951,10 +1017,16 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                        (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
                        (unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
-    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX,
-                       nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
-                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr,
-                       (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0); }
+    // SFGS_BWD_B=8: the batches-of-8 form (experiment; sample points on the pixel grid only), see composite_bwd_kernel
+    static const bool b8 = [] { const char* e = getenv("SFGS_BWD_B"); return e && !strcmp(e, "8"); }();
+#define SFGS_LAUNCH_CBWD(BB)                                                                                               \
+    hipLaunchKernelGGL(composite_bwd_kernel<BB>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX, \
+                       nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth, \
+                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr,                                      \
+                       (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0)
+    if (b8 && !frame->subpixel_offset) SFGS_LAUNCH_CBWD(8); else SFGS_LAUNCH_CBWD(16);
+#undef SFGS_LAUNCH_CBWD
+  }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
