@@ -384,7 +384,15 @@ def main():
         }
         if idu is not None:
             out["idu_render_phase"] = idu
-        print(json.dumps(out))
+        # the JSON line is the LAST line of stdout: anything native libraries still hold in C stdio buffers (RCCL prints a
+        # version banner at init when NCCL_DEBUG=VERSION is in the environment, as on the GPU boxes) goes out first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
