@@ -40,7 +40,7 @@ typedef enum SfgsStatus {
   SFGS_E_ARG = -1,         /* bad argument (null pointer, negative size, struct_size mismatch) */
   SFGS_E_HIP = -2,         /* a HIP runtime call or kernel launch failed                       */
   SFGS_E_CAPACITY = -3,    /* a caller-owned blob is smaller than the plan requires            */
-  SFGS_E_UNSUPPORTED = -4  /* e.g. sh_degree > 3, image wider than 65535 tiles                 */
+  SFGS_E_UNSUPPORTED = -4  /* e.g. sh_degree > 4, image wider than 65535 tiles                 */
 } SfgsStatus;
 
 /* Depth output convention (SURVEY 8c "unpinned semantic decisions"). */
@@ -59,7 +59,7 @@ typedef struct SfgsFrame {
   float tanfovy;
   float kernel_size;             /* Mip-Splatting 2D filter variance (arguments/__init__.py:111) */
   float scale_modifier;
-  int32_t sh_degree;             /* active SH degree 0..3                                        */
+  int32_t sh_degree;             /* active SH degree 0..4 (sh_coeffs 1 / 4 / 9 / 16 / 25 stored)     */
   int32_t sh_coeffs;             /* coefficients stored per Gaussian in `shs` (max_degree+1)^2   */
   int32_t prefiltered;           /* accepted, ignored (reference always passes False)            */
   int32_t debug;                 /* !=0: synchronise + check after every launch                  */
@@ -135,7 +135,7 @@ typedef struct SfgsGaussians {
    * (gaussian_renderer/__init__.py:112-118,121-125; utils/sh_utils.py:57-112) with torch kernels and hand the result over
    * as colors_precomp. When sh_dirs is non-NULL, `shs` above is that CHANNEL-MAJOR [N,3,sh_coeffs] coefficient tensor and
    * (shs_channel_major = 1) and sh_dirs the `dirs` argument ([N,3], used as given: eval_sh does not normalise it either), and preprocess /
-   * preprocess_bwd evaluate the expression themselves (degrees 0-3): no N x 3 intermediate, no eval_sh launch. The
+   * preprocess_bwd evaluate the expression themselves (degrees 0-4): no N x 3 intermediate, no eval_sh launch. The
    * backward writes SfgsGaussianGrads.shs channel-major and the direction gradient to SfgsGaussianGrads.sh_dirs (it does
    * NOT flow into grads.means3D: `dirs` is an input of its own, the caller's graph carries it on). */
   const float* sh_dirs;          /* [N,3] or NULL = `shs` is [N,sh_coeffs,3] and the direction is normalize(means3D - campos) */

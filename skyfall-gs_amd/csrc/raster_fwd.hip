@@ -1776,7 +1776,7 @@ static int check_frame(const SfgsFrame* f) {
   SFGS_REQUIRE(f->image_width > 0 && f->image_height > 0, SFGS_E_ARG, "image size %dx%d", f->image_width,
                f->image_height);
   SFGS_REQUIRE(f->bg && f->viewmatrix && f->projmatrix && f->campos, SFGS_E_ARG, "frame tensor pointer is NULL");
-  SFGS_REQUIRE(f->sh_degree >= 0 && f->sh_degree <= 3, SFGS_E_UNSUPPORTED, "sh_degree %d not in 0..3", f->sh_degree);
+  SFGS_REQUIRE(f->sh_degree >= 0 && f->sh_degree <= 4, SFGS_E_UNSUPPORTED, "sh_degree %d not in 0..4", f->sh_degree);
   SFGS_REQUIRE(f->tanfovx > 0.f && f->tanfovy > 0.f, SFGS_E_ARG, "tanfov must be positive");
   SFGS_REQUIRE((int64_t)f->image_width * f->image_height < (1ll << 31), SFGS_E_UNSUPPORTED, "image too large");
   return SFGS_OK;
@@ -1820,8 +1820,8 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
                  "shs_channel_major %d: 0 or 1, and 0 without sh_dirs", g->shs_channel_major);
     if (g->shs)
       SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) &&
-                       (f->sh_coeffs == 1 || f->sh_coeffs == 4 || f->sh_coeffs == 9 || f->sh_coeffs == 16),
-                   SFGS_E_ARG, "sh_coeffs %d: must be 1, 4, 9 or 16 and hold degree %d", f->sh_coeffs, f->sh_degree);
+                       (f->sh_coeffs == 1 || f->sh_coeffs == 4 || f->sh_coeffs == 9 || f->sh_coeffs == 16 || f->sh_coeffs == 25),
+                   SFGS_E_ARG, "sh_coeffs %d: must be 1, 4, 9, 16 or 25 and hold degree %d", f->sh_coeffs, f->sh_degree);
   }
   return SFGS_OK;
 }

@@ -201,6 +201,11 @@ constexpr float SH2_0 = 1.0925484305920792f, SH2_1 = -1.0925484305920792f, SH2_2
 constexpr float SH3_0 = -0.5900435899266435f, SH3_1 = 2.890611442640554f, SH3_2 = -0.4570457994644658f,
                 SH3_3 = 0.3731763325901154f, SH3_4 = -0.4570457994644658f, SH3_5 = 1.445305721320277f,
                 SH3_6 = -0.5900435899266435f;
+// degree 4 (utils/sh_utils.py:44-54,101-111): in the reference only the Python eval_sh knows it; here every SH path does
+constexpr float SH4_0 = 2.5033429417967046f, SH4_1 = -1.7701307697799304f, SH4_2 = 0.9461746957575601f,
+                SH4_3 = -0.6690465435572892f, SH4_4 = 0.10578554691520431f, SH4_5 = -0.6690465435572892f,
+                SH4_6 = 0.47308734787878004f, SH4_7 = -1.7701307697799304f, SH4_8 = 0.6258357354491761f;
+constexpr int SH_MAX_COEFFS = 25;
 
 // basis[k] for k < (deg+1)^2 at unit direction (x,y,z); colour = sum_k basis[k] * sh[k]
 SFGS_HD void sh_basis(int deg, float x, float y, float z, float* Bk) {
@@ -219,6 +224,17 @@ SFGS_HD void sh_basis(int deg, float x, float y, float z, float* Bk) {
         Bk[13] = SH3_4 * x * (4.0f * zz - xx - yy);
         Bk[14] = SH3_5 * z * (xx - yy);
         Bk[15] = SH3_6 * x * (xx - 3.0f * yy);
+        if (deg > 3) {
+          Bk[16] = SH4_0 * xy * (xx - yy);
+          Bk[17] = SH4_1 * yz * (3.f * xx - yy);
+          Bk[18] = SH4_2 * xy * (7.f * zz - 1.f);
+          Bk[19] = SH4_3 * yz * (7.f * zz - 3.f);
+          Bk[20] = SH4_4 * (zz * (35.f * zz - 30.f) + 3.f);
+          Bk[21] = SH4_5 * xz * (7.f * zz - 3.f);
+          Bk[22] = SH4_6 * (xx - yy) * (7.f * zz - 1.f);
+          Bk[23] = SH4_7 * xz * (xx - 3.f * yy);
+          Bk[24] = SH4_8 * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+        }
       }
     }
   }
@@ -247,6 +263,18 @@ SFGS_HD void sh_basis_grad(int deg, float x, float y, float z, float* dBx, float
         dBx[13] = SH3_4 * (4.f * zz - 3.f * xx - yy); dBy[13] = SH3_4 * -2.f * xy; dBz[13] = SH3_4 * 8.f * xz;
         dBx[14] = SH3_5 * 2.f * xz; dBy[14] = SH3_5 * -2.f * yz; dBz[14] = SH3_5 * (xx - yy);
         dBx[15] = SH3_6 * 3.f * (xx - yy); dBy[15] = SH3_6 * -6.f * xy; dBz[15] = 0.f;
+        if (deg > 3) {
+          dBx[16] = SH4_0 * y * (3.f * xx - yy); dBy[16] = SH4_0 * x * (xx - 3.f * yy); dBz[16] = 0.f;
+          dBx[17] = SH4_1 * 6.f * xy * z; dBy[17] = SH4_1 * 3.f * z * (xx - yy); dBz[17] = SH4_1 * y * (3.f * xx - yy);
+          dBx[18] = SH4_2 * y * (7.f * zz - 1.f); dBy[18] = SH4_2 * x * (7.f * zz - 1.f); dBz[18] = SH4_2 * 14.f * xy * z;
+          dBx[19] = 0.f; dBy[19] = SH4_3 * z * (7.f * zz - 3.f); dBz[19] = SH4_3 * y * (21.f * zz - 3.f);
+          dBx[20] = 0.f; dBy[20] = 0.f; dBz[20] = SH4_4 * z * (140.f * zz - 60.f);
+          dBx[21] = SH4_5 * z * (7.f * zz - 3.f); dBy[21] = 0.f; dBz[21] = SH4_5 * x * (21.f * zz - 3.f);
+          dBx[22] = SH4_6 * 2.f * x * (7.f * zz - 1.f); dBy[22] = SH4_6 * -2.f * y * (7.f * zz - 1.f);
+          dBz[22] = SH4_6 * 14.f * z * (xx - yy);
+          dBx[23] = SH4_7 * 3.f * z * (xx - yy); dBy[23] = SH4_7 * -6.f * xy * z; dBz[23] = SH4_7 * x * (xx - 3.f * yy);
+          dBx[24] = SH4_8 * 4.f * x * (xx - 3.f * yy); dBy[24] = SH4_8 * 4.f * y * (yy - 3.f * xx); dBz[24] = 0.f;
+        }
       }
     }
   }
@@ -271,7 +299,7 @@ SFGS_HD void sh_to_rgb(int deg, const float* sh, const float* p, const float* ca
   }
   dir[0] = x; dir[1] = y; dir[2] = z;
   *len_out = len;
-  float Bk[16];
+  float Bk[SH_MAX_COEFFS];
   sh_basis(deg, x, y, z, Bk);
   const int M = (deg + 1) * (deg + 1);
   unsigned mask = 0;
@@ -704,7 +732,7 @@ SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, c
     unsigned mask;
     const int sk = sh_cm ? 1 : 3, sc = sh_cm ? f.sh_coeffs : 1;
     sh_to_rgb(f.sh_degree, sh, p, f.campos, rgb, &mask, dir, &len, sk, sc, dir_in);
-    float Bk[16], dBx[16], dBy[16], dBz[16];
+    float Bk[SH_MAX_COEFFS], dBx[SH_MAX_COEFFS], dBy[SH_MAX_COEFFS], dBz[SH_MAX_COEFFS];
     sh_basis(f.sh_degree, dir[0], dir[1], dir[2], Bk);
     sh_basis_grad(f.sh_degree, dir[0], dir[1], dir[2], dBx, dBy, dBz);
     const int M = (f.sh_degree + 1) * (f.sh_degree + 1);

@@ -388,7 +388,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
     else if (k_ == 1) { LAUNCH(1, 0); }                                          \
     else if (k_ == 4) { if (d_ == 0) { LAUNCH(4, 0); } else { LAUNCH(4, 1); } }  \
     else if (k_ == 9) { if (d_ == 0) { LAUNCH(9, 0); } else if (d_ == 1) { LAUNCH(9, 1); } else { LAUNCH(9, 2); } } \
-    else { if (d_ == 0) { LAUNCH(16, 0); } else if (d_ == 1) { LAUNCH(16, 1); } else if (d_ == 2) { LAUNCH(16, 2); } else { LAUNCH(16, 3); } } \
+    else if (k_ == 16) { if (d_ == 0) { LAUNCH(16, 0); } else if (d_ == 1) { LAUNCH(16, 1); } else if (d_ == 2) { LAUNCH(16, 2); } else { LAUNCH(16, 3); } } \
+    else { if (d_ == 0) { LAUNCH(25, 0); } else if (d_ == 1) { LAUNCH(25, 1); } else if (d_ == 2) { LAUNCH(25, 2); } else if (d_ == 3) { LAUNCH(25, 3); } else { LAUNCH(25, 4); } } \
   } while (0)
 
 // ---- small wave / block primitives ---------------------------------------------------------------

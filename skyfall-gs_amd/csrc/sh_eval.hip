@@ -9,47 +9,13 @@
 
 namespace sfgs {
 
-// degree 4 exists only in the reference's Python eval_sh (utils/sh_utils.py:44-54,101-111; the rasterizer's in-kernel SH
-// path stops at degree 3 like its CUDA original): the nine extra basis polynomials and their partial derivatives with
-// x, y, z treated as free variables (what autograd of the reference's expression yields)
-constexpr float SH4_0 = 2.5033429417967046f, SH4_1 = -1.7701307697799304f, SH4_2 = 0.9461746957575601f,
-                SH4_3 = -0.6690465435572892f, SH4_4 = 0.10578554691520431f, SH4_5 = -0.6690465435572892f,
-                SH4_6 = 0.47308734787878004f, SH4_7 = -1.7701307697799304f, SH4_8 = 0.6258357354491761f;
-
+// (degree 4 exists only in the reference's Python eval_sh, utils/sh_utils.py:44-54,101-111; since round 4 the basis and its
+// partial derivatives up to degree 4 live in raster_math.h and the rasterizer's in-kernel paths evaluate it too)
 template <int DEG>
-__device__ __forceinline__ void sh_basis_any(float x, float y, float z, float* Bk) {
-  sh_basis(DEG > 3 ? 3 : DEG, x, y, z, Bk);
-  if constexpr (DEG > 3) {
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    Bk[16] = SH4_0 * xy * (xx - yy);
-    Bk[17] = SH4_1 * yz * (3.f * xx - yy);
-    Bk[18] = SH4_2 * xy * (7.f * zz - 1.f);
-    Bk[19] = SH4_3 * yz * (7.f * zz - 3.f);
-    Bk[20] = SH4_4 * (zz * (35.f * zz - 30.f) + 3.f);
-    Bk[21] = SH4_5 * xz * (7.f * zz - 3.f);
-    Bk[22] = SH4_6 * (xx - yy) * (7.f * zz - 1.f);
-    Bk[23] = SH4_7 * xz * (xx - 3.f * yy);
-    Bk[24] = SH4_8 * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
-  }
-}
-
+__device__ __forceinline__ void sh_basis_any(float x, float y, float z, float* Bk) { sh_basis(DEG, x, y, z, Bk); }
 template <int DEG>
 __device__ __forceinline__ void sh_basis_grad_any(float x, float y, float z, float* dBx, float* dBy, float* dBz) {
-  sh_basis_grad(DEG > 3 ? 3 : DEG, x, y, z, dBx, dBy, dBz);
-  if constexpr (DEG > 3) {
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    dBx[16] = SH4_0 * y * (3.f * xx - yy); dBy[16] = SH4_0 * x * (xx - 3.f * yy); dBz[16] = 0.f;
-    dBx[17] = SH4_1 * 6.f * xy * z; dBy[17] = SH4_1 * 3.f * z * (xx - yy); dBz[17] = SH4_1 * y * (3.f * xx - yy);
-    dBx[18] = SH4_2 * y * (7.f * zz - 1.f); dBy[18] = SH4_2 * x * (7.f * zz - 1.f); dBz[18] = SH4_2 * 14.f * xy * z;
-    dBx[19] = 0.f; dBy[19] = SH4_3 * z * (7.f * zz - 3.f); dBz[19] = SH4_3 * y * (21.f * zz - 3.f);
-    dBx[20] = 0.f; dBy[20] = 0.f; dBz[20] = SH4_4 * z * (140.f * zz - 60.f);
-    dBx[21] = SH4_5 * z * (7.f * zz - 3.f); dBy[21] = 0.f; dBz[21] = SH4_5 * x * (21.f * zz - 3.f);
-    dBx[22] = SH4_6 * 2.f * x * (7.f * zz - 1.f); dBy[22] = SH4_6 * -2.f * y * (7.f * zz - 1.f);
-    dBz[22] = SH4_6 * 14.f * z * (xx - yy);
-    dBx[23] = SH4_7 * 3.f * z * (xx - yy); dBy[23] = SH4_7 * -6.f * xy * z; dBz[23] = SH4_7 * x * (xx - 3.f * yy);
-    dBx[24] = SH4_8 * 4.f * x * (xx - 3.f * yy); dBy[24] = SH4_8 * 4.f * y * (yy - 3.f * xx); dBz[24] = 0.f;
-    (void)yz; (void)xz;
-  }
+  sh_basis_grad(DEG, x, y, z, dBx, dBy, dBz);
 }
 
 template <int DEG>

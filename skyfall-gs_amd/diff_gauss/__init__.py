@@ -574,9 +574,9 @@ class GaussianRasterizer(nn.Module):
             if shs.dim() != 3 or shs.shape[2] != 3:
                 raise ValueError("shs must be [N,K,3]")
             deg = int(self.raster_settings.sh_degree)
-            if shs.shape[1] < (deg + 1) ** 2 or shs.shape[1] not in (1, 4, 9, 16):
+            if shs.shape[1] < (deg + 1) ** 2 or shs.shape[1] not in (1, 4, 9, 16, 25):
                 raise ValueError(f"shs has {shs.shape[1]} coefficients per Gaussian; expected (max_degree + 1)^2 in "
-                                 f"(1, 4, 9, 16) and at least {(deg + 1) ** 2} for active degree {deg}")
+                                 f"(1, 4, 9, 16, 25) and at least {(deg + 1) ** 2} for active degree {deg}")
         for name, t in (("scales", scales), ("rotations", rotations),
                         ("colors_precomp", None if sh_fold is not None else colors_precomp), ("shs", shs)):
             if t is not None and (t.shape[0] != N or t.device != means3D.device):

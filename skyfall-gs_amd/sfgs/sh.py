@@ -58,8 +58,8 @@ def eval_sh(deg, sh, dirs):
 # ---- deferred result: eval_sh + 0.5 + clamp_min folded into the rasterizer ---------------------------------------------
 _METADATA = frozenset(("dim", "ndimension", "numel", "nelement", "size", "__len__", "is_contiguous", "element_size",
                        "is_floating_point", "is_complex", "stride", "storage_offset"))
-FOLD_MAX_DEGREE = 3          # the rasterizer's in-kernel SH stops at degree 3 (16 coefficients), like the upstream one
-FOLD_COEFFS = (1, 4, 9, 16)
+FOLD_MAX_DEGREE = 4          # the rasterizer's in-kernel SH goes as far as eval_sh does (round 4; the upstream one stops at 3)
+FOLD_COEFFS = (1, 4, 9, 16, 25)
 
 
 def _is_scalar(x, value=None):
@@ -79,7 +79,7 @@ class DeferredColor(torch.Tensor):
     when it receives a handle that recorded exactly `+ 0.5` and `clamp_min(0.0)`, evaluates the whole expression inside
     its preprocess kernels from the channel-major coefficients and the directions (SfgsGaussians.sh_dirs): no eval_sh
     launch, no N x 3 intermediates, no autograd nodes for the three steps. ANY other use of the handle -- other
-    arithmetic, indexing, printing, a different constant, degree 4 -- materialises the real tensor with the ordinary
+    arithmetic, indexing, printing, a different constant, an unusual coefficient count -- materialises the real tensor with the ordinary
     fused eval_sh (plus the recorded steps as torch operations, with their autograd graph) and proceeds on it."""
 
     @staticmethod
@@ -104,7 +104,7 @@ class DeferredColor(torch.Tensor):
 
     def folded_inputs(self):
         """(deg, coefficients, dirs[N,3], channel_major) when the handle stands for render()'s exact expression and the
-        rasterizer can evaluate it (degree <= 3, 1 / 4 / 9 / 16 stored coefficients); None otherwise. `coefficients` is
+        rasterizer can evaluate it (degree <= 4; 1 / 4 / 9 / 16 / 25 stored coefficients); None otherwise. `coefficients` is
         the [N,3,K] tensor itself when it is contiguous (channel_major = True: the appearance path's `.contiguous()`
         result) or, when it is the transposed view of a contiguous [N,K,3] tensor (convert_SHs_python:
         `pc.get_features.transpose(1, 2).view(-1, 3, K)`), that [N,K,3] tensor (channel_major = False) -- no copy

@@ -80,7 +80,7 @@ def _close(a, b, name, rtol=2e-5, atol_rel=2e-6):
 
 
 @pytest.mark.parametrize("features_view", [False, True])
-@pytest.mark.parametrize("deg,stored", [(0, 1), (0, 4), (1, 4), (2, 9), (1, 16), (3, 16)])
+@pytest.mark.parametrize("deg,stored", [(0, 1), (0, 4), (1, 4), (2, 9), (1, 16), (3, 16), (4, 25), (2, 25)])
 def test_folded_route_equals_eval_sh_then_colors_precomp(deg, stored, features_view):
     from sfgs import sh as sfsh
     W, H, n = 320, 192, 30000
@@ -129,8 +129,15 @@ def test_folded_colour_path_composes_with_raw_parameter_mode():
     assert got["g_opacity"].dtype == torch.float64
 
 
+G4 = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_sh4.npz"))   # the real eval_sh at degree 4
+
+
+def _golden(deg, key):
+    return G4[key] if deg == 4 else G[f"shg{deg}_{key}"]
+
+
 @pytest.mark.parametrize("shift", [0.0, 12.0])
-@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
 def test_golden_vectors_of_the_real_eval_sh_through_the_folded_route(deg, shift):
     """The REAL utils/sh_utils.py eval_sh's inputs / outputs / autograd gradients (tests/golden/make_golden.py) pushed
     through the rasterizer's own evaluation: every Gaussian is parked alone on its own pixel with opacity 0.99 and a
@@ -140,7 +147,7 @@ def test_golden_vectors_of_the_real_eval_sh_through_the_folded_route(deg, shift)
     no channel is clamped and the golden gradients apply to every element."""
     from diff_gauss import GaussianRasterizer
     from sfgs import sh as sfsh
-    sh_np, dirs_np, want = G[f"shg{deg}_sh"].copy(), G[f"shg{deg}_dirs"], G[f"shg{deg}_out"].astype(np.float64)
+    sh_np, dirs_np, want = _golden(deg, "sh").copy(), _golden(deg, "dirs"), _golden(deg, "out").astype(np.float64)
     sh_np[:, :, 0] += np.float32(shift)
     want = want + 0.28209479177387814 * shift
     n = sh_np.shape[0]
@@ -171,16 +178,16 @@ def test_golden_vectors_of_the_real_eval_sh_through_the_folded_route(deg, shift)
     np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=2e-5, atol=3e-6)
     assert bool((ref == 0).any()) == (shift == 0.0)
     # gradients: d(sum w * image_pixel)/d(sh, dirs) = alpha * [colour > 0] * eval_sh's golden gradients
-    wgt = torch.tensor(G[f"shg{deg}_w"], device=DEV)
+    wgt = torch.tensor(_golden(deg, "w"), device=DEV)
     loss = (image[:, cy, cx].T * wgt / a.detach()[:, None]).sum()
     loss.backward()
     live = torch.tensor((want + 0.5 > 0).astype(np.float32), device=DEV)            # the clamp's mask
     if float(live.min()) == 1.0:
-        np.testing.assert_allclose(sh.grad.cpu().numpy(), G[f"shg{deg}_g_sh"], rtol=3e-4, atol=3e-5)
-        np.testing.assert_allclose(dirs.grad.cpu().numpy(), G[f"shg{deg}_g_dirs"], rtol=3e-4, atol=3e-5)
+        np.testing.assert_allclose(sh.grad.cpu().numpy(), _golden(deg, "g_sh"), rtol=3e-4, atol=3e-5)
+        np.testing.assert_allclose(dirs.grad.cpu().numpy(), _golden(deg, "g_dirs"), rtol=3e-4, atol=1e-4)
     else:   # clamped channels contribute nothing: compare channel-wise on the live ones
         M = sh.grad * live[:, :, None]
-        np.testing.assert_allclose(M.cpu().numpy(), G[f"shg{deg}_g_sh"] * live.cpu().numpy()[:, :, None], rtol=3e-4,
+        np.testing.assert_allclose(M.cpu().numpy(), _golden(deg, "g_sh") * live.cpu().numpy()[:, :, None], rtol=3e-4,
                                    atol=3e-5)
 
 
@@ -204,7 +211,49 @@ def test_any_other_use_of_the_handle_is_an_ordinary_tensor():
     g2, = torch.autograd.grad(torch.clamp_min(plain + 0.5, 0.0).sum(), sh)
     torch.testing.assert_close(g1, g2, rtol=0, atol=0)
     assert h3.folded_inputs() is None                                                         # ... and stays a tensor
-    h4 = sfsh.eval_sh_deferred(4, torch.randn(8, 3, 25, device=DEV), dirs[:8])                # degree 4: eval_sh handles it
+    h4 = sfsh.eval_sh_deferred(1, torch.randn(8, 3, 6, device=DEV), dirs[:8])                 # 6 stored coefficients: eval_sh handles it
     assert torch.clamp_min(h4 + 0.5, 0.0).folded_inputs() is None
     with pytest.raises(AssertionError):
         sfsh.eval_sh_deferred(2, sh[:, :, :4], dirs)
+
+
+@pytest.mark.parametrize("deg,stored", [(4, 25), (3, 25), (3, 16)])
+def test_in_kernel_sh_path_equals_the_python_colour_path(deg, stored):
+    """SURVEY 8c item 2 at the degrees the upstream rasterizer does not have: `shs = pc.get_features` (the rasterizer
+    evaluates the SH itself, direction = normalize(xyz - campos)) against `convert_SHs_python` (eval_sh in Python, then
+    colors_precomp) -- images and every gradient, xyz through both of its roles. Degree 4 / 25 coefficients: round 4."""
+    from diff_gauss import GaussianRasterizer
+    from sfgs import sh as sfsh
+    W, H, n = 256, 160, 20000
+    frame, g = scene(n, W, H, seed=31, zrange=(250., 350.), scale_range=(0.3, 3.0), mode="precomp")
+    gen = torch.Generator().manual_seed(77)
+    feats0 = torch.randn(n, stored, 3, generator=gen) * 0.3
+    feats0[:, 0] += 0.2
+    gc, gd = (t.to(DEV) for t in upstream_grads(W, H, 5))
+    res = []
+    for in_kernel in (True, False):
+        xyz = g["means3D"].to(DEV).requires_grad_(True)
+        feats = feats0.to(DEV).requires_grad_(True)
+        leaves = {k: g[k].to(DEV).requires_grad_(True) for k in ("scales", "rotations", "opacities")}
+        means2D = torch.zeros_like(xyz, requires_grad=True)
+        if in_kernel:
+            kw = dict(shs=feats, colors_precomp=None)
+        else:
+            shs_view = feats.transpose(1, 2).view(-1, 3, stored)
+            dir_pp = xyz - frame["campos"].to(DEV).repeat(n, 1)
+            kw = dict(shs=None, colors_precomp=torch.clamp_min(
+                sfsh.eval_sh(deg, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0))
+        image, depth, _, alpha, radii, _ = GaussianRasterizer(_settings(frame, deg))(
+            means3D=xyz, means2D=means2D, opacities=leaves["opacities"], scales=leaves["scales"],
+            rotations=leaves["rotations"], cov3Ds_precomp=None, **kw)
+        torch.autograd.backward([image, depth], [gc, gd])
+        res.append(dict(image=image, depth=depth, alpha=alpha, radii=radii, g_feats=feats.grad, g_xyz=xyz.grad,
+                        g_means2D=means2D.grad, **{"g_" + k: v.grad for k, v in leaves.items()}))
+    a, b = res
+    torch.testing.assert_close(a["radii"], b["radii"], rtol=0, atol=0)
+    for k in ("image", "depth", "alpha"):
+        _close(a[k], b[k], k, rtol=1e-5, atol_rel=1e-6)
+    for k in ("g_feats", "g_xyz", "g_means2D", "g_scales", "g_rotations", "g_opacities"):
+        _close(a[k], b[k], k, rtol=5e-5, atol_rel=5e-6)
+    M = (deg + 1) ** 2
+    assert float(a["g_feats"][:, M:].abs().max() if stored > M else 0.0) == 0.0

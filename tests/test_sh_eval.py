@@ -129,5 +129,6 @@ def test_deferred_handle_records_exactly_renders_two_statements():
     view = feats.transpose(1, 2).view(-1, 3, 4)
     deg, coef, dirs, cm = torch.clamp_min(DeferredColor(1, view, d) + 0.5, 0.0).folded_inputs()
     assert cm is False and coef.shape == (10, 4, 3) and coef.data_ptr() == feats.data_ptr() and coef.is_contiguous()
-    # degree 4 / 25 coefficients stay with the stand-alone kernel
-    assert torch.clamp_min(DeferredColor(4, torch.randn(10, 3, 25), d) + 0.5, 0.0).folded_inputs() is None
+    # degree 4 / 25 coefficients fold too (round 4); an unusual coefficient count stays with the stand-alone kernel
+    assert torch.clamp_min(DeferredColor(4, torch.randn(10, 3, 25), d) + 0.5, 0.0).folded_inputs()[0] == 4
+    assert torch.clamp_min(DeferredColor(1, torch.randn(10, 3, 5), d) + 0.5, 0.0).folded_inputs() is None
