@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "act_math.h"
 #include "sfgs_internal.h"
@@ -46,6 +47,16 @@
 #endif
 //   -DSFGS_BWD_ROWSYM=1         phase 2 (grid case) forms the raw moments of a pixel row from symmetric pairs (phase2_grid_row)
 //   -DSFGS_P1_TAIL=1            phase 1: two entries per iteration while any lane has two left, then ONE single-entry step
+//   -DSFGS_BWD_LDS18=1          VERDICT r3 item 1a, built to be MEASURED (needs -DSFGS_COMPOSITE_WG_WAVES=1): exactly 8 960 bytes of
+//                               LDS per one-wave workgroup = 7 allocation granules = 18 waves per CU instead of 16: 40-byte staged
+//                               records (no ex / ey), no dummy row and no dummy record -- the (u, w) rows are stored in REVERSE
+//                               order at offset 0, so the exhausted lanes' dummy writes land at NEGATIVE offsets, and the dummy
+//                               record lies right behind the last record = the end of the allocation: both out of range, where
+//                               the hardware drops writes and returns zeros (probed: tools/microbench/lds_probe.hip,
+//                               profiles/r4_lds_probe.txt). Rests on that undocumented behaviour: an experiment, never shipped.
+#ifndef SFGS_BWD_LDS18
+#define SFGS_BWD_LDS18 0
+#endif
 #ifndef SFGS_BWD_ROWSYM
 #define SFGS_BWD_ROWSYM 0
 #endif
@@ -78,12 +89,26 @@ struct alignas(16) BwdLds {
   // UW[j][p] = (u, w) of entry j at pixel p; row B is a dummy row (written by lanes that have no blended entry left in
   // the batch, never read). Row stride 65 pairs: the pixel-major 8-byte writes and the entry-major 8-byte reads of
   // phase 2 are both bank-conflict free on the 64-bank LDS.
+#if SFGS_BWD_LDS18
+  static constexpr int REC_BYTES = 40;          // (mx, my, qa, qb) (qc, op, r, g) (b, depth): what the backward reads
+  static constexpr bool REVERSED = true;        // UW row of entry j = B - 1 - j (see SFGS_BWD_LDS18 above)
+  float2 UW[B * ROW];
+  float recs[B * 10];
+#else
+  static constexpr int REC_BYTES = 48;
+  static constexpr bool REVERSED = false;
   float2 UW[(B + 1) * ROW];
   float4 recs[(B + 1) * 3];   // staged records of the batch; record B is all zeros (the dummy entry: alpha = 0)
+#endif
 #if SFGS_BWD_LDS_PAD > 0
   float4 pad[SFGS_BWD_LDS_PAD / 16];   // occupancy experiment only
 #endif
+  // index of entry j's row in UW
+  static __device__ __forceinline__ constexpr int row_of(int j) { return REVERSED ? B - 1 - j : j; }
 };
+#if SFGS_BWD_LDS18
+static_assert(sizeof(BwdLds<16>) == 8960 && CWG_WAVES == 1, "SFGS_BWD_LDS18: 7 LDS granules per one-wave workgroup");
+#endif
 
 // value of lane I of the caller's 16-lane row, broadcast to the whole row (DPP row_newbcast; folds into
 // the consuming VALU instruction). Phase 2 uses it to read per-PIXEL registers (sample position, upstream
@@ -283,10 +308,12 @@ __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, flo
 // recs_top / uw_top: LDS byte offsets (the low 32 bits of a generic LDS address) of record B - 1 and of this pixel's slot
 // in row B - 1; both live in VGPRs across the loop (v_mad_i32_i24 takes one scalar operand: left to itself the compiler
 // re-materialises the wave's LDS base with a v_mov in every iteration).
-template <int K, int ROW, bool HAS_BG>
+template <int K, int ROW, bool HAS_BG, int REC_BYTES, bool REVERSED>
 __device__ __forceinline__ void phase1_iter(PixelBwd& ps, unsigned& pm, unsigned recs_top, unsigned uw_top, float sx,
                                             float sy) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v4f_a16 __attribute__((ext_vector_type(4)));
+  typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 40-byte records (SFGS_BWD_LDS18) are only 8-byte aligned
+  using v4f = std::conditional_t<REC_BYTES % 16 == 0, v4f_a16, v4f_a8>;
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) v4f* lds_c4;
   typedef const __attribute__((address_space(3))) v2f* lds_c2;
@@ -303,7 +330,7 @@ __device__ __forceinline__ void phase1_iter(PixelBwd& ps, unsigned& pm, unsigned
   }
 #pragma unroll
   for (int q = 0; q < K; ++q) {
-    const unsigned rp = recs_top + (unsigned)__mul24(fb[q], -48);
+    const unsigned rp = recs_top + (unsigned)__mul24(fb[q], -REC_BYTES);
     const v4f a = *(lds_c4)(uintptr_t)rp, b = *(lds_c4)(uintptr_t)(rp + 16u);
     const v2f c = *(lds_c2)(uintptr_t)(rp + 32u);
     r0[q] = make_float4(a.x, a.y, a.z, a.w); r1[q] = make_float4(b.x, b.y, b.z, b.w); r2[q] = make_float2(c.x, c.y);
@@ -317,7 +344,7 @@ __device__ __forceinline__ void phase1_iter(PixelBwd& ps, unsigned& pm, unsigned
 #pragma unroll
   for (int q = 0; q < K; ++q) {
     v2f uw; uw.x = u[q]; uw.y = w[q];
-    *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], -8 * ROW)) = uw;
+    *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], REVERSED ? 8 * ROW : -8 * ROW)) = uw;
   }
 }
 
@@ -329,19 +356,21 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 #endif
   constexpr int K = SFGS_P1_K;
   static_assert(B == 16 || B == 8, "left-aligned batch masks of B bits");
-  unsigned recs_top = (unsigned)(uintptr_t)&lds.recs[(B - 1) * 3];
-  unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(B - 1) * ROW + lane];
+  constexpr int RB = BwdLds<B>::REC_BYTES;
+  constexpr bool REV = BwdLds<B>::REVERSED;
+  unsigned recs_top = (unsigned)(uintptr_t)lds.recs + (unsigned)((B - 1) * RB);
+  unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(REV ? 0 : (B - 1) * ROW) + lane];   // row of entry B - 1 (fb = 0)
   asm volatile("" : "+v"(recs_top), "+v"(uw_top));
   // the caller only enters with at least one blended entry in the wave (a batch without any skips the phase)
 #if SFGS_P1_TAIL
   // pairs while ANY lane still has two entries; the odd last round is a single-entry step (half the instructions) instead of
   // a pair whose second entry is a dummy in every lane
   static_assert(K == 2, "SFGS_P1_TAIL pairs entries");
-  while (__ballot((pm & (pm - 1u)) != 0u) != 0ull) phase1_iter<2, ROW, HAS_BG>(ps, pm, recs_top, uw_top, sx, sy);
-  if (__ballot(pm != 0u) != 0ull) phase1_iter<1, ROW, HAS_BG>(ps, pm, recs_top, uw_top, sx, sy);
+  while (__ballot((pm & (pm - 1u)) != 0u) != 0ull) phase1_iter<2, ROW, HAS_BG, RB, REV>(ps, pm, recs_top, uw_top, sx, sy);
+  if (__ballot(pm != 0u) != 0ull) phase1_iter<1, ROW, HAS_BG, RB, REV>(ps, pm, recs_top, uw_top, sx, sy);
 #else
   do {
-    phase1_iter<K, ROW, HAS_BG>(ps, pm, recs_top, uw_top, sx, sy);
+    phase1_iter<K, ROW, HAS_BG, RB, REV>(ps, pm, recs_top, uw_top, sx, sy);
   } while (__ballot(pm != 0u) != 0ull);
 #endif
 }
@@ -366,7 +395,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[lw];
+#if !SFGS_BWD_LDS18
   if (lane < 3) lds.recs[B * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy entry (see phase 1)
+#endif
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
@@ -468,7 +499,15 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const int moff = (bi % BPG) * B;   // the batch's first bit in the group's 64-bit word (wave-uniform)
     unsigned pm = (((moff & 32) ? mw.y : mw.x) >> (moff & 31)) << (32 - B);
     if (SFGS_BWD_ABLATE & 2) pm = 0u;
+#if SFGS_BWD_LDS18
+    if ((unsigned)lane < cnt) {
+      float* rr = lds.recs + lane * 10;
+      rr[0] = n0.x; rr[1] = n0.y; rr[2] = n0.z; rr[3] = n0.w; rr[4] = n1.x; rr[5] = n1.y; rr[6] = n1.z; rr[7] = n1.w;
+      rr[8] = n2.x; rr[9] = n2.y;
+    }
+#else
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
+#endif
     if (bi >= 1) {  // batches below the last one are always full
       if (!(SFGS_BWD_ABLATE & 16))
       if (lane < B) { n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2]; }
@@ -530,10 +569,15 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     Phase2Acc pa;
     float cA, cB, cC;
     {
+#if SFGS_BWD_LDS18
+      const float* rr = lds.recs + ej * 10;
+      const float4 r0 = make_float4(rr[0], rr[1], rr[2], rr[3]), r1 = make_float4(rr[4], 0.f, 0.f, 0.f);
+#else
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
+#endif
       const float mx = r0.x, my = r0.y;
       cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x;
-      const float2* UWrow = &lds.UW[ej * ROW + grp * B];   // the lane's B pixels: rows 2 grp, 2 grp + 1 (B = 16) / row grp (B = 8)
+      const float2* UWrow = &lds.UW[BwdLds<B>::row_of(ej) * ROW + grp * B];   // the lane's B pixels: rows 2 grp, 2 grp + 1 (B = 16) / row grp (B = 8)
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
       if constexpr (B == 8) {
         // (batches of 8 are an on-grid-only experiment: the host launches <8> only without a subpixel_offset tensor)

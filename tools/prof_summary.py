@@ -29,6 +29,33 @@ def kernel_stats(path):
     print()
 
 
+def gap_stats(path):
+    """Idle time between consecutive kernels on the device (dispatch gaps of dependent launches): end of one kernel to
+    the start of the next, over the whole trace; gaps above 50 us (host-side pauses between steps) are left out."""
+    cur = sqlite3.connect(path).cursor()
+    try:
+        rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    except sqlite3.Error:
+        return
+    gaps = []
+    by_next = {}
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        g = (s1 - e0) / 1e3
+        if 0 <= g < 50:
+            gaps.append(g)
+            by_next.setdefault(short(n1), []).append(g)
+    if not gaps:
+        return
+    gaps.sort()
+    print(f"# dispatch gaps between consecutive kernels (us): n={len(gaps)} median={gaps[len(gaps)//2]:.2f} "
+          f"mean={sum(gaps)/len(gaps):.2f} p90={gaps[int(0.9*len(gaps))]:.2f}")
+    print(f"{'gap in front of':44s} {'n':>6s} {'median_us':>10s} {'mean_us':>10s}")
+    for n, v in sorted(by_next.items(), key=lambda kv: -len(kv[1])):
+        v.sort()
+        print(f"{n:44s} {len(v):6d} {v[len(v)//2]:10.2f} {sum(v)/len(v):10.2f}")
+    print()
+
+
 TRAFFIC = {}
 SQ = {}   # kernel -> {counter: average per launch}
 ALL_KERNELS = False   # --all-kernels: also kernels outside namespace sfgs (the microbenchmarks of the SQ calibration)
@@ -126,6 +153,7 @@ if __name__ == "__main__":
         kts, pmcs = args, []
     for p in kts:
         kernel_stats(p)
+        gap_stats(p)
     for p in pmcs:
         pmc_stats(p)
     derived = sq_derived() if SQ else {}
