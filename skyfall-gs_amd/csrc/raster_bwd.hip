@@ -107,7 +107,7 @@ struct alignas(16) BwdLds {
   static __device__ __forceinline__ constexpr int row_of(int j) { return REVERSED ? B - 1 - j : j; }
 };
 #if SFGS_BWD_LDS18
-static_assert(sizeof(BwdLds<16>) == 8960 && CWG_WAVES == 1, "SFGS_BWD_LDS18: 7 LDS granules per one-wave workgroup");
+static_assert(sizeof(BwdLds<16>) == 8960 && BWG_WAVES == 1, "SFGS_BWD_LDS18: 7 LDS granules per one-wave workgroup");
 #endif
 
 // value of lane I of the caller's 16-lane row, broadcast to the whole row (DPP row_newbcast; folds into
@@ -376,7 +376,7 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 }
 
 template <int B>
-__global__ void __launch_bounds__(64 * CWG_WAVES, B == 8 ? 5 : 4)   // B = 8: 4.7 KB of LDS per wave, 5 waves per SIMD by registers
+__global__ void __launch_bounds__(64 * BWG_WAVES, (B == 8 ? 20 : 16) / BWG_WAVES)   // 16 waves per CU (B = 8: 20, by registers)
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
@@ -386,13 +386,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
                      const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad,
                      const unsigned long long* __restrict__ hdr, int not_prefilled) {
   constexpr int ROW = BwdLds<B>::ROW;
-  __shared__ BwdLds<B> lds_all[CWG_WAVES];
+  __shared__ BwdLds<B> lds_all[BWG_WAVES];
   // wave-uniform: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
   unsigned sb;
   int wave, lw;
-  composite_wave_role((unsigned)nblk, sb, wave, lw);
+  composite_wave_role<BWG_WAVES>((unsigned)nblk, sb, wave, lw);
   const int lane = threadIdx.x & 63;
-  const int tx = (int)(sb % SX) * 2 + (wave & 1), ty = (int)(sb / SX) * 2 + (wave >> 1);
+  constexpr int BE = composite_block_edge<BWG_WAVES>();
+  const int tx = (int)(sb % SX) * BE + (wave % BE), ty = (int)(sb / SX) * BE + (wave / BE);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[lw];
 #if !SFGS_BWD_LDS18
@@ -1053,7 +1054,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const ImageView iv = image_view(const_cast<void*>(image), W, H, dup_capacity);
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
-  const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2, nblk = SX * SY;
+  constexpr int BE = composite_block_edge<BWG_WAVES>();
+  const int SX = (TX8 + BE - 1) / BE, SY = (TY8 + BE - 1) / BE, nblk = SX * SY;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     // (without the prefill kernel its decision word keeps the plan's zero: composite_bwd writes the zero records itself)
     if (!(frame->launch_hints & SFGS_HINT_NO_PREFILL))
@@ -1064,7 +1066,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
     // SFGS_BWD_B=8: the batches-of-8 form (experiment; sample points on the pixel grid only), see composite_bwd_kernel
     static const bool b8 = [] { const char* e = getenv("SFGS_BWD_B"); return e && !strcmp(e, "8"); }();
 #define SFGS_LAUNCH_CBWD(BB)                                                                                               \
-    hipLaunchKernelGGL(composite_bwd_kernel<BB>, dim3(nblk * (4 / CWG_WAVES)), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX, \
+    hipLaunchKernelGGL(composite_bwd_kernel<BB>, dim3(nblk * (BE * BE / BWG_WAVES)), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX, \
                        nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth, \
                        dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr,                                      \
                        (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0)

@@ -343,15 +343,27 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
 #define SFGS_COMPOSITE_WG_WAVES 4
 #endif
 constexpr int CWG_WAVES = SFGS_COMPOSITE_WG_WAVES;
+// composite_bwd's own value (round 4 experiment: 8 = 4x2 tiles, 16 = 4x4 tiles = a coarse bin per workgroup, so that the
+// tiles that gather the same records share a CU's L1; one-wave workgroups measured +3.8 %: profiles/r4_bwd_lds18_ab_not_kept.txt)
+#ifndef SFGS_BWD_WG_WAVES
+#define SFGS_BWD_WG_WAVES SFGS_COMPOSITE_WG_WAVES
+#endif
+constexpr int BWG_WAVES = SFGS_BWD_WG_WAVES;
 static_assert(CWG_WAVES == 4 || CWG_WAVES == 2 || CWG_WAVES == 1, "compositing workgroups: 4, 2 or 1 of a super-tile's tiles");
-// super-tile `sb`, wave-in-super-tile `wave` and wave-in-workgroup `lw` (its slice of the workgroup's LDS) of the calling
+static_assert(BWG_WAVES == 16 || BWG_WAVES == 8 || BWG_WAVES == 4 || BWG_WAVES == 2 || BWG_WAVES == 1, "composite_bwd workgroups");
+// A workgroup's tiles come from a BLOCK of CBLK x CBLK tiles (2 x 2 = the 16x16-pixel super-tile; 4 x 4 for workgroups of
+// 8 / 16 waves); a block is split over CBLK^2 / WAVES workgroups.
+template <int WAVES> constexpr int composite_block_edge() { return WAVES > 4 ? 4 : 2; }
+// block `sb`, wave-in-block `wave` and wave-in-workgroup `lw` (its slice of the workgroup's LDS) of the calling
 // wave; all wave-uniform: the tile, its list range and every loop bound derived from them become SGPRs
+template <int WAVES = CWG_WAVES>
 __device__ __forceinline__ void composite_wave_role(unsigned nblk, unsigned& sb, int& wave, int& lw) {
-  constexpr unsigned PER = 4 / CWG_WAVES;   // workgroups per super-tile
+  constexpr int E = composite_block_edge<WAVES>();
+  constexpr unsigned PER = E * E / WAVES;   // workgroups per block
   const unsigned l = xcd_remap(blockIdx.x, nblk * PER);
-  lw = CWG_WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  lw = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   sb = l / PER;
-  wave = (int)(l % PER) * CWG_WAVES + lw;
+  wave = (int)(l % PER) * WAVES + lw;
 }
 
 // ---- per-Gaussian SH coefficient rows: 3K floats, 16-byte vector accesses when the row size allows -----------
