@@ -158,8 +158,8 @@ class DeferredColor(torch.Tensor):
         return func(*cls._unwrap(args), **cls._unwrap(kwargs or {}))
 
 
-def eval_sh_deferred(deg, sh, dirs):
-    """`eval_sh` with the same contract and the same argument checks, returning a DeferredColor handle."""
+def _checked(deg, sh, dirs):
+    """eval_sh's argument checks (the reference's two assertions, shapes, float32 GPU tensors on one device)."""
     if not (0 <= deg <= 4):
         raise AssertionError
     if sh.shape[-1] < (deg + 1) ** 2:
@@ -168,6 +168,11 @@ def eval_sh_deferred(deg, sh, dirs):
         raise ValueError(f"eval_sh expects sh [..., 3, K] and dirs [..., 3]; got {tuple(sh.shape)}, {tuple(dirs.shape)}")
     if not sh.is_cuda or sh.dtype != torch.float32 or dirs.dtype != torch.float32 or dirs.device != sh.device:
         raise ValueError("eval_sh: float32 GPU tensors on one device required (there is no CPU fallback)")
+
+
+def eval_sh_deferred(deg, sh, dirs):
+    """`eval_sh` with the same contract and the same argument checks, returning a DeferredColor handle."""
+    _checked(deg, sh, dirs)
     if sh.dim() != 3:     # render() always passes [N,3,K]; other shapes take the ordinary route
         return eval_sh(deg, sh, dirs)
     return DeferredColor(int(deg), sh, dirs.contiguous())

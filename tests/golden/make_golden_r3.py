@@ -17,9 +17,10 @@ Every rasterizer call is recorded -- argument names, dtypes, shapes, STRIDES, th
 outputs, the upstream gradients autograd delivered and the gradients returned -- into
 tests/golden/reference_render_trace.npz; tests/test_gpu_render_trace.py replays it into the HIP path on the GPU.
 
-usage: python tests/golden/make_golden_r3.py [--check] [--with-prepass-hook]
+usage: python tests/golden/make_golden_r3.py [--check] [--with-prepass-hook] [--with-sh-hook]
   --check: regenerate and compare with the committed file
   --with-prepass-hook: with sfgs.prepass installed on the real GaussianModel (Deferred getter handles)
+  --with-sh-hook: with sfgs.sh installed on the real gaussian_renderer module (DeferredColor handles from eval_sh)
 """
 import json
 import math
@@ -151,6 +152,8 @@ def _loss(loss_utils, image, depth, cam, lambda_dssim=0.2, lambda_depth=0.5):
 
 
 HOOKED = None
+SH_HOOKED = None
+SH_SEEN = []
 
 
 def run():
@@ -176,6 +179,22 @@ def run():
         prepass.install(GaussianModel, fold=True)
         global HOOKED
         HOOKED = prepass
+    global SH_HOOKED
+    if "--with-sh-hook" in sys.argv:
+        # sfgs.sh's eval_sh hook (fold=True) on the REAL gaussian_renderer module: the name render() looks up returns a
+        # DeferredColor handle, render()'s own two statements (`+ 0.5`, `torch.clamp_min(., 0.0)`: :116-117, :124-125)
+        # are recorded on it and it arrives at the rasterizer as colors_precomp. The oracle double has no eval_sh-folded
+        # route, so the handle is materialised there -- by the stand-alone op, whose stand-in on this GPU-less host is
+        # the reference's OWN eval_sh (tests/test_sh_eval.py pins the HIP op to its golden vectors) -- and the committed
+        # trace must be reproduced bit for bit.
+        import gaussian_renderer
+        from sfgs import sh as sfsh
+        ref_eval_sh = gaussian_renderer.eval_sh
+        sfsh._checked = lambda deg, sh, dirs: None          # (the float32-GPU-tensor check: CPU tensors here)
+        sfsh._EvalSH = types.SimpleNamespace(apply=lambda deg, sh, dirs: ref_eval_sh(deg, sh, dirs))
+        sfsh.install(gaussian_renderer, fold=True)
+        assert gaussian_renderer.eval_sh is sfsh.eval_sh_deferred
+        SH_HOOKED = sfsh
     cams = _cameras(Camera)
     pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     black, white = torch.zeros(3), torch.ones(3)
@@ -203,6 +222,15 @@ def run():
             with torch.no_grad():
                 pkg = render(cam, model, pipe, bg, kernel_size=KERNEL_SIZE, **kw)
         assert len(trace) == n0 + 1
+        if SH_HOOKED is not None and trace[-1]["arg_tensors"]["colors_precomp"] is not None and not name.startswith("C_"):
+            # render()'s Python colour paths: what arrived is the handle, and what render() did to it on the way is
+            # EXACTLY the expression the rasterizer folds (the recorded offset / clamp; folded_inputs() itself reads None
+            # here because the recording wrapper has already looked at the values)
+            h = trace[-1]["arg_tensors"]["colors_precomp"]
+            assert isinstance(h, SH_HOOKED.DeferredColor), name
+            deg, sh_, dirs_, offset, clamp = h._sfgs_expr
+            assert (offset, clamp) == (0.5, 0.0) and deg == model.active_sh_degree and sh_.shape[1] == 3, name
+            SH_SEEN.append(name)
         if HOOKED is not None:   # the handles really travelled through render()
             a = trace[-1]["arg_tensors"]
             assert all(isinstance(a[k], HOOKED.Deferred) for k in ("scales", "opacities", "rotations")), name
@@ -302,6 +330,8 @@ def main():
             else:
                 np.testing.assert_array_equal(old[k], z[k], err_msg=k)
         print("reference_render_trace.npz reproduced:", len(trace), "calls;", summary)
+        if SH_HOOKED is not None:
+            print("deferred eval_sh handles arrived at the rasterizer in:", SH_SEEN)
         return
     np.savez_compressed(OUT, **z)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB;", [r["name"] for r in trace], summary)

@@ -40,6 +40,22 @@ def test_real_render_passes_the_prepass_hooks_deferred_handles_through(tmp_path)
     assert "reproduced: 7 calls" in r.stdout
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gaussian_renderer")), reason="reference tree not present (GPU box)")
+def test_real_render_records_its_two_colour_statements_on_the_deferred_eval_sh_handle(tmp_path):
+    """sfgs.sh.install(gaussian_renderer, fold=True) on the REAL module: the REAL render() calls the patched eval_sh, adds
+    0.5 and clamps (gaussian_renderer/__init__.py:115-117, :124-125) -- the driver asserts that what arrives at the
+    rasterizer as colors_precomp in every call of the appearance path and of convert_SHs_python is a DeferredColor that
+    recorded exactly `+ 0.5`, `clamp_min(0.0)` with the active SH degree and channel-major coefficients, i.e. the
+    expression the rasterizer folds into its preprocess kernels (GPU side: tests/test_gpu_sh_fold.py) -- and the oracle
+    double, which materialises the handle, reproduces the committed trace bit for bit."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden_r3.py"), "--check",
+                        "--with-sh-hook"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "reproduced: 7 calls" in r.stdout
+    assert ("deferred eval_sh handles arrived at the rasterizer in: ['A_mlp', 'A_mlp_jitter_cxcy', 'A_after_densify', "
+            "'A_testing_no_grad', 'B_sh_python_white']") in r.stdout
+
+
 def test_committed_trace_is_what_render_hands_the_rasterizer():
     """Static facts of the recorded boundary (runs everywhere): the 14 settings fields in the reference's order, the
     keyword set, dtypes and shapes of gaussian_renderer/__init__.py:132-140."""
