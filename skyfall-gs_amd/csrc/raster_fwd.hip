@@ -1091,11 +1091,119 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
 // per lane: the SHORT_LISTS form) or 1 024 (round 4: 48 KB, three workgroups per CU, the 16-key network for the lists
 // beyond 512 -- the MEDIUM_LISTS form for frames whose lists reach 513..1 024 entries, e.g. the reference's 45 / 25 degree
 // IDU cameras (arguments/__init__.py:238-249), which otherwise fell back to fine_bin + two sort kernels).
+// -DSFGS_SS_RADIX_MIN=256: select_sort_kernel<1024> sorts lists longer than that with the wave-level LDS radix sort below
+// instead of the register network (round 4 experiment, measured and NOT kept: profiles/r4_radix_sort_ab_not_kept.txt --
+// correct on every test and 150 soak configurations, low-elevation sort 0.325 -> 0.403 ms, dense 8 M 0.514 -> 0.492: its 64
+// serialised LDS round trips per list cost what the network's extra stages do). Default: never.
+#ifndef SFGS_SS_RADIX_MIN
+#define SFGS_SS_RADIX_MIN (1 << 30)
+#endif
 template <int SS_CAP>
 struct alignas(16) SelectSortLds {
   unsigned long long key[SS_CAP];
   uint32_t pay[SS_CAP];
+  uint32_t cnt[(SS_CAP > 512 && SFGS_SS_RADIX_MIN < (1 << 30)) ? 256 : 4];   // digit counters of the radix sort (experiment builds)
 };
+
+// ---- wave-level LSD radix sort of a tile's list in LDS (round 4; select_sort_kernel<1024>, lists of 257 .. 1 024 entries) -----
+// The register bitonic network costs O(n log^2 n): 55 stages x 16 keys per lane for 1 024 entries (~8 800 instructions per
+// wave); a counting sort on the 32 depth bits is 4 passes of 8-bit digits at ~60 instructions per key and pass, and a pass
+// in which every key has the same digit (the top byte of depths that differ by less than a factor of two ...) is skipped.
+// One pass, stable: the wave holds the list in registers (element r of a lane = list position 64 r + lane), (1) counts the
+// digits with LDS atomics, (2) scans the 256 counters (4 per lane), (3) ranks position by position -- for every r the 64
+// lanes find their same-digit peers with 8 ballots (match-any), rank = the digit's running base + the number of peers in
+// lower lanes, the group's first lane advances the base --, (4) writes every element to its new position in the LDS list
+// (which nobody reads during the pass: the registers hold everything) and reads its strided elements back.
+// Equal depths (a clone sits exactly on its parent until the optimiser moves it) leave the order inside a run to the
+// arrival order of the LDS list; a final odd-even pass over neighbours with equal depth bits puts them in id order, which
+// makes the result the same total order as the network's: (depth bits, id).
+__device__ __forceinline__ unsigned long long match_any8(unsigned d, bool valid) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long bal = __ballot(valid && bit);
+    peers &= bit ? bal : ~bal;
+  }
+  return peers;
+}
+
+template <int EPL, int SS_CAP>
+__device__ __forceinline__ void wave_radix_sort_lds(SelectSortLds<SS_CAP>& lds, int L, int lane) {
+  unsigned long long key[EPL];
+  unsigned pay[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) {
+    const int i = min(r * 64 + lane, SS_CAP - 1);
+    key[r] = lds.key[i]; pay[r] = lds.pay[i];
+  }
+  uint32_t* cnt = lds.cnt;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 32 + 8 * pass;
+    *reinterpret_cast<uint4*>(cnt + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int r = 0; r < EPL; ++r)
+      if (r * 64 + lane < L) atomicAdd(&cnt[(unsigned)(key[r] >> shift) & 0xffu], 1u);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint4 c = *reinterpret_cast<const uint4*>(cnt + 4 * lane);
+    const unsigned uL = (unsigned)L;
+    if (__ballot(c.x == uL || c.y == uL || c.z == uL || c.w == uL) != 0ull) continue;   // one digit holds every key
+    const unsigned tot = c.x + c.y + c.z + c.w;
+    const unsigned ex = wave_incl_scan_u32(tot) - tot;
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<uint4*>(cnt + 4 * lane) = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned pos[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const bool valid = r * 64 + lane < L;
+      const unsigned d = (unsigned)(key[r] >> shift) & 0xffu;
+      const unsigned long long peers = match_any8(d, valid);
+      const unsigned lower = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+      const unsigned base = cnt[d];
+      pos[r] = base + lower;
+      __builtin_amdgcn_wave_barrier();                      // every peer has read the base before the group's first lane
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // moves it on
+      if (valid && lower == 0u) cnt[d] = base + (unsigned)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+#pragma unroll
+    for (int r = 0; r < EPL; ++r)
+      if (r * 64 + lane < L) { lds.key[pos[r]] = key[r]; lds.pay[pos[r]] = pay[r]; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const int i = min(r * 64 + lane, SS_CAP - 1);
+      key[r] = lds.key[i]; pay[r] = lds.pay[i];
+    }
+  }
+  // the LDS list now holds the registers' content (also when every pass was skipped: it was never overwritten)
+  // ---- ties: neighbours with equal depth bits in id order (odd-even transposition, until a round swaps nothing) ----------
+  for (;;) {
+    bool swapped = false;
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase) {
+      for (int k = lane; 2 * k + phase + 1 < L; k += 64) {
+        const int p = 2 * k + phase;
+        const unsigned long long a = lds.key[p], b = lds.key[p + 1];
+        if ((unsigned)(a >> 32) == (unsigned)(b >> 32) && (unsigned)a > (unsigned)b) {
+          const unsigned pa = lds.pay[p], pb = lds.pay[p + 1];
+          lds.key[p] = b; lds.key[p + 1] = a; lds.pay[p] = pb; lds.pay[p + 1] = pa;
+          swapped = true;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (__ballot(swapped) == 0ull) break;
+  }
+}
 
 template <int SS_CAP>
 __global__ void __launch_bounds__(256)
@@ -1191,6 +1299,19 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
         }
       }
     };
+    if constexpr (SS_CAP > 512 && SFGS_SS_RADIX_MIN < (1 << 30)) {
+      if (L > SFGS_SS_RADIX_MIN) {   // the radix sort of the long lists (wave_radix_sort_lds above): sorted IN the LDS list
+        if (L <= 512) wave_radix_sort_lds<8, SS_CAP>(lds, L, lane);
+        else wave_radix_sort_lds<16, SS_CAP>(lds, L, lane);
+        const unsigned s = (unsigned)bin_base + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+        if (lane == 0) tile_range[t] = make_uint2(s, c);
+        for (int i = lane; i < L; i += 64) {
+          sorted_id[s + i] = (unsigned)(lds.key[i] & 0xffffffffull);
+          sorted_dup[s + i] = lds.pay[i];
+        }
+        return;
+      }
+    }
     if (L <= 64) finish(std::integral_constant<int, 1>{});
     else if (L <= 128) finish(std::integral_constant<int, 2>{});
     else if (L <= 256) finish(std::integral_constant<int, 4>{});

@@ -400,3 +400,35 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, monkeypatch):
         assert a["counters"][k] == b["counters"][k], k
     for k in a["grads"]:
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
+
+
+@pytest.mark.parametrize("route", ["fused", "fused1024"])
+def test_equal_depths_keep_the_id_order_on_every_route(route, monkeypatch):
+    """Clones sit exactly on their parents until the optimiser moves them (scene/gaussian_model.py: densify_and_clone):
+    every Gaussian here exists three times with the same mean, i.e. the same depth bits, in lists of ~800 entries. The
+    order inside a tile is (depth bits, id) on every route -- the register network sorts the 64-bit key, the radix sort of
+    the 1 024-entry fused kernel (round 4) sorts the depth bits and then orders the equal-depth neighbours by id -- so
+    images, radii and every gradient equal the split route's bit for bit, and the oracle's within the parity bars."""
+    frame, g = scene(300, 24, 24, seed=5, zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.03))
+    gen = torch.Generator().manual_seed(9)
+    g3 = {}
+    for k, v in g.items():
+        if v is None:
+            g3[k] = None
+        elif k == "means3D":
+            g3[k] = v.repeat(3, 1).contiguous()                       # identical positions: identical depth bits
+        else:                                                          # ... but different looks
+            g3[k] = torch.cat([v, v[torch.randperm(300, generator=gen)], v[torch.randperm(300, generator=gen)]]).contiguous()
+    gc, gd = upstream_grads(24, 24, 2)
+    R = orc.OracleRender(frame, **g3)
+    assert 256 < R.max_tile_list
+    monkeypatch.setenv("SFGS_SORT", route)
+    a = run_hip(frame, g3, gc, gd)
+    monkeypatch.setenv("SFGS_SORT", "split")
+    b = run_hip(frame, g3, gc, gd)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in a["grads"]:
+        np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
+    np.testing.assert_array_equal(a["radii"], R.radii)
+    parity.assert_image_close("color", a["color"], R.color)
