@@ -57,6 +57,15 @@
 #ifndef SFGS_BWD_LDS18
 #define SFGS_BWD_LDS18 0
 #endif
+//   -DSFGS_BWD_STORE3=0         the round-3 record stores: the combine step left float 4 k + row of the record in lane (entry,
+//                               row) of register k, i.e. three dword stores 16 bytes apart per lane. Shipped since round 4
+//                               (STORE3 = 1): the network's inputs are permuted so that the lane holds floats 3 row .. 3 row + 2 --
+//                               ONE global_store_dwordx3 per lane, an entry's four lanes cover its 48 contiguous bytes with one
+//                               instruction. Same sums, same bits; composite_bwd 0.406 -> 0.353 ms (profiles/r4_bwd_store3_ab.txt):
+//                               the kernel was paying for 48 store instructions' worth of address processing per batch.
+#ifndef SFGS_BWD_STORE3
+#define SFGS_BWD_STORE3 1
+#endif
 #ifndef SFGS_BWD_ROWSYM
 #define SFGS_BWD_ROWSYM 0
 #endif
@@ -484,7 +493,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #if defined(SFGS_BWD_XCHG)
   for (int i = lane; i < B * ROW; i += 64) lds.UW[i] = make_float2(0.f, 0.f);
 #endif
-  float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats grp, 4 + grp, 8 + grp
+  float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats 3 row .. 3 row + 2 (row = lane >> 4)
   unsigned p_dup = 0;
   bool p_valid = false;
   for (int bi = nbatch - 1; bi >= 0; --bi) {
@@ -525,8 +534,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       if constexpr (DG_F4 == 4) {   // one 16-byte quarter per lane: the entry's four lanes fill a 64-byte sector
         dupgrad[(size_t)p_dup * 4 + orow] = make_float4(pq0, pq1, pq2, 0.f);
       } else {
+#if SFGS_BWD_STORE3
+        typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
+        v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
+        *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
+#else
         float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + orow;
         dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
+#endif
       }
     }
 #if !defined(SFGS_BWD_XCHG)
@@ -682,9 +697,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     }
     // Combine the four partial lanes (ej, row 0..3) of every entry in a fixed order (deterministic). The record's 12
     // floats are linear in the sums, so every lane forms them from its PARTIAL sums first; then two rounds of the gfx950
-    // half-wave / row SWAPS reduce two (then four) values per instruction pair and leave float 4 k + row of the record
-    // in lane (ej, row) of register k: 9 v_permlane*_swap + 9 adds instead of 24 ds_bpermute + 24 adds, and each lane
-    // stores three floats (the deferred store needs 3 registers instead of 12).
+    // half-wave / row SWAPS reduce two (then four) values per instruction pair and leave floats 3 row .. 3 row + 2 of the
+    // record in lane (ej, row): 9 v_permlane*_swap + 9 adds instead of 24 ds_bpermute + 24 adds, and each lane stores its
+    // three floats with one 12-byte store (the deferred store needs 3 registers instead of 12).
     // The record holds the RAW sums (GradSums order): op and the conic, which turn them into dL/dmean2D, dL/dconic ...,
     // are the same for all duplicates of a Gaussian, so preprocess_bwd applies them once to the summed record
     // (raster_math.h: grad2d_from_sums) instead of this kernel once per (Gaussian, tile) pair -- 20 instructions per batch.
@@ -694,8 +709,15 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         // halves: lanes 0..31 get O[4k] summed over (row r, row r + 2), lanes 32..63 get O[4k+2]; likewise O[4k+1] / O[4k+3]
+#if SFGS_BWD_STORE3
+        // rows 0..3 end up with O[k], O[3 + k], O[6 + k], O[9 + k]: lane (ej, row) holds floats 3 row .. 3 row + 2 of the record in
+        // q[0..2] -- ONE 12-byte store per lane, the entry's four lanes cover its 48 contiguous bytes with one instruction
+        const float s02 = swap32_add(O[k], O[6 + k]);
+        const float s13 = swap32_add(O[3 + k], O[9 + k]);
+#else
         const float s02 = swap32_add(O[4 * k], O[4 * k + 2]);
         const float s13 = swap32_add(O[4 * k + 1], O[4 * k + 3]);
+#endif
         // rows: row 0 = O[4k], row 1 = O[4k+1], row 2 = O[4k+2], row 3 = O[4k+3], each summed over the four rows
         q[k] = swap16_add(s02, s13);
         if constexpr (B == 8)   // ... and over the two pixel rows that share a DPP row (lanes i and i + 8)
@@ -713,8 +735,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     if constexpr (DG_F4 == 4) {
       dupgrad[(size_t)p_dup * 4 + orow] = make_float4(pq0, pq1, pq2, 0.f);
     } else {
+#if SFGS_BWD_STORE3
+      typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
+      v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
+      *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
+#else
       float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + orow;
       dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
+#endif
     }
   }
 }
