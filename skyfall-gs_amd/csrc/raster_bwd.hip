@@ -970,8 +970,9 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     A.x = acc.get(0); A.y = acc.get(1); A.ax = acc.get(2); A.ay = acc.get(3);
     A.xx = acc.get(4); A.xy = acc.get(5); A.yy = acc.get(6); A.u = acc.get(7);
     A.r = acc.get(8); A.g = acc.get(9); A.b = acc.get(10); A.d = acc.get(11);
-    const float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
-    float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
+    float p[3], s[3];
+    load3(means3D + 3 * (size_t)g, p);
+    load3(scales + 3 * (size_t)g, s);
     const float4 qraw = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
     float4 qv = qraw;
     float opacity;
@@ -990,7 +991,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
       float shl[ROW];
       load_row<ROW>(shs + (size_t)ROW * g, shl);
       if constexpr (CM != 0) {
-        const float din[3] = {sh_dirs[3 * (size_t)g], sh_dirs[3 * (size_t)g + 1], sh_dirs[3 * (size_t)g + 2]};
+        float din[3];
+        load3(sh_dirs + 3 * (size_t)g, din);
         preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl, CM == 1, din, gdir);
       } else {
         preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl);
@@ -1015,23 +1017,16 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   } else if constexpr (RAW) {   // not visible: every gradient is zero (the raw opacity's in its own dtype)
     if (raw_mask & 2) static_cast<double*>(g_opac_)[g] = 0.0; else static_cast<float*>(g_opac_)[g] = 0.f;
   }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    g_means3D[3 * (size_t)g + i] = out.means3D[i];
-    g_means2D[3 * (size_t)g + i] = out.means2D[i];
-    g_scales[3 * (size_t)g + i] = out.scales[i];
-  }
+  store3(g_means3D + 3 * (size_t)g, out.means3D[0], out.means3D[1], out.means3D[2]);
+  store3(g_means2D + 3 * (size_t)g, out.means2D[0], out.means2D[1], out.means2D[2]);
+  store3(g_scales + 3 * (size_t)g, out.scales[0], out.scales[1], out.scales[2]);
   *reinterpret_cast<float4*>(g_rots + 4 * (size_t)g) = make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]);
   if constexpr (!RAW) static_cast<float*>(g_opac_)[g] = out.opacity;
   if constexpr (K > 0) {
     store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
-    if constexpr (CM != 0) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) g_sh_dirs[3 * (size_t)g + i] = gdir[i];
-    }
+    if constexpr (CM != 0) store3(g_sh_dirs + 3 * (size_t)g, gdir[0], gdir[1], gdir[2]);
   } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) g_colors[3 * (size_t)g + i] = out.rgb[i];
+    store3(g_colors + 3 * (size_t)g, out.rgb[0], out.rgb[1], out.rgb[2]);
   }
 }
 

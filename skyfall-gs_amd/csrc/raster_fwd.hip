@@ -162,13 +162,14 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     // every input of the Gaussian is requested before the first one is used (the empty asm below consumes one word of
     // each load, which keeps the compiler from sinking the loads behind the near-plane test inside project_gaussian and
     // behind `if (pr.visible)`: three dependent round trips to memory per thread otherwise)
-    float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
-    float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
+    float p[3], s[3];
+    load3(means3D + 3 * (size_t)g, p);
+    load3(scales + 3 * (size_t)g, s);
     float4 qv = *reinterpret_cast<const float4*>(rots + 4 * (size_t)g);
     float opacity_in = 0.f;
     if constexpr (!RAW) opacity_in = static_cast<const float*>(opac_)[g];
     float rgb_in[3] = {0.f, 0.f, 0.f};
-    if constexpr (K == 0) { rgb_in[0] = colors[3 * (size_t)g]; rgb_in[1] = colors[3 * (size_t)g + 1]; rgb_in[2] = colors[3 * (size_t)g + 2]; }
+    if constexpr (K == 0) load3(colors + 3 * (size_t)g, rgb_in);
     asm volatile("" :: "v"(p[2]), "v"(s[0]), "v"(qv.x), "v"(opacity_in), "v"(rgb_in[0]));   // all five in registers here
     if constexpr (RAW) {   // raw parameters -> what render() would have passed (the mask is uniform over the launch)
 #define SFGS_ACT_FWD(FT, OT)                                                                                        \
@@ -195,7 +196,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
         unsigned cm; float dir[3], len;
         if constexpr (CM != 0) {
-          const float din[3] = {sh_dirs[3 * (size_t)g], sh_dirs[3 * (size_t)g + 1], sh_dirs[3 * (size_t)g + 2]};
+          float din[3];
+          load3(sh_dirs + 3 * (size_t)g, din);
           sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len, CM == 1 ? 1 : 3, CM == 1 ? K : 1, din);
         } else {
           sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len);
@@ -1025,6 +1027,23 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&key)[EPL]
   bitonic_sizes<EPL, 2>(key, pay, lane);
 }
 
+// A lane's EPL consecutive list entries (positions lane * EPL ..) as 16-byte (8- / 4-byte) stores instead of EPL dword
+// stores 4 * EPL bytes apart (round 4: one scattered dword store per entry was the expensive way to write a list, cf.
+// profiles/r4_bwd_store3_ab.txt). Every list owns its slots up to the next multiple of 64 (LIST_ALIGN), so a lane whose
+// group starts inside that range writes all of it; the entries beyond the list's length are padding nobody reads.
+template <int EPL>
+__device__ __forceinline__ void store_list_entries(uint32_t* __restrict__ dst, const unsigned (&v)[EPL]) {
+  if constexpr (EPL >= 4) {
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i)
+      reinterpret_cast<uint4*>(dst)[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else if constexpr (EPL == 2) {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(v[0], v[1]);
+  } else {
+    dst[0] = v[0];
+  }
+}
+
 template <int EPL>
 __device__ __forceinline__ void sort_tile_in_registers(unsigned s, int L, int lane, const uint4* __restrict__ items,
                                                        uint32_t* __restrict__ sorted_id,
@@ -1043,13 +1062,13 @@ __device__ __forceinline__ void sort_tile_in_registers(unsigned s, int L, int la
     pay[r] = in ? it[r].z : 0u;
   }
   wave_bitonic_sort<EPL>(key, pay, lane);
+  static_assert(LIST_ALIGN % EPL == 0, "a lane's entries lie inside or outside the list's slot range as a whole");
+  if (lane * EPL < ((L + LIST_ALIGN - 1) & ~(LIST_ALIGN - 1))) {
+    unsigned ids[EPL];
 #pragma unroll
-  for (int r = 0; r < EPL; ++r) {
-    const int e = lane * EPL + r;
-    if (e < L) {
-      sorted_id[s + e] = (unsigned)(key[r] & 0xffffffffull);
-      sorted_dup[s + e] = pay[r];
-    }
+    for (int r = 0; r < EPL; ++r) ids[r] = (unsigned)(key[r] & 0xffffffffull);
+    store_list_entries<EPL>(sorted_id + s + lane * EPL, ids);
+    store_list_entries<EPL>(sorted_dup + s + lane * EPL, pay);
   }
 }
 
@@ -1290,13 +1309,12 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
       wave_bitonic_sort<EPL>(key, pay, lane);
       const unsigned s = (unsigned)bin_base + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
       if (lane == 0) tile_range[t] = make_uint2(s, c);
+      if (lane * EPL < ((L + LIST_ALIGN - 1) & ~(LIST_ALIGN - 1))) {   // the tile owns its slots up to the next multiple of 64
+        unsigned ids[EPL];
 #pragma unroll
-      for (int r = 0; r < EPL; ++r) {
-        const int e = lane * EPL + r;
-        if (e < L) {
-          sorted_id[s + e] = (unsigned)(key[r] & 0xffffffffull);
-          sorted_dup[s + e] = pay[r];
-        }
+        for (int r = 0; r < EPL; ++r) ids[r] = (unsigned)(key[r] & 0xffffffffull);
+        store_list_entries<EPL>(sorted_id + s + lane * EPL, ids);
+        store_list_entries<EPL>(sorted_dup + s + lane * EPL, pay);
       }
     };
     if constexpr (SS_CAP > 512 && SFGS_SS_RADIX_MIN < (1 << 30)) {

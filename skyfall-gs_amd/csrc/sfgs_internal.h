@@ -366,6 +366,18 @@ __device__ __forceinline__ void composite_wave_role(unsigned nblk, unsigned& sb,
   wave = (int)(l % PER) * WAVES + lw;
 }
 
+// ---- [N,3] rows (means, scales, colours and their gradients): ONE 12-byte access per thread instead of three dword accesses
+// 12 bytes apart (round 4; cf. profiles/r4_bwd_store3_ab.txt: partial scattered accesses cost per instruction, not per byte)
+typedef float sfgs_v3f __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void load3(const float* __restrict__ src, float (&dst)[3]) {
+  const sfgs_v3f v = *reinterpret_cast<const sfgs_v3f*>(src);
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+}
+__device__ __forceinline__ void store3(float* __restrict__ dst, float a, float b, float c) {
+  sfgs_v3f v; v.x = a; v.y = b; v.z = c;
+  *reinterpret_cast<sfgs_v3f*>(dst) = v;
+}
+
 // ---- per-Gaussian SH coefficient rows: 3K floats, 16-byte vector accesses when the row size allows -----------
 template <int CNT>
 __device__ __forceinline__ void load_row(const float* __restrict__ src, float (&dst)[CNT]) {
