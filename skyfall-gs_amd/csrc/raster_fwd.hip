@@ -25,6 +25,9 @@
 
 namespace sfgs {
 
+#ifndef SFGS_PRE_REC_TRANSPOSE
+#define SFGS_PRE_REC_TRANSPOSE 0   // preprocess: the wave's records leave through LDS as lane-contiguous stores (A/B knob, round 4)
+#endif
 #ifndef SFGS_FWD_STRIP_EXACT
 #define SFGS_FWD_STRIP_EXACT 0   // composite_fwd: exact ellipse-vs-pixel-row strip test (A/B knob, round 4)
 #endif
@@ -153,7 +156,11 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   bool big = false;                  // walk handled cooperatively by the wave (BIG_WALK < coarse bins < 64)
   bool huge = false;                 // >= 64 coarse bins: walked by big_walk_kernel
   const int lane = threadIdx.x & 63;
+#if SFGS_PRE_REC_TRANSPOSE
+  SplatRec r = {};   // every lane's record is stored
+#else
   SplatRec r;
+#endif
   BinRange br;
   float thr = 0.f;
   int cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;
@@ -204,11 +211,13 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         }
       }
       r = make_record(pr, opacity_in, rgb);
+#if !SFGS_PRE_REC_TRANSPOSE
       rec_out[REC_F4 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
       // (r, g) and (b, depth) sit in aligned pairs: the compositing loops fetch them with one 16-byte and one 8-byte
       // LDS read into the register pairs their packed multiply-adds take
       rec_out[REC_F4 * (size_t)g + 1] = make_float4(r.qc, r.op, r.r, r.g);
       rec_out[REC_F4 * (size_t)g + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
+#endif
       depth_bits = __float_as_uint(r.depth);
       br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
       br.y0 = imax(br.y0, kf.band0); br.y1 = imax(br.y0, imin(br.y1, kf.band1));  // band rendering
@@ -238,6 +247,28 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       }
     }
   }
+#if SFGS_PRE_REC_TRANSPOSE
+  {
+    // The wave's 64 records (48 bytes each, 3 KB contiguous in rec_out) leave through LDS so that every store instruction
+    // writes 64 ADJACENT 16-byte pieces (whole lines) instead of 64 pieces 48 bytes apart (experiment knob, round 4; the
+    // records of Gaussians that are not visible are written too -- nobody reads them)
+    static_assert(REC_F4 == 3, "48-byte records");
+    __shared__ float4 s_rec[PRE_BLOCK / 64][64 * 3];
+    float4* st = s_rec[threadIdx.x >> 6];
+    st[lane * 3 + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
+    st[lane * 3 + 1] = make_float4(r.qc, r.op, r.r, r.g);
+    st[lane * 3 + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const size_t w0 = (size_t)(blockIdx.x * PRE_BLOCK + (threadIdx.x & ~63)) * 3;   // first float4 of the wave's records
+    const size_t wend = (size_t)N * 3;
+    if (__ballot(vis != 0u) != 0ull) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (w0 + (size_t)(k * 64 + lane) < wend) rec_out[w0 + k * 64 + lane] = st[k * 64 + lane];
+    }
+  }
+#endif
   // Mid-size splats (more than BIG_WALK, fewer than 64 coarse bins) are walked by the whole wave, lane = tile, instead
   // of serially by their owner thread.
   const unsigned long long big_lanes = __ballot(big);
