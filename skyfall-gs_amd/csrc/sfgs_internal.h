@@ -387,6 +387,12 @@ __device__ __forceinline__ void load_row(const float* __restrict__ src, float (&
       const float4 v = reinterpret_cast<const float4*>(src)[i];
       dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
     }
+  } else if constexpr (CNT % 3 == 0) {   // 3 K floats with K = 1, 9, 25: 12-byte accesses instead of dwords a row apart
+#pragma unroll
+    for (int i = 0; i < CNT / 3; ++i) {
+      const sfgs_v3f v = reinterpret_cast<const sfgs_v3f*>(src)[i];
+      dst[3 * i] = v.x; dst[3 * i + 1] = v.y; dst[3 * i + 2] = v.z;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < CNT; ++i) dst[i] = src[i];
@@ -398,6 +404,12 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
 #pragma unroll
     for (int i = 0; i < CNT / 4; ++i)
       reinterpret_cast<float4*>(dst)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+  } else if constexpr (CNT % 3 == 0) {
+#pragma unroll
+    for (int i = 0; i < CNT / 3; ++i) {
+      sfgs_v3f v; v.x = src[3 * i]; v.y = src[3 * i + 1]; v.z = src[3 * i + 2];
+      reinterpret_cast<sfgs_v3f*>(dst)[i] = v;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < CNT; ++i) dst[i] = src[i];
