@@ -390,7 +390,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ src, float (&
   } else if constexpr (CNT % 3 == 0) {   // 3 K floats with K = 1, 9, 25: 12-byte accesses instead of dwords a row apart
 #pragma unroll
     for (int i = 0; i < CNT / 3; ++i) {
-      const sfgs_v3f v = reinterpret_cast<const sfgs_v3f*>(src)[i];
+      const sfgs_v3f v = *reinterpret_cast<const sfgs_v3f*>(src + 3 * i);   // (sizeof(sfgs_v3f) is 16: index in floats)
       dst[3 * i] = v.x; dst[3 * i + 1] = v.y; dst[3 * i + 2] = v.z;
     }
   } else {
@@ -408,7 +408,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
 #pragma unroll
     for (int i = 0; i < CNT / 3; ++i) {
       sfgs_v3f v; v.x = src[3 * i]; v.y = src[3 * i + 1]; v.z = src[3 * i + 2];
-      reinterpret_cast<sfgs_v3f*>(dst)[i] = v;
+      *reinterpret_cast<sfgs_v3f*>(dst + 3 * i) = v;
     }
   } else {
 #pragma unroll
