@@ -66,6 +66,14 @@
 #ifndef SFGS_BWD_STORE3
 #define SFGS_BWD_STORE3 1
 #endif
+//   -DSFGS_BWD_GATHER48=0       the round-3 gathers: three 16-byte loads per entry by 16 lanes and three LDS staging writes. Shipped
+//                               since round 4 (GATHER48 = 1): ONE gather instruction per batch -- 48 lanes = 16 entries x 3 pieces,
+//                               adjacent lanes on adjacent pieces, i.e. one 48-byte request per record instead of three 16-byte
+//                               ones -- staged with one contiguous LDS write; bit-identical, 0.364 -> 0.353 ms
+//                               (profiles/r4_gather48_ab.txt)
+#ifndef SFGS_BWD_GATHER48
+#define SFGS_BWD_GATHER48 (SFGS_BWD_LDS18 ? 0 : 1)
+#endif
 #ifndef SFGS_BWD_ROWSYM
 #define SFGS_BWD_ROWSYM 0
 #endif
@@ -464,13 +472,30 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int nbatch = (int)((kmax + B - 1) / B);
   // Software pipeline over the batches (back to front): the dependent id -> record gathers of the NEXT batch are in
   // flight while this one is processed, the ids of the one after are fetched alongside (as in the forward).
-  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  [[maybe_unused]] float4 n1 = n0, n2 = n0;
   unsigned dup_cur = 0, id_next = 0;
+#if SFGS_BWD_GATHER48
+  // one gather INSTRUCTION per batch: lane = (entry g_rec = lane / 3, 16-byte piece g_piece = lane % 3) for lanes < 3 B, so
+  // adjacent lanes fetch adjacent pieces of a record (one 48-byte request per record instead of three 16-byte ones from
+  // three instructions) and the LDS stage is written with one contiguous ds_write_b128 (float4 index = lane)
+  static_assert(3 * B <= 64 && REC_F4 == 3 && !SFGS_BWD_LDS18, "GATHER48: 48-byte records, at most 21 entries per batch");
+  const int g_rec = lane / 3, g_piece = lane - 3 * g_rec;
+#endif
   {
     const unsigned b0 = (unsigned)(nbatch - 1) * B;
     // the duplicate index of entry ej is needed by all four lanes (ej, row) of the entry: each stores a quarter of
     // the entry's gradient record (see the combine step)
     if ((unsigned)ej < kmax - b0) dup_cur = sorted_dup[s + b0 + ej];
+#if SFGS_BWD_GATHER48
+    if (lane < 3 * B && (unsigned)g_rec < kmax - b0) {
+      const unsigned id = sorted_id[s + b0 + g_rec];
+      n0 = rec[REC_F4 * (size_t)id + g_piece];
+    }
+    if (nbatch >= 2) {
+      if (lane < 3 * B) id_next = sorted_id[s + b0 - B + g_rec];
+    }
+#else
     if ((unsigned)lane < kmax - b0) {
       const unsigned id = sorted_id[s + b0 + lane];
       n0 = rec[REC_F4 * (size_t)id]; n1 = rec[REC_F4 * (size_t)id + 1]; n2 = rec[REC_F4 * (size_t)id + 2];
@@ -478,6 +503,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     if (nbatch >= 2) {
       if (lane < B) id_next = sorted_id[s + b0 - B + lane];
     }
+#endif
   }
   // hit-mask words of the tile's 64-entry groups (one uint2 per pixel and group), fetched one group ahead
   static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
@@ -515,19 +541,29 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       rr[0] = n0.x; rr[1] = n0.y; rr[2] = n0.z; rr[3] = n0.w; rr[4] = n1.x; rr[5] = n1.y; rr[6] = n1.z; rr[7] = n1.w;
       rr[8] = n2.x; rr[9] = n2.y;
     }
+#elif SFGS_BWD_GATHER48
+    if (lane < 3 * B && (unsigned)g_rec < cnt) lds.recs[lane] = n0;
 #else
     if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
 #endif
     if (bi >= 1) {  // batches below the last one are always full
       if (!(SFGS_BWD_ABLATE & 16))
+#if SFGS_BWD_GATHER48
+      if (lane < 3 * B) n0 = rec[REC_F4 * (size_t)id_next + g_piece];
+#else
       if (lane < B) { n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2]; }
+#endif
       // the duplicate indices of the NEXT batch (needed only when its records are stored): loaded one batch ahead into
       // the register whose old value was copied (my_dup) at the top of this iteration. A two-deep rotation
       // (cur <- next <- load) made the compiler copy the freshly loaded value right away: an s_waitcnt vmcnt(0) directly
       // behind the record gathers, i.e. every wave sat out the full gather latency once per batch.
       dup_cur = sorted_dup[s + b0 - B + ej];
       if (bi >= 2) {
+#if SFGS_BWD_GATHER48
+        if (lane < 3 * B) id_next = sorted_id[s + b0 - 2 * B + g_rec];
+#else
         if (lane < B) id_next = sorted_id[s + b0 - 2 * B + lane];
+#endif
       }
     }
     if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {  // the previous batch's gradient records

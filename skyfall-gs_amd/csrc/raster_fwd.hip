@@ -28,6 +28,9 @@ namespace sfgs {
 #ifndef SFGS_PRE_REC_TRANSPOSE
 #define SFGS_PRE_REC_TRANSPOSE 0   // preprocess: the wave's records leave through LDS as lane-contiguous stores (A/B knob, round 4)
 #endif
+#ifndef SFGS_FWD_GATHER3
+#define SFGS_FWD_GATHER3 0   // composite_fwd: the batch's records fetched in piece order (adjacent lanes on adjacent 16-byte pieces)
+#endif
 #ifndef SFGS_FWD_STRIP_EXACT
 #define SFGS_FWD_STRIP_EXACT 0   // composite_fwd: exact ellipse-vs-pixel-row strip test (A/B knob, round 4)
 #endif
@@ -1760,6 +1763,26 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   float4* st = stage[lw];
   // Software pipeline over batches of 64 list entries: the (dependent) id -> record gathers of batch i+1
   // are issued before batch i is composited, so their latency hides behind ~1600 VALU instructions.
+#if SFGS_FWD_GATHER3
+  // The batch's 64 records = 192 sixteen-byte pieces, fetched by three instructions in PIECE order: lane holds pieces
+  // 64 k + lane (k = 0, 1, 2), i.e. adjacent lanes fetch adjacent pieces of a record -- one 48-byte request per record
+  // instead of three 16-byte ones from three instructions -- and the LDS stage is written contiguously (float4 index =
+  // piece index). Round 4, with composite_bwd's GATHER48 (profiles/r4_gather48_ab.txt).
+  static_assert(REC_F4 == 3 && !SFGS_FWD_STRIP_EXACT, "48-byte records");
+  float4 nq[3];
+  unsigned idq[3];
+  unsigned q_rec[3], q_piece[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned q = 64u * k + (unsigned)lane;
+    q_rec[k] = q / 3u; q_piece[k] = q - 3u * q_rec[k];
+    nq[k] = make_float4(0.f, 0.f, 0.f, 0.f); idq[k] = 0u;
+    if (s + q_rec[k] < e) nq[k] = rec[REC_F4 * (size_t)sorted_id[s + q_rec[k]] + q_piece[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (s + 64 + q_rec[k] < e) idq[k] = sorted_id[s + 64 + q_rec[k]];
+#else
   float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
   unsigned id_next = 0;
   if (s + lane < e) {
@@ -1767,9 +1790,25 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     n0 = rec[REC_F4 * (size_t)id]; n1 = rec[REC_F4 * (size_t)id + 1]; n2 = rec[REC_F4 * (size_t)id + 2];
   }
   if (s + 64 + lane < e) id_next = sorted_id[s + 64 + lane];
+#endif
   for (unsigned b = s; b < e; b += 64) {
     if (__ballot(ps.T > 0.f) == 0ull) break;  // every pixel of the tile is saturated
     const unsigned cnt = min(64u, e - b);
+#if SFGS_FWD_GATHER3
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st[64 * k + lane] = nq[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)   // prefetch: records of the next batch, ids of the one after
+      if (b + 64 + q_rec[k] < e) nq[k] = rec[REC_F4 * (size_t)idq[k] + q_piece[k]];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (b + 128 + q_rec[k] < e) idq[k] = sorted_id[b + 128 + q_rec[k]];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // this lane's STAGED entry (entry index = lane): centre y and y-extent, for the strip lists
+    const float stage_my = reinterpret_cast<const float*>(st)[lane * 12 + 1];
+    const float stage_ey = reinterpret_cast<const float*>(st)[lane * 12 + 11];
+#else
     st[lane * 3] = n0; st[lane * 3 + 1] = n1; st[lane * 3 + 2] = n2;
     const float stage_my = n0.y, stage_ey = n2.w;
 #if SFGS_FWD_STRIP_EXACT
@@ -1781,6 +1820,7 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     if (b + 128 + lane < e) id_next = sorted_id[b + 128 + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
     const unsigned k0 = b - s;
     // Strip skipping. Only ~25 % of the (pixel, splat) pairs of a tile list hit (splats of a few pixels on an 8x8
     // tile), and a wave cannot skip per lane -- but it can per strip: lanes 16r..16r+15 (one DPP row) own pixel rows
