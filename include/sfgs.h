@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 12
+#define SFGS_ABI_VERSION 13
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -142,6 +142,13 @@ typedef struct SfgsGaussians {
   int32_t shs_channel_major;     /* with sh_dirs: 1 = `shs` is eval_sh's [N,3,sh_coeffs]; 0 = it is [N,sh_coeffs,3] (what
                                     render()'s convert_SHs_python path passes to eval_sh is a transposed VIEW of the
                                     model's [N,K,3] features: hand over the features themselves). 0 without sh_dirs */
+  /* SPLIT SH STORAGE (ABI 13). The reference's model keeps the SH coefficients as two parameters, _features_dc [N,1,3]
+   * and _features_rest [N,K-1,3], and concatenates them on every get_features call (scene/gaussian_model.py:227-231; two
+   * calls per render(): gaussian_renderer/__init__.py:114,121-122,127). When shs_rest is non-NULL, `shs` above holds
+   * coefficient 0 only ([N,1,3]) and shs_rest coefficients 1 .. sh_coeffs-1 ([N,sh_coeffs-1,3]); preprocess reads the two
+   * arrays, the backward writes SfgsGaussianGrads.shs ([N,1,3]) and .shs_rest: no concatenated copy, no split of its
+   * gradient. Needs sh_coeffs > 1 and shs_channel_major == 0; with or without sh_dirs. */
+  const float* shs_rest;         /* [N,sh_coeffs-1,3] or NULL = `shs` holds all sh_coeffs coefficients */
 } SfgsGaussians;
 
 /* Gradient outputs of the backward pass (all device, float32, fully overwritten). */
@@ -156,6 +163,7 @@ typedef struct SfgsGaussianGrads {
   float* colors_precomp; /* [N,3] or NULL */
   float* shs;            /* [N,sh_coeffs,3] or NULL ([N,3,sh_coeffs] with SfgsGaussians.shs_channel_major) */
   float* sh_dirs;        /* [N,3]; non-NULL exactly when SfgsGaussians.sh_dirs is */
+  float* shs_rest;       /* [N,sh_coeffs-1,3]; non-NULL exactly when SfgsGaussians.shs_rest is (`shs` is then [N,1,3]) */
 } SfgsGaussianGrads;
 
 /* Sizes (bytes) of the caller-owned scratch blobs. */

@@ -906,12 +906,13 @@ template <int K, int DEG, bool RAW, int CM>
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
-                      int raw_mask, const float* __restrict__ shs, const float* __restrict__ sh_dirs,
+                      int raw_mask, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                      const float* __restrict__ sh_dirs,
                       const int* __restrict__ radii,
                       const uint2* __restrict__ dup, const float4* __restrict__ dupgrad,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
                       float* __restrict__ g_rots, void* __restrict__ g_opac_, float* __restrict__ g_colors,
-                      float* __restrict__ g_shs, float* __restrict__ g_sh_dirs) {
+                      float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_sh_dirs) {
   constexpr int PB_CHUNK = 128;   // records per staging chunk and wave: 6 KB of LDS
   static_assert((PB_CHUNK * DG_F4) % 64 == 0, "whole load rounds");
   __shared__ float4 pb_stage[PRE_BLOCK / 64][PB_CHUNK * DG_F4];
@@ -1025,7 +1026,16 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     const float q[4] = {qv.x, qv.y, qv.z, qv.w};
     if constexpr (K > 0) {
       float shl[ROW];
-      load_row<ROW>(shs + (size_t)ROW * g, shl);
+      if constexpr (K > 1) {
+        if (shs_rest) {   // split storage: coefficient 0 in `shs`, the others in `shs_rest` (SfgsGaussians.shs_rest)
+          load3(shs + 3 * (size_t)g, reinterpret_cast<float(&)[3]>(shl[0]));
+          load_row<ROW - 3>(shs_rest + (size_t)(ROW - 3) * g, reinterpret_cast<float(&)[ROW - 3]>(shl[3]));
+        } else {
+          load_row<ROW>(shs + (size_t)ROW * g, shl);
+        }
+      } else {
+        load_row<ROW>(shs + (size_t)ROW * g, shl);
+      }
       if constexpr (CM != 0) {
         float din[3];
         load3(sh_dirs + 3 * (size_t)g, din);
@@ -1059,7 +1069,16 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   *reinterpret_cast<float4*>(g_rots + 4 * (size_t)g) = make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]);
   if constexpr (!RAW) static_cast<float*>(g_opac_)[g] = out.opacity;
   if constexpr (K > 0) {
-    store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
+    if constexpr (K > 1) {
+      if (g_shs_rest) {
+        store3(g_shs + 3 * (size_t)g, gshl[0], gshl[1], gshl[2]);
+        store_row<ROW - 3>(g_shs_rest + (size_t)(ROW - 3) * g, reinterpret_cast<const float(&)[ROW - 3]>(gshl[3]));
+      } else {
+        store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
+      }
+    } else {
+      store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
+    }
     if constexpr (CM != 0) store3(g_sh_dirs + 3 * (size_t)g, gdir[0], gdir[1], gdir[2]);
   } else {
     store3(g_colors + 3 * (size_t)g, out.rgb[0], out.rgb[1], out.rgb[2]);
@@ -1098,6 +1117,9 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                    (g->shs != nullptr) == (grads->shs != nullptr) && (g->sh_dirs != nullptr) == (grads->sh_dirs != nullptr),
                SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
   SFGS_REQUIRE(!g->sh_dirs || g->shs, SFGS_E_ARG, "sh_dirs without shs");
+  SFGS_REQUIRE((g->shs_rest != nullptr) == (grads->shs_rest != nullptr) &&
+                   (!g->shs_rest || (g->shs && frame->sh_coeffs > 1 && g->shs_channel_major == 0)),
+               SFGS_E_ARG, "shs_rest (split SH storage): gradient output must match, needs shs, sh_coeffs > 1, coefficient-major");
   SFGS_REQUIRE(g->filter_3D ? (g->raw_f64_mask & ~3) == 0 : g->raw_f64_mask == 0, SFGS_E_ARG,
                "raw_f64_mask %d: bit 0 = filter_3D is float64, bit 1 = raw opacities are float64; 0 without filter_3D",
                g->raw_f64_mask);
@@ -1141,8 +1163,9 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
 #define SFGS_LAUNCH_PBWD_(K, D, RAW, CM)                                                                               \
   hipLaunchKernelGGL((preprocess_bwd_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,  \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask, g->shs,   \
-                     g->sh_dirs, radii, gv.dup, (const float4*)dupgrad, grads->means3D, grads->means2D, grads->scales, \
-                     grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs, grads->sh_dirs)
+                     g->shs_rest, g->sh_dirs, radii, gv.dup, (const float4*)dupgrad, grads->means3D, grads->means2D,   \
+                     grads->scales, grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs,      \
+                     grads->shs_rest, grads->sh_dirs)
 #define SFGS_LAUNCH_PBWD(K, D)                                                                                         \
   do {                                                                                                                 \
     if constexpr ((K) > 0) {                                                                                           \

@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
                   int raw_mask,
-                  const float* __restrict__ colors, const float* __restrict__ shs, const float* __restrict__ sh_dirs,
-                  int* __restrict__ radii,
+                  const float* __restrict__ colors, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                  const float* __restrict__ sh_dirs, int* __restrict__ radii,
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
@@ -203,7 +203,16 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         rgb[0] = rgb_in[0]; rgb[1] = rgb_in[1]; rgb[2] = rgb_in[2];
       } else {
         float shl[3 * K];
-        load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
+        if constexpr (K > 1) {
+          if (shs_rest) {   // split storage (SfgsGaussians.shs_rest): coefficient 0 and coefficients 1 .. K-1 in two arrays
+            load3(shs + 3 * (size_t)g, reinterpret_cast<float(&)[3]>(shl[0]));
+            load_row<3 * K - 3>(shs_rest + (3 * (size_t)K - 3) * g, reinterpret_cast<float(&)[3 * K - 3]>(shl[3]));
+          } else {
+            load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
+          }
+        } else {
+          load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
+        }
         unsigned cm; float dir[3], len;
         if constexpr (CM != 0) {
           float din[3];
@@ -2028,6 +2037,8 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
     SFGS_REQUIRE(!g->sh_dirs || g->shs, SFGS_E_ARG, "sh_dirs (eval_sh-folded colour path) needs shs");
     SFGS_REQUIRE(g->sh_dirs ? (g->shs_channel_major & ~1) == 0 : g->shs_channel_major == 0, SFGS_E_ARG,
                  "shs_channel_major %d: 0 or 1, and 0 without sh_dirs", g->shs_channel_major);
+    SFGS_REQUIRE(!g->shs_rest || (g->shs && f->sh_coeffs > 1 && g->shs_channel_major == 0), SFGS_E_ARG,
+                 "shs_rest (split SH storage) needs shs, sh_coeffs > 1 and coefficient-major storage");
     if (g->shs)
       SFGS_REQUIRE(f->sh_coeffs >= (f->sh_degree + 1) * (f->sh_degree + 1) &&
                        (f->sh_coeffs == 1 || f->sh_coeffs == 4 || f->sh_coeffs == 9 || f->sh_coeffs == 16 || f->sh_coeffs == 25),
@@ -2101,7 +2112,8 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
 #define SFGS_LAUNCH_PRE_(K, D, RAW, CM)                                                                                \
   hipLaunchKernelGGL((preprocess_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,      \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask,           \
-                     g->colors_precomp, g->shs, g->sh_dirs, radii, gv.rec, gv.dup, tv.coarse_count, bv.slabs,          \
+                     g->colors_precomp, g->shs, g->shs_rest, g->sh_dirs, radii, gv.rec, gv.dup, tv.coarse_count,       \
+                     bv.slabs,                                                                                         \
                      (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
                      gv.big_list, tv.hdr, tv.dup_pool, two_pass ? bv.pairs : nullptr, gv.block_items)
 #define SFGS_LAUNCH_PRE(K, D)                                                                                          \

@@ -247,18 +247,23 @@ def _dp(t):
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings, filter_3D=None,
-                sh_dirs=None, sh_degree=None, sh_channel_major=False):
+                sh_dirs=None, sh_degree=None, sh_channel_major=False, shs_rest=None):
         # filter_3D given: RAW-PARAMETER MODE (include/sfgs.h SfgsGaussians) -- opacities / scales / rotations are the
         # model's raw parameters (opacities possibly float64) and the gradients returned for them are the raw ones
         # sh_dirs given: EVAL_SH-FOLDED COLOUR PATH -- shs holds eval_sh's coefficients ([N,3,K] when sh_channel_major,
         # else [N,K,3]), sh_dirs its `dirs`, sh_degree the degree it was called with (sfgs.sh.DeferredColor)
+        # shs_rest given: SPLIT SH STORAGE -- shs is the model's _features_dc [N,1,3], shs_rest its _features_rest [N,K-1,3]
+        # (sfgs.features.DeferredFeatures); their two gradients come back separately
         lib = L.load()
         dev = means3D.device
         di = dev.index
         N = int(means3D.shape[0])
         H, W = int(settings.image_height), int(settings.image_width)
         sh_coeffs = 0 if shs is None else int(shs.shape[2] if sh_channel_major else shs.shape[1])
-        need_bwd = any(ctx.needs_input_grad[:7]) or (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9])
+        if shs_rest is not None:
+            sh_coeffs = 1 + int(shs_rest.shape[1])
+        nig = ctx.needs_input_grad
+        need_bwd = any(nig[:7]) or (len(nig) > 9 and nig[9]) or (len(nig) > 12 and nig[12])
         band = getattr(settings, "tile_rows", None)
         if need_bwd and band:
             raise ValueError("tile_rows (band rendering) is a forward-only extension: the backward needs the whole "
@@ -277,6 +282,8 @@ class _Rasterize(torch.autograd.Function):
                 gs.sh_dirs = sh_dirs.data_ptr()
                 gs.shs_channel_major = int(bool(sh_channel_major))
                 frame.sh_degree = int(sh_degree)
+            if shs_rest is not None:
+                gs.shs_rest = shs_rest.data_ptr()
             if filter_3D is not None:
                 from sfgs.prepass import f64_mask
                 gs.filter_3D = filter_3D.data_ptr()
@@ -392,13 +399,14 @@ class _Rasterize(torch.autograd.Function):
             ctx.st = (frame, gs, keep, cap, ccap, D, int(cnt.num_big_chunks), hkey, sh_coeffs, colors_precomp is not None,
                       shs is not None, opacities.dtype, total, settings, bool(sh_channel_major))
             ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D,
-                                  sh_dirs)
+                                  sh_dirs, shs_rest)
         return color, depth, norm, alpha, radii
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_norm, g_alpha, g_radii):
         lib = L.load()
-        means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D, sh_dirs = ctx.saved_tensors
+        (means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D, sh_dirs,
+         shs_rest) = ctx.saved_tensors
         (frame0, gs, keep, cap, ccap, ndup, big_chunks, hkey, K, has_colors, has_shs, opac_dtype, total, settings, sh_cm) = ctx.st
         dev = means3D.device
         di = dev.index
@@ -432,6 +440,9 @@ class _Rasterize(torch.autograd.Function):
             sizes = [pad(4 * N), pad(3 * N), pad(3 * N), pad(3 * N)]
             if f32_opac:
                 sizes.append(pad(N))
+            if shs_rest is not None:
+                sizes.append(pad((ncol - 3) * N))           # split SH storage: dL/d(_features_rest), then dL/d(_features_dc) last
+                ncol = 3
             sizes.append(pad(ncol * N))
             if sh_dirs is not None:
                 sizes.insert(len(sizes) - 1, pad(3 * N))    # dL/d(dirs) of the eval_sh-folded colour path
@@ -446,9 +457,14 @@ class _Rasterize(torch.autograd.Function):
             g_last = parts[-1][:ncol * N]
             g_col = g_last.view(N, 3) if has_colors else None
             g_dirs = parts[-2][:3 * N].view(N, 3) if sh_dirs is not None else None
-            g_shs = (g_last.view(N, 3, K) if sh_cm else g_last.view(N, K, 3)) if has_shs else None
+            g_rest = None
+            if shs_rest is not None:
+                g_shs = g_last.view(N, 1, 3)
+                g_rest = parts[-3 if sh_dirs is not None else -2][:(3 * K - 3) * N].view(N, K - 1, 3)
+            else:
+                g_shs = (g_last.view(N, 3, K) if sh_cm else g_last.view(N, K, 3)) if has_shs else None
             grads = L.SfgsGaussianGrads(_SIZEOF_GRADS, g_means3D.data_ptr(), g_means2D.data_ptr(), g_scales.data_ptr(),
-                                        g_rot.data_ptr(), g_opac.data_ptr(), _dp(g_col), _dp(g_shs), _dp(g_dirs))
+                                        g_rot.data_ptr(), g_opac.data_ptr(), _dp(g_col), _dp(g_shs), _dp(g_dirs), _dp(g_rest))
             # one record per duplicate INDEX: the indices come from 8 disjoint ranges of [0, capacity) (no single allocator
             # word), so the array spans the capacity the frame was planned with; the gaps are never touched
             dg_bytes = _layout(lib, N, int(settings.image_width), int(settings.image_height), cap, ccap, True)[1] if ndup else 256
@@ -460,7 +476,7 @@ class _Rasterize(torch.autograd.Function):
         finally:
             if switch:
                 torch.cuda.set_device(prev_dev)
-        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None, g_dirs, None, None
+        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None, g_dirs, None, None, g_rest
 
 
 def _f32grad(g):
@@ -497,23 +513,27 @@ class _HipBackend:
             raise ValueError(f"{name} must live on the GPU (got {t.device}); this rasterizer has no CPU path")
 
     supports_sh_dirs = True   # the eval_sh-folded colour path: sh_fold = (degree, coefficients, dirs[N,3], channel_major)
+    supports_shs_rest = True  # split SH storage: `shs` (or sh_fold's coefficients) may be the pair (features_dc, features_rest)
 
     @staticmethod
     def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings, sh_fold=None):
-        if sh_fold is not None:
-            return _Rasterize.apply(means3D, means2D, sh_fold[1], None, opacities, scales, rotations, raster_settings,
-                                    None, sh_fold[2], sh_fold[0], sh_fold[3])
-        return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings)
+        return _HipBackend.rasterize_raw(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, None,
+                                         raster_settings, sh_fold)
 
     @staticmethod
     def rasterize_raw(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation, filter_3D,
                       raster_settings, sh_fold=None):
-        """Raw-parameter mode: the activations + 3D filter of sfgs.prepass run inside preprocess / preprocess_bwd."""
+        """filter_3D given: raw-parameter mode -- the activations + 3D filter of sfgs.prepass run inside preprocess /
+        preprocess_bwd."""
+        dirs = deg = None
+        cm = False
         if sh_fold is not None:
-            return _Rasterize.apply(means3D, means2D, sh_fold[1], None, raw_opacity, raw_scaling, raw_rotation,
-                                    raster_settings, filter_3D, sh_fold[2], sh_fold[0], sh_fold[3])
+            deg, shs, dirs, cm = sh_fold
+        rest = None
+        if isinstance(shs, tuple):
+            shs, rest = shs
         return _Rasterize.apply(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation,
-                                raster_settings, filter_3D)
+                                raster_settings, filter_3D, dirs, deg, cm, rest)
 
 
 _backend = _HipBackend
@@ -565,22 +585,41 @@ class GaussianRasterizer(nn.Module):
             sh_fold = colors_precomp.folded_inputs() if getattr(_backend, "supports_sh_dirs", False) else None
             if sh_fold is None:
                 colors_precomp = colors_precomp.materialise()
-            elif sh_fold[1].shape[0] != N or tuple(sh_fold[2].shape) != (N, 3) or sh_fold[1].device != means3D.device:
-                raise ValueError("colors_precomp (deferred eval_sh): first dimension / device must match means3D")
+            else:
+                coeffs = sh_fold[1]
+                if isinstance(coeffs, tuple) and not getattr(_backend, "supports_shs_rest", False):
+                    coeffs = torch.cat(coeffs, dim=1)
+                    sh_fold = (sh_fold[0], coeffs, sh_fold[2], sh_fold[3])
+                first = coeffs[0] if isinstance(coeffs, tuple) else coeffs
+                if first.shape[0] != N or tuple(sh_fold[2].shape) != (N, 3) or first.device != means3D.device:
+                    raise ValueError("colors_precomp (deferred eval_sh): first dimension / device must match means3D")
         if sh_fold is None:
             colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
+        shs_rest = None
         if shs is not None:
+            # DeferredFeatures (sfgs.features' patched get_features, handed over untouched): the library reads the model's
+            # two coefficient parameters themselves; a handle something looked into is the ordinary tensor
+            from sfgs import features as _features
+            if isinstance(shs, _features.DeferredFeatures):
+                parts = _features.split_parts(shs) if getattr(_backend, "supports_shs_rest", False) else None
+                if parts is not None and not parts[2]:
+                    shs, shs_rest = parts[0], parts[1]
+                else:
+                    shs = shs.materialise()
             shs = _f32c(shs, "shs")
             if shs.dim() != 3 or shs.shape[2] != 3:
                 raise ValueError("shs must be [N,K,3]")
             deg = int(self.raster_settings.sh_degree)
-            if shs.shape[1] < (deg + 1) ** 2 or shs.shape[1] not in (1, 4, 9, 16, 25):
-                raise ValueError(f"shs has {shs.shape[1]} coefficients per Gaussian; expected (max_degree + 1)^2 in "
+            k = shs.shape[1] + (0 if shs_rest is None else shs_rest.shape[1])
+            if k < (deg + 1) ** 2 or k not in (1, 4, 9, 16, 25):
+                raise ValueError(f"shs has {k} coefficients per Gaussian; expected (max_degree + 1)^2 in "
                                  f"(1, 4, 9, 16, 25) and at least {(deg + 1) ** 2} for active degree {deg}")
         for name, t in (("scales", scales), ("rotations", rotations),
                         ("colors_precomp", None if sh_fold is not None else colors_precomp), ("shs", shs)):
             if t is not None and (t.shape[0] != N or t.device != means3D.device):
                 raise ValueError(f"{name}: first dimension / device must match means3D")
+        if shs_rest is not None:
+            shs = (shs, shs_rest)
         _settings_tensors(self.raster_settings, means3D.device)   # shapes / dtypes / devices of the 14-field tuple
         kw = {} if sh_fold is None else {"sh_fold": sh_fold}
         if sh_fold is not None:

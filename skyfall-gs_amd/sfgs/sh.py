@@ -108,12 +108,21 @@ class DeferredColor(torch.Tensor):
         the [N,3,K] tensor itself when it is contiguous (channel_major = True: the appearance path's `.contiguous()`
         result) or, when it is the transposed view of a contiguous [N,K,3] tensor (convert_SHs_python:
         `pc.get_features.transpose(1, 2).view(-1, 3, K)`), that [N,K,3] tensor (channel_major = False) -- no copy
-        either way; any other striding is made contiguous."""
+        either way; any other striding is made contiguous. With sfgs.features installed the convert_SHs_python view is a
+        DeferredFeatures handle and `coefficients` the PAIR (features_dc [N,1,3], features_rest [N,K-1,3])."""
         deg, sh, dirs, offset, clamp = self._sfgs_expr
         if self._sfgs_real is not None or offset != 0.5 or clamp != 0.0:
             return None
         if deg > FOLD_MAX_DEGREE or sh.shape[2] not in FOLD_COEFFS:
             return None
+        from . import features
+        if isinstance(sh, features.DeferredFeatures):
+            # convert_SHs_python with sfgs.features installed: `pc.get_features.transpose(1, 2).view(-1, 3, K)` is still a
+            # handle on the model's two parameters -- the rasterizer reads them as they are (SfgsGaussians.shs_rest)
+            parts = features.split_parts(sh)
+            if parts is not None and parts[2]:
+                return deg, (parts[0], parts[1]), dirs, False
+            sh = sh.materialise()
         if sh.is_contiguous():
             return deg, sh, dirs, True
         t = sh.transpose(1, 2)
