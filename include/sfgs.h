@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 13
+#define SFGS_ABI_VERSION 14
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -194,7 +194,11 @@ typedef struct SfgsRasterCounters {
                                   over because a few workgroups own most of the frame's duplicates: double
                                   dup_capacity. A caller should also treat max_coarse_bin > coarse_capacity as
                                   overflow (the library ORs it in; belt and braces)                         */
-  int64_t max_coarse_bin;      /* items in the fullest 32x32-pixel coarse bin                               */
+  int64_t max_coarse_bin;      /* most items appended DIRECTLY to one 32x32-pixel coarse bin's slab: those of the splats
+                                  that reach more than 6 coarse bins (a whole wave walks them) or, with one-pass binning,
+                                  every item. ABI 14: the items of the default two-pass binning no longer count -- they are
+                                  stored bin-sorted and exactly sized, without a per-bin capacity -- so this is 0 for a
+                                  frame of small splats, however skewed (a distant view: the scene in a few bins) */
   int64_t num_huge_splats;     /* splats reaching >= 64 coarse bins (their walk is a kernel of its own)        */
   int64_t num_big_chunks;      /* 1024-record chunks of Gaussians with > 2048 duplicates (backward pre-reduction) */
   int64_t prev_valid;          /* != 0: the prev_* fields below were read from SfgsFrame.feedback              */
@@ -204,6 +208,9 @@ typedef struct SfgsRasterCounters {
   int64_t prev_tiles_over_512; /* previous frame: tiles with more than 512 entries, whichever route sorted them
                                   (prev_long_tiles counts the tiles LEFT to the long-list kernels: under MEDIUM_LISTS
                                   only those beyond 1 024): MEDIUM_LISTS pays when they are a sizeable part of the frame */
+  int64_t max_bin_items;       /* ALL items of the fullest coarse bin (slab + bin-sorted run): what SFGS_HINT_SHORT_LISTS is
+                                  chosen from. Filled by sfgs_raster_counters_decode / sfgs_raster_read_counters; 0 from
+                                  sfgs_raster_read_counters_pinned (its 64 bytes end before it) */
 } SfgsRasterCounters;
 
 int sfgs_abi_version(void);
@@ -230,10 +237,13 @@ int64_t sfgs_raster_slot_capacity(int32_t W, int32_t H, int64_t num_duplicates);
 
 /* Forward, stage 1 ("plan"): preprocess every Gaussian (cull, EWA projection, 2D mip filter,
  * radius, SH->RGB), write radii[N] (int32) and bin every Gaussian COARSELY: one 16-byte item per
- * (Gaussian, 32x32-pixel coarse bin) holding the mask of the 8x8 tiles it can contribute to, appended
- * to that bin's slab in `bins` (coarse_capacity items per bin; dup_capacity duplicate indices).
- * Neither count is known beforehand: if the counters report overflow, call again with a bins blob
- * sized for counters.num_duplicates / counters.max_coarse_bin. Asynchronous on `stream`.
+ * (Gaussian, 32x32-pixel coarse bin) holding the mask of the 8x8 tiles it can contribute to. The items
+ * are sorted by bin into an exactly sized array inside `bins` (one radix pass; memory in proportion to
+ * the items, whatever the frame's skew -- ABI 14); only the items of splats that reach more than 6
+ * coarse bins are appended to their bin's slab (coarse_capacity items per bin) with an atomic each.
+ * dup_capacity = duplicate indices / list slots. Neither count is known beforehand: if the counters
+ * report overflow, call again with a bins blob sized for counters.num_duplicates /
+ * counters.max_coarse_bin. Asynchronous on `stream`.
  * counters_pinned_host_128 (optional): 128 bytes of PINNED host memory (hipHostMalloc / torch pin_memory) that the
  * plan's last kernel fills with the frame's counters. Record an event right after this call, enqueue
  * sfgs_raster_forward_render, THEN wait for the event and sfgs_raster_counters_decode the buffer: the capacity

@@ -551,8 +551,9 @@ __device__ __forceinline__ int rank_row(int k, int NWG) {
 }
 __global__ void __launch_bounds__(RANK_COLS * RANK_GROUPS)
 bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_hits,
-                uint32_t* __restrict__ sc_base, uint32_t* __restrict__ coarse_count) {
+                uint32_t* __restrict__ sc_base, uint32_t* __restrict__ coarse_count, unsigned long long* __restrict__ hdr) {
   __shared__ unsigned s_c[RANK_GROUPS][RANK_COLS], s_h[RANK_GROUPS][RANK_COLS];
+  __shared__ unsigned s_tot[RANK_COLS], s_first[RANK_COLS];
   const int c = threadIdx.x % RANK_COLS, g = threadIdx.x / RANK_COLS;
   const int bin = min(blockIdx.x * RANK_COLS + c, NCB - 1);      // (lanes beyond the last bin repeat it and write nothing)
   const bool live = blockIdx.x * RANK_COLS + c < NCB;
@@ -574,7 +575,25 @@ bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uin
   }
   s_c[g][c] = sc; s_h[g][c] = sh;
   __syncthreads();                                   // (every row group has read the counter BEFORE the last one rewrites it)
-  unsigned run = (unsigned)old;
+  // The bins' runs in BinsView::csr are EXACTLY sized: this workgroup takes the room of its 16 bins with ONE device atomic
+  // on the header's cursor (128 atomics per frame at 1080p) and lays the bins out one after the other. Which workgroup comes
+  // first is a race -- it decides where a bin's run lies, never what it holds.
+  if (g == 0) {
+    unsigned tot = 0u;
+    for (int q = 0; q < RANK_GROUPS; ++q) tot += s_c[q][c];
+    s_tot[c] = live ? tot : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned sum = 0u;
+#pragma unroll
+    for (int k = 0; k < RANK_COLS; ++k) { s_first[k] = sum; sum += s_tot[k]; }
+    const unsigned at = (unsigned)atomicAdd(&hdr[HDR_CSR_CURSOR], (unsigned long long)sum);
+#pragma unroll
+    for (int k = 0; k < RANK_COLS; ++k) s_first[k] += at;
+  }
+  __syncthreads();
+  unsigned run = s_first[c];                         // position in BinsView::csr
   for (int q = 0; q < g; ++q) run += s_c[q][c];
   for (int w = w0; w < w1; w += 4) {
     unsigned tc[4];
@@ -587,10 +606,13 @@ bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uin
         run += tc[u];
       }
   }
-  if (g == RANK_GROUPS - 1 && live) {   // (its `run` is the bin's new item count; empty trailing groups carry it along)
+  if (g == RANK_GROUPS - 1 && live) {
     unsigned hits = (unsigned)(old >> 32);
     for (int q = 0; q < RANK_GROUPS; ++q) hits += s_h[q][c];
-    *counter = (unsigned long long)run | ((unsigned long long)hits << 32);
+    // word 0: ALL items of the bin (the directly appended ones + this run), word 1: their tile hits
+    *counter = (unsigned long long)((unsigned)old + s_tot[c]) | ((unsigned long long)hits << 32);
+    coarse_count[(size_t)bin * CC_STRIDE + 6] = s_first[c];
+    coarse_count[(size_t)bin * CC_STRIDE + 7] = s_tot[c];
   }
 }
 
@@ -610,8 +632,8 @@ __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__
 __global__ void __launch_bounds__(SCATTER_NT)
 bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_t* __restrict__ block_items,
                    const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_base,
-                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long* __restrict__ hdr,
-                   int plan_roles, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
+                   uint4* __restrict__ csr, unsigned csr_capacity, unsigned coarse_capacity,
+                   unsigned long long* __restrict__ hdr, int plan_roles, uint32_t* __restrict__ coarse_count, const uint32_t* __restrict__ block_nvis,
                    const unsigned long long* __restrict__ block_dref, const unsigned long long* __restrict__ feedback,
                    const unsigned long long* __restrict__ dup_pool, unsigned long long* __restrict__ host_out) {
   const int n_scatter = (int)gridDim.x - plan_roles;
@@ -623,7 +645,7 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
   const int wg = (int)blockIdx.x;   // scatter workgroup
   __shared__ unsigned s_prefix[SCATTER_BLOCKS + 1];
   __shared__ unsigned s_red[SCATTER_NT / 64 + 1];
-  __shared__ unsigned s_delta[SCATTER_BINS];   // bin's first slab rank - its first sorted position
+  __shared__ unsigned s_delta[SCATTER_BINS];   // first position of the workgroup's run of the bin in `csr` - its first sorted position
   __shared__ unsigned s_cur[SCATTER_BINS];     // the bin's cursor in the sorted order
   __shared__ unsigned short s_idx[SCATTER_IDX];   // pair index at every sorted position
   const int tid = threadIdx.x;
@@ -668,9 +690,9 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
           if (pos < (unsigned)SCATTER_IDX) {
             s_idx[pos] = (unsigned short)(i0 + u * SCATTER_NT);
           } else {
-            const unsigned rank = s_delta[cb] + pos;
-            if (rank < coarse_capacity) slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, m);
-            else hdr[HDR_OVERFLOW] = 1ull;
+            const unsigned at = s_delta[cb] + pos;
+            if (at < csr_capacity) csr[at] = make_uint4(it[u].x, it[u].y, it[u].z, m);
+            else hdr[HDR_OVERFLOW] = 1ull;   // (cannot happen: the runs hold exactly the pairs that exist)
           }
         }
       }
@@ -687,9 +709,8 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
       for (int u = 0; u < SCATTER_MLP; ++u) {
         if (q0 + u * SCATTER_NT < nsorted) {
           const int cb = (int)(it[u].w >> 16) - r0;
-          const unsigned rank = s_delta[cb] + (q0 + u * SCATTER_NT);
-          if (rank < coarse_capacity)
-            slabs[(size_t)(r0 + cb) * coarse_capacity + rank] = make_uint4(it[u].x, it[u].y, it[u].z, it[u].w & 0xffffu);
+          const unsigned at = s_delta[cb] + (q0 + u * SCATTER_NT);
+          if (at < csr_capacity) csr[at] = make_uint4(it[u].x, it[u].y, it[u].z, it[u].w & 0xffffu);
           else hdr[HDR_OVERFLOW] = 1ull;
         }
       }
@@ -839,22 +860,27 @@ __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__
                                unsigned coarse_capacity) {
   if (role == 1) { bin_base_scan(NCB, coarse_count, hdr); return; }   // second workgroup, concurrently
   __shared__ unsigned long long s_acc[SCAN_NT / 64];
-  unsigned long long nvis = 0, dref = 0, cmax = 0;
+  unsigned long long nvis = 0, dref = 0, cmax = 0, dmax = 0;
   for (int i = threadIdx.x; i < NB; i += SCAN_NT) { nvis += block_nvis[i]; dref += block_dref[i]; }
-  for (int i = threadIdx.x; i < NCB; i += SCAN_NT) cmax = max(cmax, (unsigned long long)coarse_count[(size_t)i * CC_STRIDE]);
-  for (int pass = 0; pass < 3; ++pass) {
-    unsigned long long v = pass == 0 ? nvis : pass == 1 ? dref : cmax;
+  for (int i = threadIdx.x; i < NCB; i += SCAN_NT) {
+    const uint2 c01 = *reinterpret_cast<const uint2*>(&coarse_count[(size_t)i * CC_STRIDE]);
+    const unsigned in_csr = coarse_count[(size_t)i * CC_STRIDE + 7];
+    cmax = max(cmax, (unsigned long long)c01.x);               // all items of the bin: what the sort route is chosen from
+    dmax = max(dmax, (unsigned long long)(c01.x - in_csr));    // the directly appended ones: what the slab has to hold
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    unsigned long long v = pass == 0 ? nvis : pass == 1 ? dref : pass == 2 ? cmax : dmax;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       const unsigned long long o = __shfl_xor(v, d);
-      v = pass == 2 ? max(v, o) : v + o;
+      v = pass >= 2 ? max(v, o) : v + o;
     }
     if (lane_id() == 0) s_acc[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
-      for (int w = 0; w < SCAN_NT / 64; ++w) t = pass == 2 ? max(t, s_acc[w]) : t + s_acc[w];
-      hdr[pass == 0 ? HDR_N_VIS : pass == 1 ? HDR_D_REF : HDR_MAX_COARSE] = t;
+      for (int w = 0; w < SCAN_NT / 64; ++w) t = pass >= 2 ? max(t, s_acc[w]) : t + s_acc[w];
+      hdr[pass == 0 ? HDR_N_VIS : pass == 1 ? HDR_D_REF : pass == 2 ? HDR_MAX_BIN_ITEMS : HDR_MAX_COARSE] = t;
     }
     __syncthreads();
   }
@@ -882,7 +908,7 @@ __device__ void plan_scan_role(int role, int NCB, int NB, uint32_t* __restrict__
     host_out[12] = feedback ? feedback[FB_MAX_LIST] : 0ull;
     host_out[13] = feedback ? feedback[FB_PREFILLED] : 0ull;
     host_out[14] = feedback ? feedback[FB_OVER_512] : 0ull;
-    host_out[15] = 0ull;
+    host_out[15] = hdr[HDR_MAX_BIN_ITEMS];
   }
 }
 
@@ -902,14 +928,15 @@ plan_scan_kernel(int NCB, int NB, uint32_t* __restrict__ coarse_count, const uin
 // every coarse item into its per-tile duplicates: items[slot] = (id, depth, dup index, 0).
 __global__ void __launch_bounds__(256)
 fine_bin_kernel(int TX8, int TY8, int CX, int NCB, const uint32_t* __restrict__ coarse_count,
-                const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long slot_capacity,
+                const uint4* __restrict__ csr, const uint4* __restrict__ slabs, unsigned coarse_capacity,
+                unsigned long long slot_capacity,
                 uint2* __restrict__ tile_range, uint4* __restrict__ items, uint32_t* __restrict__ long_tiles,
                 unsigned long long* __restrict__ hdr) {
   __shared__ unsigned cnt[COARSE_TILES];
   __shared__ unsigned long long s_base;
   const int cb = blockIdx.x, tid = threadIdx.x;
-  const unsigned n = min(coarse_count[(size_t)cb * CC_STRIDE], coarse_capacity);
-  const uint4* slab = slabs + (size_t)cb * coarse_capacity;
+  const BinItems slab = bin_items(coarse_count + (size_t)cb * CC_STRIDE, csr, slabs, (size_t)cb, coarse_capacity);
+  const unsigned n = slab.n;
   if (tid < COARSE_TILES) cnt[tid] = 0;
   __syncthreads();
   // the bin's coarse items are read ONCE, all loads of a thread in flight together (the kernel is latency-bound: one
@@ -1270,7 +1297,8 @@ __device__ __forceinline__ void wave_radix_sort_lds(SelectSortLds<SS_CAP>& lds, 
 template <int SS_CAP>
 __global__ void __launch_bounds__(256)
 select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coarse_count,
-                   const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long slot_capacity,
+                   const uint4* __restrict__ csr, const uint4* __restrict__ slabs, unsigned coarse_capacity,
+                   unsigned long long slot_capacity,
                    uint2* __restrict__ tile_range, uint4* __restrict__ items, uint32_t* __restrict__ long_tiles,
                    unsigned long long* __restrict__ hdr, uint32_t* __restrict__ sorted_id,
                    uint32_t* __restrict__ sorted_dup) {
@@ -1286,9 +1314,9 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
   const int t = ty * TX8 + tx;
   const int bit = q * COARSE + wave;                 // this tile's bit of the coarse items' masks
   uint32_t* line = coarse_count + (size_t)cb * CC_STRIDE;
-  const unsigned n = min(line[0], coarse_capacity);
+  const BinItems slab = bin_items(line, csr, slabs, (size_t)cb, coarse_capacity);
+  const unsigned n = slab.n;
   if (n == 0) { if (lane == 0 && tx < TX8) tile_range[t] = make_uint2(0u, 0u); return; }   // uniform per workgroup
-  const uint4* slab = slabs + (size_t)cb * coarse_capacity;
   SelectSortLds<SS_CAP>& lds = lds_all[wave];
   // ---- scan: the workgroup reads the slab ONCE (R items per thread and round trip, unconditional loads from clamped
   // indices) and hands every item to the lists of the row's tiles it touches. Positions come from LDS atomics: the order
@@ -2092,7 +2120,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                bins_bytes_plan(dup_capacity, NCB, coarse_capacity, N));
   SFGS_REQUIRE(bins, SFGS_E_ARG, "bins blob is NULL");
   const GeomView gv = geom_view(geom, N);
-  const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
+  const BinsView bv = bins_view_csr(bins, dup_capacity, NCB, coarse_capacity, N);
   const KFrame kf = make_kframe(frame);
   const int NB = (int)pre_blocks(N);
   SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
@@ -2143,11 +2171,12 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                            gv.block_items, tv.sc_cnt, tv.sc_hits); }
       { ProfScope ps_(KID_BIN_RANK, stream);
         hipLaunchKernelGGL(bin_rank_kernel, dim3(((int)NCB + RANK_COLS - 1) / RANK_COLS), dim3(RANK_COLS * RANK_GROUPS), 0,
-                           stream, NWG, (int)NCB, tv.sc_cnt, tv.sc_hits, tv.sc_base, tv.coarse_count); }
+                           stream, NWG, (int)NCB, tv.sc_cnt, tv.sc_hits, tv.sc_base, tv.coarse_count, tv.hdr); }
       plan_roles = plan_scan_separate() ? 0 : 2;
       { ProfScope ps_(KID_BIN_SCATTER, stream);
         hipLaunchKernelGGL(bin_scatter_kernel, dim3(NWG + plan_roles), dim3(SCATTER_NT), 0, stream, NB, (int)NCB, bv.pairs,
-                           gv.block_items, tv.sc_cnt, tv.sc_base, bv.slabs, (unsigned)coarse_capacity, tv.hdr, plan_roles,
+                           gv.block_items, tv.sc_cnt, tv.sc_base, bv.csr,
+                           (unsigned)std::min<size_t>(pairs_bytes(N) / 16, 0xffffffffull), (unsigned)coarse_capacity, tv.hdr, plan_roles,
                            tv.coarse_count, tv.block_nvis, tv.block_dref, (const unsigned long long*)frame->feedback,
                            (const unsigned long long*)tv.dup_pool, (unsigned long long*)counters_pinned_host); }
     }
@@ -2179,15 +2208,17 @@ struct MergeParts {
 
 __global__ void __launch_bounds__(256)
 plan_export_kernel(int N, int NCB, const float4* __restrict__ rec, const uint32_t* __restrict__ coarse_count,
-                   const uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned export_capacity,
-                   float4* __restrict__ rec_out, uint32_t* __restrict__ count_out, uint4* __restrict__ items_out) {
+                   const uint4* __restrict__ csr, const uint4* __restrict__ slabs, unsigned coarse_capacity,
+                   unsigned export_capacity, float4* __restrict__ rec_out, uint32_t* __restrict__ count_out,
+                   uint4* __restrict__ items_out) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
   for (size_t i = t; i < (size_t)N * 3; i += nthreads) rec_out[i] = rec[(i / 3) * REC_F4 + i % 3];
   for (size_t cb = t; cb < (size_t)NCB; cb += nthreads)
-    count_out[cb] = min(min(coarse_count[cb * CC_STRIDE], coarse_capacity), export_capacity);
+    count_out[cb] = min(bin_items(coarse_count + cb * CC_STRIDE, csr, slabs, cb, coarse_capacity).n, export_capacity);
   for (size_t i = t; i < (size_t)NCB * export_capacity; i += nthreads) {
     const size_t cb = i / export_capacity, k = i % export_capacity;
-    if (k < min(coarse_count[cb * CC_STRIDE], coarse_capacity)) items_out[i] = slabs[cb * coarse_capacity + k];
+    const BinItems b = bin_items(coarse_count + cb * CC_STRIDE, csr, slabs, cb, coarse_capacity);
+    if (k < b.n) items_out[i] = b[(unsigned)k];
   }
 }
 
@@ -2241,9 +2272,9 @@ extern "C" int sfgs_raster_plan_export(const SfgsFrame* frame, int32_t N, const 
   const int64_t NCB = coarse_bins(W, H);
   const TilesView tv = tiles_view(const_cast<void*>(tiles), W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
-  const BinsView bv = bins_view(const_cast<void*>(bins), dup_capacity, NCB, coarse_capacity);
+  const BinsView bv = bins_view_csr(const_cast<void*>(bins), dup_capacity, NCB, coarse_capacity, N);
   hipLaunchKernelGGL(plan_export_kernel, dim3(2048), dim3(256), 0, stream, (int)N, (int)NCB, gv.rec, tv.coarse_count,
-                     bv.slabs, (unsigned)coarse_capacity, (unsigned)export_capacity, (float4*)rec_out, count_out,
+                     bv.csr, bv.slabs, (unsigned)coarse_capacity, (unsigned)export_capacity, (float4*)rec_out, count_out,
                      (uint4*)items_out);
   SFGS_POST_LAUNCH("plan_export", stream, frame->debug);
   return SFGS_OK;
@@ -2303,6 +2334,7 @@ static void unpack_counters(const unsigned long long* h, SfgsRasterCounters* out
   out->max_tile_list = (int64_t)h[HDR_MAX_LIST];
   out->overflow = (int64_t)h[HDR_OVERFLOW];
   out->max_coarse_bin = (int64_t)h[HDR_MAX_COARSE];
+  out->max_bin_items = (int64_t)h[HDR_MAX_BIN_ITEMS];
   out->num_huge_splats = (int64_t)h[HDR_BIG_COUNT];
   out->num_big_chunks = (int64_t)h[HDR_BIG_CHUNKS];
   out->prev_valid = out->prev_long_tiles = out->prev_max_tile_list = out->prev_prefilled = out->prev_tiles_over_512 = 0;
@@ -2322,6 +2354,7 @@ extern "C" int sfgs_raster_counters_decode(const void* host_128, SfgsRasterCount
   out->prev_max_tile_list = (int64_t)h[12];
   out->prev_prefilled = (int64_t)h[13];
   out->prev_tiles_over_512 = (int64_t)h[14];
+  out->max_bin_items = (int64_t)h[15];
   return SFGS_OK;
 }
 
@@ -2368,7 +2401,7 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   SFGS_REQUIRE(image == nullptr || image_sz >= image_bytes(W, H, dup_capacity), SFGS_E_CAPACITY, "image blob too small");
   const TilesView tv = tiles_view(tiles, W, H, N, nullptr);
   const GeomView gv = geom_view(const_cast<void*>(geom), N);
-  const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
+  const BinsView bv = bins_view_csr(bins, dup_capacity, NCB, coarse_capacity, N);
   const KFrame kf = make_kframe(frame);
   const int TX8 = tiles8_x(W), TY8 = tiles8_y(H), T8 = TX8 * TY8, CX = coarse_x(W);
   // Two routes to the sorted per-tile lists (bit-identical results): select_sort_kernel (no per-tile items in memory, one
@@ -2380,20 +2413,20 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
     { ProfScope ps_(KID_SORT_SMALL, stream);
       if (fused_cap > 512)
         hipLaunchKernelGGL(select_sort_kernel<1024>, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX,
-                           (int)NCB, tv.coarse_count, bv.slabs, (unsigned)coarse_capacity,
+                           (int)NCB, tv.coarse_count, bv.csr, bv.slabs, (unsigned)coarse_capacity,
                            (unsigned long long)dup_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id,
                            bv.sorted_dup);
       else
         hipLaunchKernelGGL(select_sort_kernel<512>, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX,
-                           (int)NCB, tv.coarse_count, bv.slabs, (unsigned)coarse_capacity,
+                           (int)NCB, tv.coarse_count, bv.csr, bv.slabs, (unsigned)coarse_capacity,
                            (unsigned long long)dup_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id,
                            bv.sorted_dup); }
     SFGS_POST_LAUNCH("select_sort", stream, frame->debug);
   } else {
     { ProfScope ps_(KID_FINE_BIN, stream);
       hipLaunchKernelGGL(fine_bin_kernel, dim3((unsigned)NCB), dim3(256), 0, stream, TX8, TY8, CX, (int)NCB,
-                         tv.coarse_count, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.tile_range,
-                         bv.items, tv.long_tiles, tv.hdr); }
+                         tv.coarse_count, bv.csr, bv.slabs, (unsigned)coarse_capacity, (unsigned long long)dup_capacity,
+                         tv.tile_range, bv.items, tv.long_tiles, tv.hdr); }
     SFGS_POST_LAUNCH("fine_bin", stream, frame->debug);
   }
   if (num_duplicates != 0) {  // < 0: unknown (render enqueued before the counters were read)

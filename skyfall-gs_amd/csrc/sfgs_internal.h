@@ -114,12 +114,15 @@ enum HeaderSlot {
   HDR_OVERFLOW = 4,   // set by preprocess when dup_capacity / coarse_capacity is too small (redo the plan)
   HDR_SUBPIX_BOUND = 5,  // float bits of max |subpixel_offset| (0 when none)
   HDR_ITEM_ALLOC = 6,    // list slots the coarse bins' lists can take at most (total of the plan's per-bin bases)
-  HDR_MAX_COARSE = 7,    // fullest coarse bin (sizes coarse_capacity for the next frame)
+  HDR_MAX_COARSE = 7,    // fullest coarse-bin SLAB: the most items appended directly to one bin (splats of more than BIG_WALK
+                         // bins; one-pass binning) -- what coarse_capacity has to hold; the two-pass items live in BinsView::csr
   HDR_LONG_COUNT = 8,    // tiles whose list is too long for the register sort (> 512 entries)
   HDR_BIG_CHUNKS = 9,    // entries of BinsView::big_chunks (1024-record chunks of Gaussians with > BWD_BIG duplicates)
   HDR_BIG_COUNT = 10,    // entries of GeomView::big_list (splats whose binning walk is done by big_walk_kernel)
-  HDR_PREFILLED = 11     // backward: 1 when dupgrad_prefill_kernel zeroed the whole record array (composite_bwd then
+  HDR_PREFILLED = 11,    // backward: 1 when dupgrad_prefill_kernel zeroed the whole record array (composite_bwd then
                          // skips the entries behind a tile's last contributor), else 0
+  HDR_CSR_CURSOR = 12,   // two-pass binning: items handed out of BinsView::csr so far (bin_rank_kernel: one atomic per 16 bins)
+  HDR_MAX_BIN_ITEMS = 13 // fullest coarse bin counting ALL its items (slab + csr run): what the sort route is chosen from
 };
 
 // float4s per compositing record in global memory: 3 = packed 48-byte records; 4 = 64-byte stride (the fourth is never
@@ -185,7 +188,9 @@ struct TilesView {
                             //   counter), word 2 = the bin's first list slot (scanned by the plan from the hits)
                             //   word 3 = slots handed out to the bin's tiles so far (select_sort_kernel: one atomic
                             //   per tile), word 4 = the bin's longest tile list (reduced by list_stats), word 5 = the bin's
-                            //   tiles with more than 512 entries (select_sort_kernel<1024>; summed by list_stats)
+                            //   tiles with more than 512 entries (select_sort_kernel<1024>; summed by list_stats),
+                            //   word 6 = first item of the bin's run in BinsView::csr, word 7 = items of that run (two-pass
+                            //   binning, bin_rank_kernel; word 0 counts them too: word 0 - word 7 items sit in the bin's slab)
   uint2* tile_range;        // [T8] (first list slot, list length) of every 8x8 tile
   uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]
@@ -237,6 +242,13 @@ static inline size_t big_chunk_capacity(int64_t D) { return (size_t)(D / 512 + 6
 
 struct BinsView {
   uint4* slabs;          // [NCB][coarse_capacity] coarse items (Gaussian id, depth bits, first dup index, 16-bit tile mask)
+                         //     appended DIRECTLY, with a device atomic per item: those of the splats reaching more than
+                         //     BIG_WALK coarse bins (walked by a whole wave: preprocess_kernel / big_walk_kernel), every item of
+                         //     the one-pass binning, a merged plan's. The two-pass binning's items are in `csr`.
+  uint4* csr;            // two-pass binning: the coarse items sorted by bin, every bin's run contiguous and exactly sized
+                         //     (coarse_count words 6, 7) -- no per-bin capacity, memory in proportion to the items. Behind
+                         //     everything else in the blob (bins_view_csr: only the plan / render / export stages, which know
+                         //     N, use it); capacity = the pair list's = PAIRS_PER_BLOCK per preprocess workgroup
   uint2* big_chunks;     // [D / 512 + 64] (Gaussian id, chunk index) of the chunks described above
   uint4* items;          // [D] per-tile segments, unsorted: (Gaussian id, depth bits, dup index, 0)
   uint32_t* sorted_id;   // [D] per-tile lists of Gaussian ids, front to back
@@ -253,10 +265,14 @@ static inline size_t bins_bytes(int64_t D, int64_t NCB, int64_t coarse_cap) {
          align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
 }
 // the plan of N Gaussians (and therefore what sfgs_raster_sizes / sfgs_raster_scratch_layout report): room for the pair list
-static inline size_t bins_bytes_plan(int64_t D, int64_t NCB, int64_t coarse_cap, int64_t N) {
+// ... with the binning's arrays: the pair list (on top of the lists) and, behind both, the bin-sorted items (BinsView::csr)
+static inline size_t bins_csr_offset(int64_t D, int64_t NCB, int64_t coarse_cap, int64_t N) {
   const size_t lists = align_up((size_t)D * 16, 256) + 2 * align_up((size_t)D * 4, 256);
   return align_up((size_t)NCB * coarse_cap * 16, 256) + align_up(big_chunk_capacity(D) * 8, 256) +
          (lists > pairs_bytes(N) ? lists : pairs_bytes(N));
+}
+static inline size_t bins_bytes_plan(int64_t D, int64_t NCB, int64_t coarse_cap, int64_t N) {
+  return bins_csr_offset(D, NCB, coarse_cap, N) + pairs_bytes(N);
 }
 static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coarse_cap) {
   BinsView b;
@@ -267,8 +283,36 @@ static inline BinsView bins_view(void* base, int64_t D, int64_t NCB, int64_t coa
   b.sorted_id = (uint32_t*)p; p += align_up((size_t)D * 4, 256);
   b.sorted_dup = (uint32_t*)p;
   b.pairs = b.items;
+  b.csr = nullptr;
   return b;
 }
+// the view of the stages that know N (plan, render, export): with the bin-sorted item array
+static inline BinsView bins_view_csr(void* base, int64_t D, int64_t NCB, int64_t coarse_cap, int64_t N) {
+  BinsView b = bins_view(base, D, NCB, coarse_cap);
+  b.csr = (uint4*)((char*)base + bins_csr_offset(D, NCB, coarse_cap, N));
+  return b;
+}
+
+#ifdef __HIPCC__
+// A coarse bin's items as its consumers see them: the run in BinsView::csr first (two-pass binning), then what was appended
+// directly to the bin's slab (clamped to the slab's capacity: an overflowing plan is flagged, never read past).
+struct BinItems {
+  const uint4* csr;   // items 0 .. nc-1
+  const uint4* uni;   // items nc .. n-1, addressed uni[i] (the pointer is pre-shifted by -nc)
+  unsigned nc, n;
+  __device__ __forceinline__ uint4 operator[](unsigned i) const { return *(i < nc ? csr + i : uni + i); }
+};
+__device__ __forceinline__ BinItems bin_items(const uint32_t* __restrict__ line, const uint4* __restrict__ csr,
+                                              const uint4* __restrict__ slabs, size_t cb, unsigned coarse_capacity) {
+  BinItems b;
+  b.nc = csr ? line[7] : 0u;
+  const unsigned direct = line[0] - b.nc;
+  b.n = b.nc + (direct < coarse_capacity ? direct : coarse_capacity);
+  b.csr = csr + line[6];
+  b.uni = slabs + cb * (size_t)coarse_capacity - b.nc;
+  return b;
+}
+#endif
 
 constexpr int LIST_ALIGN = 64;  // every tile list starts on a multiple of 64 slots (fine_bin_kernel)
 

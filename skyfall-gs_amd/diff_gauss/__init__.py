@@ -78,6 +78,11 @@ def _hints_on():
     return os.environ.get("SFGS_HINTS", "1") != "0"
 
 
+def _binning_direct():
+    import os
+    return os.environ.get("SFGS_BINNING", "") == "direct"
+
+
 def _medium_on():
     import os
     return os.environ.get("SFGS_MEDIUM_LISTS", "1") != "0"   # A/B switch: 0 = frames with lists of 513 .. 1 024 take the split route
@@ -294,7 +299,10 @@ class _Rasterize(torch.autograd.Function):
             over, ncb = _layout(lib, N, W, H, 0, 0, False)[2:4]    # list-slot overhead: every tile list is 64-slot aligned
             ncb = max(ncb, 1)
             cap = max(hint[0], 4 * N + over)
-            ccap = max(hint[1], 8 * N // ncb, 256)
+            # coarse_capacity holds only the items appended DIRECTLY to a coarse bin's slab -- those of splats reaching more
+            # than 6 coarse bins, none in most frames -- since the two-pass binning stores its items bin-sorted and exactly
+            # sized (ABI 14); with one-pass binning (images beyond 65 536 coarse bins, SFGS_BINNING=direct) every item goes there
+            ccap = max(hint[1], 8 * N // ncb if (ncb > 65536 or _binning_direct()) else 0, 256)
             # few, large allocations: the Python time before the first launch is GPU idle time
             # band rendering (tile_rows extension) leaves the pixels outside the band untouched: start from zeros there
             outs = (torch.zeros if band else torch.empty)(5, H, W, dtype=torch.float32, device=dev)
@@ -372,14 +380,15 @@ class _Rasterize(torch.autograd.Function):
                     if hs["prefill_ran"]:
                         hs["prefilled"] = int(cnt.prev_prefilled)
                 hs["huge"] = int(cnt.num_huge_splats)
-                hs["cmax"] = cmax
+                hs["cmax"] = int(cnt.max_bin_items)
                 hs["prefill_ran"] = False
             _cap_hint[(di, W, H)] = (cap if pool_grown else
                                      max(int(D * 1.25) + 1024 + over, min(cap, 2 * D + 1024 + over)),
                                      max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
             global _last_counters
             _last_counters = dict(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
-                                  num_visible=int(cnt.num_visible), max_coarse_bin=cmax,
+                                  num_visible=int(cnt.num_visible), max_coarse_bin=cmax, max_bin_items=int(cnt.max_bin_items),
+                                  num_huge_splats=int(cnt.num_huge_splats),
                                   max_tile_list=int(cnt.max_tile_list), N=N, W=W, H=H, dup_capacity=cap,
                                   coarse_capacity=ccap, fwd_hints=int(fwd_hints))   # published by reference assignment (atomic)
         finally:

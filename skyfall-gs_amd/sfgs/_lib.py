@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -73,7 +73,7 @@ class SfgsRasterCounters(C.Structure):
                 ("max_tile_list", C.c_int64), ("overflow", C.c_int64), ("max_coarse_bin", C.c_int64),
                 ("num_huge_splats", C.c_int64), ("num_big_chunks", C.c_int64), ("prev_valid", C.c_int64),
                 ("prev_long_tiles", C.c_int64), ("prev_max_tile_list", C.c_int64), ("prev_prefilled", C.c_int64),
-                ("prev_tiles_over_512", C.c_int64)]
+                ("prev_tiles_over_512", C.c_int64), ("max_bin_items", C.c_int64)]
 
 
 # every symbol include/sfgs.h declares: name -> (restype, argtypes)

@@ -341,7 +341,9 @@ def plan_export(settings, inputs, export_capacity=None):
         L.check(lib.sfgs_raster_sizes(N, W, H, 0, 0, L.C.byref(sizes)))
         ncb = max(int(sizes.coarse_bins), 1)
         cap = int(lib.sfgs_raster_slot_capacity(W, H, 4 * N))
-        ccap = max(8 * N // ncb, 256)
+        # (coarse_capacity: room of a coarse bin's SLAB, i.e. for the huge splats' items only since ABI 14 -- every item with
+        # one-pass binning)
+        ccap = max(8 * N // ncb if (ncb > 65536 or dg._binning_direct()) else 0, 256)
         radii = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
         while True:
             L.check(lib.sfgs_raster_sizes(N, W, H, cap, ccap, L.C.byref(sizes)))
@@ -361,6 +363,7 @@ def plan_export(settings, inputs, export_capacity=None):
             if (new_cap, new_ccap) == (cap, ccap):
                 new_cap = cap * 2        # a duplicate-index pool ran over although the total fits: more room per pool
             cap, ccap = new_cap, new_ccap
+        cmax = max(cmax, int(cnt.max_bin_items))      # the export carries ALL items of a bin (slab + bin-sorted run)
         if export_capacity is None:
             export_capacity = _agree_max(max(cmax, 1), dev)
         C = int(export_capacity)

@@ -49,6 +49,9 @@ CASES = {
 BINNING_CASES = {
     "uhd_two_bin_rounds": dict(n=30000, W=3840, H=2160, kw=dict(zrange=(250., 350.), scale_range=(0.1, 1.2))),
     "mid_splats_many_items": dict(n=20000, W=640, H=360, kw=dict(zrange=(40., 60.), scale_range=(0.3, 0.7), opacity_range=(0.02, 0.2))),
+    # a distant view: the whole scene inside a handful of the frame's 2 040 coarse bins
+    "skewed_far_view": dict(n=60000, W=1920, H=1080, kw=dict(zrange=(250., 350.), scale_range=(0.05, 0.4), xy_fill=0.04,
+                                                              opacity_range=(0.02, 0.3))),
 }
 
 
@@ -357,7 +360,7 @@ def test_skewed_workgroups_and_the_duplicate_index_pools():
 
 
 @pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p", "uhd_two_bin_rounds",
-                                  "mid_splats_many_items"])
+                                  "mid_splats_many_items", "skewed_far_view"])
 def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
     """Two-pass binning (pair list + bin_scatter_kernel, the default) and the one-pass path with one device atomic per
     coarse item (SFGS_BINNING=direct) build the same frame: duplicate indices come from the same scan and every tile list
@@ -370,10 +373,37 @@ def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
     b = run_hip(frame, g, gc, gd)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    for k in ("num_duplicates", "num_duplicates_ref", "num_visible", "max_coarse_bin", "max_tile_list"):
+    for k in ("num_duplicates", "num_duplicates_ref", "num_visible", "max_bin_items", "max_tile_list"):
         assert a["counters"][k] == b["counters"][k], k
+    # ABI 14: the two-pass binning stores its items bin-sorted and exactly sized; only directly appended items (those of
+    # splats reaching more than 6 coarse bins) count towards coarse_capacity -- every item on the one-pass path
+    assert b["counters"]["max_coarse_bin"] == b["counters"]["max_bin_items"]
+    assert a["counters"]["max_coarse_bin"] <= a["counters"]["max_bin_items"]
+    if case in ("cfg2_like", "skewed_far_view"):     # small splats only
+        assert a["counters"]["max_coarse_bin"] == 0
     for k in a["grads"]:
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
+
+
+def test_a_skewed_frame_needs_no_per_bin_capacity():
+    """ABI 14: the two-pass binning's items are stored bin-sorted and EXACTLY sized, so a distant view -- every Gaussian in
+    a handful of coarse bins -- plans in one attempt with the minimal slab capacity and a scratch in proportion to the
+    items. (Until ABI 13 the bins were uniform slabs sized for the fullest one: this frame, 60 000 Gaussians at 1080p,
+    took 2 040 x ~15 000 x 16 bytes = 0.5 GB of slabs after two overflowing attempts; 2 M Gaussians seen from afar 65 GB.)"""
+    import diff_gauss
+    c = BINNING_CASES["skewed_far_view"]
+    frame, g = scene(c["n"], c["W"], c["H"], seed=11, **c["kw"])
+    diff_gauss._cap_hint.clear()
+    out = run_hip(frame, g, backward=False)
+    cnt = out["counters"]
+    assert cnt["max_bin_items"] > 5000 and cnt["num_huge_splats"] == 0      # skewed indeed
+    assert cnt["max_coarse_bin"] == 0 and cnt["coarse_capacity"] == 256      # nothing needs a slab
+    import ctypes as C
+    from sfgs import _lib as L
+    lib = L.load()
+    lay = L.SfgsScratchLayout(C.sizeof(L.SfgsScratchLayout))
+    L.check(lib.sfgs_raster_scratch_layout(c["n"], c["W"], c["H"], cnt["dup_capacity"], cnt["coarse_capacity"], 0, C.byref(lay)))
+    assert int(lay.total_bytes) < 128 << 20    # (of which ~55 MB is list-slot index space: 1 088 slots per coarse bin)
 
 
 @pytest.mark.parametrize("route", ["fused", "fused1024"])
@@ -396,7 +426,7 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, monkeypatch):
     b = run_hip(frame, g, gc, gd)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    for k in ("num_duplicates", "num_duplicates_ref", "num_visible", "max_coarse_bin", "max_tile_list"):
+    for k in ("num_duplicates", "num_duplicates_ref", "num_visible", "max_coarse_bin", "max_bin_items", "max_tile_list"):
         assert a["counters"][k] == b["counters"][k], k
     for k in a["grads"]:
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)

@@ -22,6 +22,8 @@ from sfgs.synth import scene  # noqa: E402
 
 N, W, H = int(os.environ.get("N", 2_000_000)), 1920, 1080
 frame, g = scene(N, W, H, seed=0, mode="sh", sh_degree=1)
+# the reference's Camera keeps its matrices on the GPU (scene/cameras.py:62-72): render()'s `.cuda()` calls are no-ops
+frame = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in frame.items()}
 gen = torch.Generator().manual_seed(5)
 filter_3D = torch.exp(torch.randn(N, 1, generator=gen, dtype=torch.float64) * 0.5 - 1.0)
 gt = torch.rand(3, H, W, generator=gen).cuda()
