@@ -902,7 +902,10 @@ struct DupAcc {
 // gradients (what sfgs_prepass_backward would make of this kernel's non-raw outputs: the same functions, act_math.h).
 // CM != 0 (SfgsGaussians.sh_dirs): the view direction is given per Gaussian and its gradient goes to g_sh_dirs instead of
 // into g_means3D; CM == 1: coefficients and their gradients channel-major [N,3,K], CM == 2: [N,K,3].
-template <int K, int DEG, bool RAW, int CM>
+// CMX = CM, or CM + 3 for SPLIT SH STORAGE (SfgsGaussians.shs_rest; CM 0 or 2): an instantiation of its own, because a
+// run-time choice between the unsplit row's twelve 16-byte accesses and the split rows' 12-byte ones costs the UNSPLIT path
+// 10 - 20 % at 16 coefficients (profiles/r4_split_sh_rows_ab.txt).
+template <int K, int DEG, bool RAW, int CMX>
 __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
@@ -913,6 +916,9 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
                       float* __restrict__ g_rots, void* __restrict__ g_opac_, float* __restrict__ g_colors,
                       float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_sh_dirs) {
+  constexpr bool SPLIT = CMX >= 3;
+  constexpr int CM = SPLIT ? CMX - 3 : CMX;
+  static_assert(!SPLIT || (K > 1 && CM != 1), "split SH storage: more than one coefficient, coefficient-major");
   constexpr int PB_CHUNK = 128;   // records per staging chunk and wave: 6 KB of LDS
   static_assert((PB_CHUNK * DG_F4) % 64 == 0, "whole load rounds");
   __shared__ float4 pb_stage[PRE_BLOCK / 64][PB_CHUNK * DG_F4];
@@ -1026,16 +1032,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     const float q[4] = {qv.x, qv.y, qv.z, qv.w};
     if constexpr (K > 0) {
       float shl[ROW];
-      if constexpr (K > 1) {
-        if (shs_rest) {   // split storage: coefficient 0 in `shs`, the others in `shs_rest` (SfgsGaussians.shs_rest)
-          load3(shs + 3 * (size_t)g, reinterpret_cast<float(&)[3]>(shl[0]));
-          load_row<ROW - 3>(shs_rest + (size_t)(ROW - 3) * g, reinterpret_cast<float(&)[ROW - 3]>(shl[3]));
-        } else {
-          load_row<ROW>(shs + (size_t)ROW * g, shl);
-        }
-      } else {
-        load_row<ROW>(shs + (size_t)ROW * g, shl);
-      }
+      if constexpr (SPLIT) load_sh_rows<K>(shs, shs_rest, (size_t)g, shl);   // coefficient 0 in `shs`, the others in `shs_rest`
+      else load_row<ROW>(shs + (size_t)ROW * g, shl);
       if constexpr (CM != 0) {
         float din[3];
         load3(sh_dirs + 3 * (size_t)g, din);
@@ -1069,16 +1067,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   *reinterpret_cast<float4*>(g_rots + 4 * (size_t)g) = make_float4(out.rot[0], out.rot[1], out.rot[2], out.rot[3]);
   if constexpr (!RAW) static_cast<float*>(g_opac_)[g] = out.opacity;
   if constexpr (K > 0) {
-    if constexpr (K > 1) {
-      if (g_shs_rest) {
-        store3(g_shs + 3 * (size_t)g, gshl[0], gshl[1], gshl[2]);
-        store_row<ROW - 3>(g_shs_rest + (size_t)(ROW - 3) * g, reinterpret_cast<const float(&)[ROW - 3]>(gshl[3]));
-      } else {
-        store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
-      }
-    } else {
-      store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
-    }
+    if constexpr (SPLIT) store_sh_rows<K>(g_shs, g_shs_rest, (size_t)g, gshl);
+    else store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
     if constexpr (CM != 0) store3(g_sh_dirs + 3 * (size_t)g, gdir[0], gdir[1], gdir[2]);
   } else {
     store3(g_colors + 3 * (size_t)g, out.rgb[0], out.rgb[1], out.rgb[2]);
@@ -1168,6 +1158,10 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                      grads->shs_rest, grads->sh_dirs)
 #define SFGS_LAUNCH_PBWD(K, D)                                                                                         \
   do {                                                                                                                 \
+    if constexpr ((K) > 1) {   /* split SH storage (shs_rest): instantiations of their own (CMX = CM + 3) */            \
+      if (g->shs_rest && g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 5); else SFGS_LAUNCH_PBWD_(K, D, false, 5); break; } \
+      if (g->shs_rest) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 3); else SFGS_LAUNCH_PBWD_(K, D, false, 3); break; } \
+    }                                                                                                                  \
     if constexpr ((K) > 0) {                                                                                           \
       if (g->sh_dirs && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 1); else SFGS_LAUNCH_PBWD_(K, D, false, 1); break; } \
       if (g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 2); else SFGS_LAUNCH_PBWD_(K, D, false, 2); break; } \

@@ -203,16 +203,10 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         rgb[0] = rgb_in[0]; rgb[1] = rgb_in[1]; rgb[2] = rgb_in[2];
       } else {
         float shl[3 * K];
-        if constexpr (K > 1) {
-          if (shs_rest) {   // split storage (SfgsGaussians.shs_rest): coefficient 0 and coefficients 1 .. K-1 in two arrays
-            load3(shs + 3 * (size_t)g, reinterpret_cast<float(&)[3]>(shl[0]));
-            load_row<3 * K - 3>(shs_rest + (3 * (size_t)K - 3) * g, reinterpret_cast<float(&)[3 * K - 3]>(shl[3]));
-          } else {
-            load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
-          }
-        } else {
-          load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
-        }
+        // coefficient-major rows: K 12-byte loads from one array or, split storage (SfgsGaussians.shs_rest), from two --
+        // the same instructions either way (load_sh_rows); the channel-major form [N,3,K] reads its 3 K floats as they lie
+        if constexpr (K > 1 && CM != 1) load_sh_rows<K>(shs, shs_rest, (size_t)g, shl);
+        else load_row<3 * K>(shs + 3 * (size_t)K * g, shl);
         unsigned cm; float dir[3], len;
         if constexpr (CM != 0) {
           float din[3];

@@ -460,6 +460,30 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
   }
 }
 
+// A Gaussian's K coefficient rows (coefficient-major: 3 floats per coefficient) from ONE array [N,K,3] or, split storage
+// (SfgsGaussians.shs_rest), coefficient 0 from `first` [N,1,3] and the others from `rest` [N,K-1,3]: the same K 12-byte
+// accesses either way -- only two wave-uniform base pointers differ, no branch. preprocess uses this form for both
+// layouts; preprocess_bwd only in its split instantiations (a branch between the float4-grouped and the 3-float-grouped
+// form of the row cost its UNSPLIT path 20 % at 16 coefficients, this form 10 %: profiles/r4_split_sh_rows_ab.txt).
+template <int K>
+__device__ __forceinline__ void load_sh_rows(const float* __restrict__ first, const float* __restrict__ rest, size_t g,
+                                             float (&dst)[3 * K]) {
+  const float* r0 = first + (rest ? 3 : 3 * K) * g;
+  const float* rk = rest ? rest + (size_t)(3 * K - 3) * g - 3 : r0;
+  load3(r0, reinterpret_cast<float(&)[3]>(dst[0]));
+#pragma unroll
+  for (int k = 1; k < K; ++k) load3(rk + 3 * k, reinterpret_cast<float(&)[3]>(dst[3 * k]));
+}
+template <int K>
+__device__ __forceinline__ void store_sh_rows(float* __restrict__ first, float* __restrict__ rest, size_t g,
+                                              const float (&src)[3 * K]) {
+  float* r0 = first + (rest ? 3 : 3 * K) * g;
+  float* rk = rest ? rest + (size_t)(3 * K - 3) * g - 3 : r0;
+  store3(r0, src[0], src[1], src[2]);
+#pragma unroll
+  for (int k = 1; k < K; ++k) store3(rk + 3 * k, src[3 * k], src[3 * k + 1], src[3 * k + 2]);
+}
+
 // Launch `KERNEL<K, DEG>` for the runtime (sh_coeffs, sh_degree) pair; K = 0 is the colors_precomp path.
 #define SFGS_DISPATCH_SH(K_RT, DEG_RT, LAUNCH)                                   \
   do {                                                                           \
