@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 14
+#define SFGS_ABI_VERSION 15
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -149,6 +149,14 @@ typedef struct SfgsGaussians {
    * arrays, the backward writes SfgsGaussianGrads.shs ([N,1,3]) and .shs_rest: no concatenated copy, no split of its
    * gradient. Needs sh_coeffs > 1 and shs_channel_major == 0; with or without sh_dirs. */
   const float* shs_rest;         /* [N,sh_coeffs-1,3] or NULL = `shs` holds all sh_coeffs coefficients */
+  /* DIRECTIONS FROM CENTRES (ABI 15). render()'s Python colour paths compute eval_sh's `dirs` as
+   *     dir_pp = xyz - camera_center.repeat(N, 1);  dirs = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+   * (gaussian_renderer/__init__.py:114-115, :122-123): six elementwise / reduction launches and eight more on the way
+   * back. sh_centers, an alternative to sh_dirs, hands over the subtrahend ([N,3], as render() built it -- any values)
+   * instead of the finished directions: preprocess evaluates normalize(means3D - sh_centers) itself (the float sequence
+   * of the in-kernel SH path's normalize(means3D - campos)) and preprocess_bwd adds the direction's gradient to
+   * grads.means3D; grads.sh_dirs stays NULL. Everything else as with sh_dirs (shs layout, shs_channel_major, shs_rest). */
+  const float* sh_centers;       /* [N,3] or NULL */
 } SfgsGaussians;
 
 /* Gradient outputs of the backward pass (all device, float32, fully overwritten). */
@@ -162,7 +170,7 @@ typedef struct SfgsGaussianGrads {
   float* opacities;      /* [N,1]; raw-parameter mode with raw_f64_mask bit 1: [N,1] float64 (cast the pointer) */
   float* colors_precomp; /* [N,3] or NULL */
   float* shs;            /* [N,sh_coeffs,3] or NULL ([N,3,sh_coeffs] with SfgsGaussians.shs_channel_major) */
-  float* sh_dirs;        /* [N,3]; non-NULL exactly when SfgsGaussians.sh_dirs is */
+  float* sh_dirs;        /* [N,3]; non-NULL exactly when SfgsGaussians.sh_dirs is (NULL with sh_centers) */
   float* shs_rest;       /* [N,sh_coeffs-1,3]; non-NULL exactly when SfgsGaussians.shs_rest is (`shs` is then [N,1,3]) */
 } SfgsGaussianGrads;
 

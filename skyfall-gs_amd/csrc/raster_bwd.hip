@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(PRE_BLOCK)
 preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
                       int raw_mask, const float* __restrict__ shs, const float* __restrict__ shs_rest,
-                      const float* __restrict__ sh_dirs,
+                      const float* __restrict__ sh_dirs, int dirs_are_centers,
                       const int* __restrict__ radii,
                       const uint2* __restrict__ dup, const float4* __restrict__ dupgrad,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
@@ -1037,7 +1037,10 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
       if constexpr (CM != 0) {
         float din[3];
         load3(sh_dirs + 3 * (size_t)g, din);
-        preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl, CM == 1, din, gdir);
+        // dirs_are_centers (SfgsGaussians.sh_centers): direction = normalize(p - centre), its gradient goes into means3D
+        // like the in-kernel SH path's; otherwise the direction was an input and its gradient is one (g_sh_dirs)
+        preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl, CM == 1, dirs_are_centers ? nullptr : din, gdir,
+                                 dirs_are_centers ? din : nullptr);
       } else {
         preprocess_backward_sums(f, p, s, q, opacity, shl, A, out, gshl);
       }
@@ -1069,7 +1072,7 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   if constexpr (K > 0) {
     if constexpr (SPLIT) store_sh_rows<K>(g_shs, g_shs_rest, (size_t)g, gshl);
     else store_row<ROW>(g_shs + (size_t)ROW * g, gshl);
-    if constexpr (CM != 0) store3(g_sh_dirs + 3 * (size_t)g, gdir[0], gdir[1], gdir[2]);
+    if constexpr (CM != 0) { if (!dirs_are_centers) store3(g_sh_dirs + 3 * (size_t)g, gdir[0], gdir[1], gdir[2]); }
   } else {
     store3(g_colors + 3 * (size_t)g, out.rgb[0], out.rgb[1], out.rgb[2]);
   }
@@ -1106,7 +1109,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   SFGS_REQUIRE((g->colors_precomp != nullptr) == (grads->colors_precomp != nullptr) &&
                    (g->shs != nullptr) == (grads->shs != nullptr) && (g->sh_dirs != nullptr) == (grads->sh_dirs != nullptr),
                SFGS_E_ARG, "colour gradient outputs must match the colour inputs");
-  SFGS_REQUIRE(!g->sh_dirs || g->shs, SFGS_E_ARG, "sh_dirs without shs");
+  SFGS_REQUIRE(!(g->sh_dirs || g->sh_centers) || g->shs, SFGS_E_ARG, "sh_dirs / sh_centers without shs");
+  SFGS_REQUIRE(!(g->sh_dirs && g->sh_centers), SFGS_E_ARG, "sh_dirs and sh_centers are alternatives");
   SFGS_REQUIRE((g->shs_rest != nullptr) == (grads->shs_rest != nullptr) &&
                    (!g->shs_rest || (g->shs && frame->sh_coeffs > 1 && g->shs_channel_major == 0)),
                SFGS_E_ARG, "shs_rest (split SH storage): gradient output must match, needs shs, sh_coeffs > 1, coefficient-major");
@@ -1153,18 +1157,19 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
 #define SFGS_LAUNCH_PBWD_(K, D, RAW, CM)                                                                               \
   hipLaunchKernelGGL((preprocess_bwd_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,  \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask, g->shs,   \
-                     g->shs_rest, g->sh_dirs, radii, gv.dup, (const float4*)dupgrad, grads->means3D, grads->means2D,   \
+                     g->shs_rest, g->sh_dirs ? g->sh_dirs : g->sh_centers, g->sh_centers ? 1 : 0, radii, gv.dup,       \
+                     (const float4*)dupgrad, grads->means3D, grads->means2D,                                           \
                      grads->scales, grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs,      \
                      grads->shs_rest, grads->sh_dirs)
 #define SFGS_LAUNCH_PBWD(K, D)                                                                                         \
   do {                                                                                                                 \
     if constexpr ((K) > 1) {   /* split SH storage (shs_rest): instantiations of their own (CMX = CM + 3) */            \
-      if (g->shs_rest && g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 5); else SFGS_LAUNCH_PBWD_(K, D, false, 5); break; } \
+      if (g->shs_rest && (g->sh_dirs || g->sh_centers)) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 5); else SFGS_LAUNCH_PBWD_(K, D, false, 5); break; } \
       if (g->shs_rest) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 3); else SFGS_LAUNCH_PBWD_(K, D, false, 3); break; } \
     }                                                                                                                  \
     if constexpr ((K) > 0) {                                                                                           \
-      if (g->sh_dirs && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 1); else SFGS_LAUNCH_PBWD_(K, D, false, 1); break; } \
-      if (g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 2); else SFGS_LAUNCH_PBWD_(K, D, false, 2); break; } \
+      if ((g->sh_dirs || g->sh_centers) && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 1); else SFGS_LAUNCH_PBWD_(K, D, false, 1); break; } \
+      if (g->sh_dirs || g->sh_centers) { if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 2); else SFGS_LAUNCH_PBWD_(K, D, false, 2); break; } \
     }                                                                                                                  \
     if (g->filter_3D) SFGS_LAUNCH_PBWD_(K, D, true, 0); else SFGS_LAUNCH_PBWD_(K, D, false, 0);                        \
   } while (0)

@@ -141,7 +141,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                   const float* __restrict__ rots, const void* __restrict__ opac_, const void* __restrict__ filt,
                   int raw_mask,
                   const float* __restrict__ colors, const float* __restrict__ shs, const float* __restrict__ shs_rest,
-                  const float* __restrict__ sh_dirs, int* __restrict__ radii,
+                  const float* __restrict__ sh_dirs, int dirs_are_centers, int* __restrict__ radii,
                   float4* __restrict__ rec_out, uint2* __restrict__ dup_out, uint32_t* __restrict__ coarse_count,
                   uint4* __restrict__ slabs, unsigned coarse_capacity, unsigned long long dup_capacity,
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
@@ -211,7 +211,10 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         if constexpr (CM != 0) {
           float din[3];
           load3(sh_dirs + 3 * (size_t)g, din);
-          sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len, CM == 1 ? 1 : 3, CM == 1 ? K : 1, din);
+          // dirs_are_centers (SfgsGaussians.sh_centers): `sh_dirs` holds per-Gaussian centres c and the direction is
+          // normalize(p - c), computed here like the in-kernel SH path's normalize(p - campos); wave-uniform
+          sh_to_rgb(DEG, shl, p, dirs_are_centers ? din : f.campos, rgb, &cm, dir, &len, CM == 1 ? 1 : 3, CM == 1 ? K : 1,
+                    dirs_are_centers ? nullptr : din);
         } else {
           sh_to_rgb(DEG, shl, p, f.campos, rgb, &cm, dir, &len);
         }
@@ -2056,9 +2059,10 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
     SFGS_REQUIRE(g->filter_3D ? (g->raw_f64_mask & ~3) == 0 : g->raw_f64_mask == 0, SFGS_E_ARG,
                  "raw_f64_mask %d: bit 0 = filter_3D is float64, bit 1 = raw opacities are float64; 0 without filter_3D",
                  g->raw_f64_mask);
-    SFGS_REQUIRE(!g->sh_dirs || g->shs, SFGS_E_ARG, "sh_dirs (eval_sh-folded colour path) needs shs");
-    SFGS_REQUIRE(g->sh_dirs ? (g->shs_channel_major & ~1) == 0 : g->shs_channel_major == 0, SFGS_E_ARG,
-                 "shs_channel_major %d: 0 or 1, and 0 without sh_dirs", g->shs_channel_major);
+    SFGS_REQUIRE(!(g->sh_dirs || g->sh_centers) || g->shs, SFGS_E_ARG, "sh_dirs / sh_centers (eval_sh-folded colour path) need shs");
+    SFGS_REQUIRE(!(g->sh_dirs && g->sh_centers), SFGS_E_ARG, "sh_dirs and sh_centers are alternatives");
+    SFGS_REQUIRE((g->sh_dirs || g->sh_centers) ? (g->shs_channel_major & ~1) == 0 : g->shs_channel_major == 0, SFGS_E_ARG,
+                 "shs_channel_major %d: 0 or 1, and 0 without sh_dirs / sh_centers", g->shs_channel_major);
     SFGS_REQUIRE(!g->shs_rest || (g->shs && f->sh_coeffs > 1 && g->shs_channel_major == 0), SFGS_E_ARG,
                  "shs_rest (split SH storage) needs shs, sh_coeffs > 1 and coefficient-major storage");
     if (g->shs)
@@ -2134,15 +2138,16 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
 #define SFGS_LAUNCH_PRE_(K, D, RAW, CM)                                                                                \
   hipLaunchKernelGGL((preprocess_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,      \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask,           \
-                     g->colors_precomp, g->shs, g->shs_rest, g->sh_dirs, radii, gv.rec, gv.dup, tv.coarse_count,       \
+                     g->colors_precomp, g->shs, g->shs_rest, g->sh_dirs ? g->sh_dirs : g->sh_centers,                 \
+                     g->sh_centers ? 1 : 0, radii, gv.rec, gv.dup, tv.coarse_count,                                    \
                      bv.slabs,                                                                                         \
                      (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
                      gv.big_list, tv.hdr, tv.dup_pool, two_pass ? bv.pairs : nullptr, gv.block_items)
 #define SFGS_LAUNCH_PRE(K, D)                                                                                          \
   do {                                                                                                                 \
     if constexpr ((K) > 0) {                                                                                           \
-      if (g->sh_dirs && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 1); else SFGS_LAUNCH_PRE_(K, D, false, 1); break; } \
-      if (g->sh_dirs) { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 2); else SFGS_LAUNCH_PRE_(K, D, false, 2); break; } \
+      if ((g->sh_dirs || g->sh_centers) && g->shs_channel_major) { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 1); else SFGS_LAUNCH_PRE_(K, D, false, 1); break; } \
+      if (g->sh_dirs || g->sh_centers) { if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 2); else SFGS_LAUNCH_PRE_(K, D, false, 2); break; } \
     }                                                                                                                  \
     if (g->filter_3D) SFGS_LAUNCH_PRE_(K, D, true, 0); else SFGS_LAUNCH_PRE_(K, D, false, 0);                          \
   } while (0)

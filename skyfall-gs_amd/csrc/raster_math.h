@@ -628,7 +628,7 @@ SFGS_HD Grad2D grad2d_from_sums(const GradSums& S, const Projected& pr, float op
 SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, const float* p, const float* s,
                                     const float* q, float opacity, const float* sh, const Grad2D& A, GaussGrads& out,
                                     float* g_sh, bool sh_cm = false, const float* dir_in = nullptr,
-                                    float* g_dir = nullptr) {
+                                    float* g_dir = nullptr, const float* center = nullptr) {
   const float* V = f.view;
   const float* PM = f.proj;
   float gp[3] = {0.f, 0.f, 0.f};
@@ -731,7 +731,8 @@ SFGS_HD void preprocess_backward_pr(const FrameParams& f, const Projected& pr, c
     float rgb[3], dir[3], len;
     unsigned mask;
     const int sk = sh_cm ? 1 : 3, sc = sh_cm ? f.sh_coeffs : 1;
-    sh_to_rgb(f.sh_degree, sh, p, f.campos, rgb, &mask, dir, &len, sk, sc, dir_in);
+    // center != nullptr (SfgsGaussians.sh_centers): the direction is normalize(p - center) instead of normalize(p - campos)
+    sh_to_rgb(f.sh_degree, sh, p, center ? center : f.campos, rgb, &mask, dir, &len, sk, sc, dir_in);
     float Bk[SH_MAX_COEFFS], dBx[SH_MAX_COEFFS], dBy[SH_MAX_COEFFS], dBz[SH_MAX_COEFFS];
     sh_basis(f.sh_degree, dir[0], dir[1], dir[2], Bk);
     sh_basis_grad(f.sh_degree, dir[0], dir[1], dir[2], dBx, dBy, dBz);
@@ -771,10 +772,10 @@ SFGS_HD void preprocess_backward_one(const FrameParams& f, const float* p, const
 SFGS_HD void preprocess_backward_sums(const FrameParams& f, const float* p, const float* s, const float* q,
                                       float opacity, const float* sh, const GradSums& S, GaussGrads& out,
                                       float* g_sh, bool sh_cm = false, const float* dir_in = nullptr,
-                                      float* g_dir = nullptr) {
+                                      float* g_dir = nullptr, const float* center = nullptr) {
   const Projected pr = project_gaussian(f, p, s, q);  // bit-identical to the forward
   preprocess_backward_pr(f, pr, p, s, q, opacity, sh, grad2d_from_sums(S, pr, opacity, f.W, f.H), out, g_sh, sh_cm,
-                         dir_in, g_dir);
+                         dir_in, g_dir, center);
 }
 
 }  // namespace sfgs

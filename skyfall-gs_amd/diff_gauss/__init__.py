@@ -252,13 +252,15 @@ def _dp(t):
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings, filter_3D=None,
-                sh_dirs=None, sh_degree=None, sh_channel_major=False, shs_rest=None):
+                sh_dirs=None, sh_degree=None, sh_channel_major=False, shs_rest=None, sh_centers=None):
         # filter_3D given: RAW-PARAMETER MODE (include/sfgs.h SfgsGaussians) -- opacities / scales / rotations are the
         # model's raw parameters (opacities possibly float64) and the gradients returned for them are the raw ones
         # sh_dirs given: EVAL_SH-FOLDED COLOUR PATH -- shs holds eval_sh's coefficients ([N,3,K] when sh_channel_major,
         # else [N,K,3]), sh_dirs its `dirs`, sh_degree the degree it was called with (sfgs.sh.DeferredColor)
         # shs_rest given: SPLIT SH STORAGE -- shs is the model's _features_dc [N,1,3], shs_rest its _features_rest [N,K-1,3]
         # (sfgs.features.DeferredFeatures); their two gradients come back separately
+        # sh_centers given (instead of sh_dirs): eval_sh's dirs are normalize(means3D - sh_centers), evaluated by the library
+        # (sfgs.viewdirs); the direction's gradient arrives in means3D's
         lib = L.load()
         dev = means3D.device
         di = dev.index
@@ -283,8 +285,11 @@ class _Rasterize(torch.autograd.Function):
             frame = L.SfgsFrame.from_buffer_copy(proto)
             gs = L.SfgsGaussians(_SIZEOF_GS, N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                  opacities.data_ptr(), _dp(colors_precomp), _dp(shs))
-            if sh_dirs is not None:
-                gs.sh_dirs = sh_dirs.data_ptr()
+            if sh_dirs is not None or sh_centers is not None:
+                if sh_dirs is not None:
+                    gs.sh_dirs = sh_dirs.data_ptr()
+                else:
+                    gs.sh_centers = sh_centers.data_ptr()
                 gs.shs_channel_major = int(bool(sh_channel_major))
                 frame.sh_degree = int(sh_degree)
             if shs_rest is not None:
@@ -408,14 +413,14 @@ class _Rasterize(torch.autograd.Function):
             ctx.st = (frame, gs, keep, cap, ccap, D, int(cnt.num_big_chunks), hkey, sh_coeffs, colors_precomp is not None,
                       shs is not None, opacities.dtype, total, settings, bool(sh_channel_major))
             ctx.save_for_backward(means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D,
-                                  sh_dirs, shs_rest)
+                                  sh_dirs, shs_rest, sh_centers)
         return color, depth, norm, alpha, radii
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_norm, g_alpha, g_radii):
         lib = L.load()
         (means3D, scales, rotations, opacities, colors_precomp, shs, radii, scratch, filter_3D, sh_dirs,
-         shs_rest) = ctx.saved_tensors
+         shs_rest, sh_centers) = ctx.saved_tensors     # (sh_centers: kept alive for `gs`, which points into it)
         (frame0, gs, keep, cap, ccap, ndup, big_chunks, hkey, K, has_colors, has_shs, opac_dtype, total, settings, sh_cm) = ctx.st
         dev = means3D.device
         di = dev.index
@@ -485,7 +490,7 @@ class _Rasterize(torch.autograd.Function):
         finally:
             if switch:
                 torch.cuda.set_device(prev_dev)
-        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None, g_dirs, None, None, g_rest
+        return g_means3D, g_means2D, g_shs, g_col, g_opac, g_scales, g_rot, None, None, g_dirs, None, None, g_rest, None
 
 
 def _f32grad(g):
@@ -523,6 +528,7 @@ class _HipBackend:
 
     supports_sh_dirs = True   # the eval_sh-folded colour path: sh_fold = (degree, coefficients, dirs[N,3], channel_major)
     supports_shs_rest = True  # split SH storage: `shs` (or sh_fold's coefficients) may be the pair (features_dc, features_rest)
+    supports_sh_centers = True  # sh_fold's dirs may be ("centers", tensor[N,3]): directions = normalize(means3D - centres)
 
     @staticmethod
     def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings, sh_fold=None):
@@ -534,15 +540,17 @@ class _HipBackend:
                       raster_settings, sh_fold=None):
         """filter_3D given: raw-parameter mode -- the activations + 3D filter of sfgs.prepass run inside preprocess /
         preprocess_bwd."""
-        dirs = deg = None
+        dirs = deg = centers = None
         cm = False
         if sh_fold is not None:
             deg, shs, dirs, cm = sh_fold
+            if isinstance(dirs, tuple):
+                centers, dirs = dirs[1], None
         rest = None
         if isinstance(shs, tuple):
             shs, rest = shs
         return _Rasterize.apply(means3D, means2D, shs, colors_precomp, raw_opacity, raw_scaling, raw_rotation,
-                                raster_settings, filter_3D, dirs, deg, cm, rest)
+                                raster_settings, filter_3D, dirs, deg, cm, rest, centers)
 
 
 _backend = _HipBackend
@@ -567,6 +575,9 @@ class GaussianRasterizer(nn.Module):
         if scales is None or rotations is None:
             raise ValueError("Please provide scales and rotations")
         N = int(means3D.shape[0])
+        from sfgs import viewdirs as _viewdirs
+        means3D = _viewdirs.materialise(means3D)     # sfgs.viewdirs' handle on `_xyz` (render(): means3D = pc.get_xyz)
+        means3D_given = means3D
         means3D = _f32c(means3D, "means3D")
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise ValueError("means3D must be [N,3]")
@@ -602,6 +613,13 @@ class GaussianRasterizer(nn.Module):
                 first = coeffs[0] if isinstance(coeffs, tuple) else coeffs
                 if first.shape[0] != N or tuple(sh_fold[2].shape) != (N, 3) or first.device != means3D.device:
                     raise ValueError("colors_precomp (deferred eval_sh): first dimension / device must match means3D")
+                if isinstance(sh_fold[2], _viewdirs.LazyDirs):
+                    # render()'s `dir_pp / dir_pp.norm(...)` still unevaluated: the library normalises means3D - centres
+                    # itself -- provided the handle's positions ARE this call's means3D
+                    centers = (_viewdirs.centers_of(sh_fold[2], means3D_given)
+                               if getattr(_backend, "supports_sh_centers", False) and means3D is means3D_given else None)
+                    dirs = ("centers", centers) if centers is not None else sh_fold[2].materialise().contiguous()
+                    sh_fold = (sh_fold[0], sh_fold[1], dirs, sh_fold[3])
         if sh_fold is None:
             colors_precomp = _f32c(colors_precomp, "colors_precomp", (3,))
         shs_rest = None

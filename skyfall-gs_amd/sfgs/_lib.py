@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -28,7 +28,8 @@ class SfgsGaussians(C.Structure):
                 ("rotations", C.c_void_p), ("opacities", C.c_void_p), ("colors_precomp", C.c_void_p),
                 ("shs", C.c_void_p), ("filter_3D", C.c_void_p), ("raw_f64_mask", C.c_int32),   # raw-parameter mode
                 ("sh_dirs", C.c_void_p), ("shs_channel_major", C.c_int32),                      # eval_sh-folded colour path
-                ("shs_rest", C.c_void_p)]                                                       # split SH storage (ABI 13)
+                ("shs_rest", C.c_void_p),                                                       # split SH storage (ABI 13)
+                ("sh_centers", C.c_void_p)]                                                     # directions from centres (ABI 15)
 
 
 class SfgsGaussianGrads(C.Structure):

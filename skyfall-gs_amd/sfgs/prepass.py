@@ -202,16 +202,21 @@ def install(gaussian_model_cls, fold=None):
     fold=True (default; SFGS_PREPASS_FOLD=0 in the environment turns it off): the getters return Deferred handles and the
     rasterizer applies the activations inside its own preprocess kernels (see Deferred); fold=False: they return the
     tensors of one fused_activations launch. With fold, `get_features` is patched as well (sfgs.features: a handle on
-    _features_dc / _features_rest instead of their concatenation; SFGS_FEATURES_FOLD=0 keeps the reference's getter)."""
+    _features_dc / _features_rest instead of their concatenation; SFGS_FEATURES_FOLD=0 keeps the reference's getter) and
+    `get_xyz` (sfgs.viewdirs: render()'s view-direction statements recorded and evaluated by the rasterizer; SFGS_DIRS_FOLD=0)."""
     import os
     if fold is None:
         fold = os.environ.get("SFGS_PREPASS_FOLD", "1") != "0"
     _FOLD[gaussian_model_cls] = bool(fold)
-    from . import features
+    from . import features, viewdirs
     if fold and os.environ.get("SFGS_FEATURES_FOLD", "1") != "0":
         features.install(gaussian_model_cls)      # get_features without the concatenation (sfgs.features)
     else:
         features.uninstall(gaussian_model_cls)
+    if fold and os.environ.get("SFGS_DIRS_FOLD", "1") != "0":
+        viewdirs.install(gaussian_model_cls)      # render()'s dir_pp normalisation inside the rasterizer (sfgs.viewdirs)
+    else:
+        viewdirs.uninstall(gaussian_model_cls)
     if gaussian_model_cls in _ORIG:
         return
     _ORIG[gaussian_model_cls] = {n: gaussian_model_cls.__dict__[n] for n in
@@ -223,7 +228,8 @@ def install(gaussian_model_cls, fold=None):
 
 def uninstall(gaussian_model_cls):
     _FOLD.pop(gaussian_model_cls, None)
-    from . import features
+    from . import features, viewdirs
     features.uninstall(gaussian_model_cls)
+    viewdirs.uninstall(gaussian_model_cls)
     for n, v in _ORIG.pop(gaussian_model_cls, {}).items():
         setattr(gaussian_model_cls, n, v)

@@ -94,7 +94,8 @@ class DeferredColor(torch.Tensor):
     def materialise(self):
         if self._sfgs_real is None:
             deg, sh, dirs, offset, clamp = self._sfgs_expr
-            v = _EvalSH.apply(deg, sh.contiguous(), dirs)
+            from . import viewdirs
+            v = _EvalSH.apply(deg, sh.contiguous(), viewdirs.materialise(dirs).contiguous())
             if offset != 0.0:
                 v = v + offset
             if clamp is not None:
@@ -109,7 +110,9 @@ class DeferredColor(torch.Tensor):
         result) or, when it is the transposed view of a contiguous [N,K,3] tensor (convert_SHs_python:
         `pc.get_features.transpose(1, 2).view(-1, 3, K)`), that [N,K,3] tensor (channel_major = False) -- no copy
         either way; any other striding is made contiguous. With sfgs.features installed the convert_SHs_python view is a
-        DeferredFeatures handle and `coefficients` the PAIR (features_dc [N,1,3], features_rest [N,K-1,3])."""
+        DeferredFeatures handle and `coefficients` the PAIR (features_dc [N,1,3], features_rest [N,K-1,3]). `dirs` is
+        what eval_sh was given: a tensor, or the sfgs.viewdirs handle standing for render()'s normalised `dir_pp` (the
+        rasterizer asks it for the centres: viewdirs.centers_of)."""
         deg, sh, dirs, offset, clamp = self._sfgs_expr
         if self._sfgs_real is not None or offset != 0.5 or clamp != 0.0:
             return None

@@ -154,6 +154,7 @@ def _loss(loss_utils, image, depth, cam, lambda_dssim=0.2, lambda_depth=0.5):
 HOOKED = None
 SH_HOOKED = None
 SH_SEEN = []
+DIRS_SEEN = []
 
 
 def run():
@@ -231,9 +232,23 @@ def run():
             deg, sh_, dirs_, offset, clamp = h._sfgs_expr
             assert (offset, clamp) == (0.5, 0.0) and deg == model.active_sh_degree and sh_.shape[1] == 3, name
             SH_SEEN.append(name)
+            if HOOKED is not None:
+                # both hooks: eval_sh's `dirs` is the sfgs.viewdirs handle that recorded render()'s two direction
+                # statements (:114-115 / :122-123) on the model's own positions, with the repeated camera centre
+                from sfgs import viewdirs
+                assert isinstance(dirs_, viewdirs.LazyDirs) and dirs_._sfgs_kind == viewdirs.DIRS, name
+                dirpp, norm = dirs_._sfgs_src
+                assert norm._sfgs_src is dirpp and dirpp._sfgs_src[0]._sfgs_src is model._xyz, name
+                cen = dirpp._sfgs_src[1]
+                assert tuple(cen.shape) == tuple(model._xyz.shape) and bool((cen == cam.camera_center).all()), name
+                DIRS_SEEN.append(name)
         if HOOKED is not None:   # the handles really travelled through render()
             a = trace[-1]["arg_tensors"]
             assert all(isinstance(a[k], HOOKED.Deferred) for k in ("scales", "opacities", "rotations")), name
+            from sfgs import features, viewdirs
+            assert isinstance(a["means3D"], viewdirs.LazyDirs) and a["means3D"]._sfgs_src is model._xyz, name
+            if a["shs"] is not None:    # render(): shs = pc.get_features (:127)
+                assert isinstance(a["shs"], features.DeferredFeatures), name
         trace[-1]["name"] = name
         assert set(pkg) == {"render", "render_depth", "render_norm", "render_alpha", "viewspace_points",
                             "visibility_filter", "radii", "extra"}
@@ -332,6 +347,8 @@ def main():
         print("reference_render_trace.npz reproduced:", len(trace), "calls;", summary)
         if SH_HOOKED is not None:
             print("deferred eval_sh handles arrived at the rasterizer in:", SH_SEEN)
+            if DIRS_SEEN:
+                print("with recorded view directions in:", DIRS_SEEN)
         return
     np.savez_compressed(OUT, **z)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB;", [r["name"] for r in trace], summary)

@@ -56,6 +56,24 @@ def test_real_render_records_its_two_colour_statements_on_the_deferred_eval_sh_h
             "'A_testing_no_grad', 'B_sh_python_white']") in r.stdout
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gaussian_renderer")), reason="reference tree not present (GPU box)")
+def test_real_render_with_every_hook_records_its_view_direction_statements(tmp_path):
+    """Both hooks on the REAL classes: `get_xyz` returns the sfgs.viewdirs handle, the REAL render() subtracts the repeated
+    camera centre, takes `.norm(dim=1, keepdim=True)` and divides (gaussian_renderer/__init__.py:114-115, :122-123) -- the
+    driver asserts that eval_sh's `dirs` argument inside the colour handle is the handle that recorded exactly these
+    statements on the model's own `_xyz`, in every call of the two Python colour paths -- `shs = pc.get_features` arrives
+    as the sfgs.features handle, means3D as the handle on `_xyz`, and the oracle double, which materialises all of them
+    with ordinary torch operations, reproduces the committed trace bit for bit (values, dtypes, strides, requires_grad).
+    GPU side (the rasterizer evaluating the directions itself): tests/test_gpu_viewdirs.py."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden_r3.py"), "--check",
+                        "--with-prepass-hook", "--with-sh-hook"], cwd=str(tmp_path), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "reproduced: 7 calls" in r.stdout
+    assert ("with recorded view directions in: ['A_mlp', 'A_mlp_jitter_cxcy', 'A_after_densify', 'A_testing_no_grad', "
+            "'B_sh_python_white']") in r.stdout
+
+
 def test_committed_trace_is_what_render_hands_the_rasterizer():
     """Static facts of the recorded boundary (runs everywhere): the 14 settings fields in the reference's order, the
     keyword set, dtypes and shapes of gaussian_renderer/__init__.py:132-140."""
