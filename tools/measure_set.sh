@@ -13,7 +13,7 @@ $B --n 1000000 > "$R/bench_1000000.json" 2>/dev/null
 $B --config cfg4 > "$R/bench_cfg4.json" 2>/dev/null          # 5 M, 2560x1440, z ~ U(500, 700), dL/ddepth != 0
 $B --config cfg3 > "$R/bench_cfg3.json" 2>/dev/null          # 108 forward-only 1024^2 renders + the timed fwd+bwd steps
 $B --n 5000000 --width 2560 --height 1440 > "$R/bench_5M_1440p_cfg2geometry.json" 2>/dev/null   # (the r1/r2 "cfg 4" line)
-HSA_ENABLE_IPC_MODE_LEGACY=0 $B --force-dist > "$R/bench_force_dist_rccl.json" 2>/dev/null      # RCCL all-reduce every step, world = 1
+HSA_ENABLE_IPC_MODE_LEGACY=0 $B --force-dist > "$R/bench_force_dist_rccl.json" 2> "$R/bench_force_dist_rccl.err"      # RCCL all-reduce every step, world = 1
 $B --sh-degree 1 > "$R/bench_sh1.json" 2>/dev/null
 $B --sh-degree 3 > "$R/bench_sh3.json" 2>/dev/null
 $B --forward-only > "$R/fps_2M.json" 2>/dev/null
