@@ -76,6 +76,10 @@ def main():
                          "--n / --width / --height override the config's size")
     ap.add_argument("--zrange", type=float, nargs=2, default=None, metavar=("ZMIN", "ZMAX"),
                     help="view depth range of the synthetic scene (default: the config's)")
+    ap.add_argument("--subpixel-offset", choices=["none", "zeros"], default="none",
+                    help="'zeros': hand the rasterizer an all-zero [H,W,2] subpixel_offset tensor, which is what the reference's "
+                         "render() allocates on every call when ray jitter is off (gaussian_renderer/__init__.py:37-38); "
+                         "'none' (the headline since round 1): no tensor")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: initialise torch.distributed over RCCL (backend nccl, world size 1) and run the "
                          "24 966-float device all-reduce every step, as the N > 1 runs do")
@@ -151,7 +155,9 @@ def main():
     gc, gd = upstream_grads(W, H, rank)
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"],
-        kernel_size=frame["kernel_size"], subpixel_offset=None, bg=frame["bg"].to(dev),
+        kernel_size=frame["kernel_size"],
+        subpixel_offset=torch.zeros(H, W, 2, dtype=torch.float32, device=dev) if args.subpixel_offset == "zeros" else None,
+        bg=frame["bg"].to(dev),
         scale_modifier=1.0, viewmatrix=frame["view"].to(dev), projmatrix=frame["proj"].to(dev), sh_degree=max(sh, 0),
         campos=frame["campos"].to(dev), prefiltered=False, debug=False)
     rast = GaussianRasterizer(settings)
@@ -380,7 +386,8 @@ def main():
             "config": {"workload": f"configs[{CFG['configs_index']}]: synthetic {args.config} scene (SURVEY 8d), N={N} Gaussians/GPU, "
                                    f"{W}x{H}, z ~ U({zrange[0]:g}, {zrange[1]:g}), "
                                    f"{'colors_precomp' if sh < 0 else 'SH degree %d in-kernel' % sh}, "
-                                   f"kernel_size=0.1, dL/dimage and dL/ddepth ~ N(0,1)/P, seed=rank, one scene per GPU",
+                                   f"kernel_size=0.1, subpixel_offset={'zeros[H,W,2]' if args.subpixel_offset == 'zeros' else 'None'}, "
+                                   f"dL/dimage and dL/ddepth ~ N(0,1)/P, seed=rank, one scene per GPU",
                        "name": args.config, "zrange": list(zrange),
                        "N": N, "width": W, "height": H, "N_vis": Nvis, "D_ref_16x16": D_ref, "D_binned_8x8": D_eff,
                        "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
