@@ -70,6 +70,7 @@ HINT_MEDIUM_LISTS = 32
 SHORT_LIST_MAX, SHORT_BIN_MAX = 512, 8192
 MEDIUM_LIST_MAX = 1024     # MEDIUM_LISTS: the same kernel with room for lists of 513 .. 1 024 entries (low-elevation views)
 MEDIUM_TILE_SHARE = 4      # ... asked for when at least a quarter of the frame's tiles had more than 512 entries
+HUGE_QUIET_FRAMES = 32     # frames without a huge splat before NO_HUGE_SPLATS is asserted again
 PREFILL_PROBE_EVERY = 32   # backward passes between two launches of the dead-entry prefill kernel while it keeps saying no
 
 
@@ -384,7 +385,11 @@ class _Rasterize(torch.autograd.Function):
                     hs["over512"] = int(cnt.prev_tiles_over_512)
                     if hs["prefill_ran"]:
                         hs["prefilled"] = int(cnt.prev_prefilled)
-                hs["huge"] = int(cnt.num_huge_splats)
+                # NO_HUGE_SPLATS is the one hint whose violation costs a second plan + render: after a frame WITH huge splats the
+                # walk kernel (5 us when it finds nothing) stays in for HUGE_QUIET_FRAMES frames -- a camera schedule that
+                # alternates between views with and without such splats (the IDU stage's mixed elevations) must not redo
+                # every other frame
+                hs["huge"] = HUGE_QUIET_FRAMES if cnt.num_huge_splats else max(hs["huge"] - 1, 0)
                 hs["cmax"] = int(cnt.max_bin_items)
                 hs["prefill_ran"] = False
             _cap_hint[(di, W, H)] = (cap if pool_grown else

@@ -60,8 +60,9 @@ def _run(frames, reps):
     return res
 
 
-def test_hints_never_change_a_result():
+def test_hints_never_change_a_result(monkeypatch):
     import diff_gauss
+    monkeypatch.setattr(diff_gauss, "HUGE_QUIET_FRAMES", 1)   # no hysteresis: the sequence below must hit the violated-hint redo
     frames = _frames()
     old = os.environ.get("SFGS_HINTS")
     try:
@@ -87,6 +88,26 @@ def test_hints_never_change_a_result():
     # the sequence did exercise what it claims to
     by = {r["name"]: r["counters"] for r in got}
     assert by["long_lists#1"]["num_duplicates"] > 10 * by["calm#1"]["num_duplicates"]
+
+
+def test_huge_splat_hint_waits_for_a_quiet_period(monkeypatch):
+    """NO_HUGE_SPLATS is the one hint whose violation costs a second plan + render. After a frame with huge splats it is
+    asserted again only after HUGE_QUIET_FRAMES frames without one, so a camera schedule that alternates between views
+    with and without such splats (the IDU stage's mixed elevations, train.py:364-420) does not redo every other frame."""
+    import diff_gauss
+    from diff_gauss import HINT_NO_HUGE_SPLATS
+    monkeypatch.setattr(diff_gauss, "HUGE_QUIET_FRAMES", 3)
+    fr = {n: (f, g) for n, f, g in _frames()}
+    calm, huge = ("calm",) + fr["calm"], ("huge_splats",) + fr["huge_splats"]
+    diff_gauss._hint_state.clear()
+    seq = [calm, calm, huge, calm, huge, calm, calm, calm, calm, calm]
+    res = _run(seq, 1)
+    hinted = [bool(r["counters"]["fwd_hints"] & HINT_NO_HUGE_SPLATS) for r in res]
+    nhuge = [r["counters"]["num_huge_splats"] for r in res]
+    assert nhuge[2] > 0 and nhuge[4] > 0 and nhuge[3] == 0
+    # frame 0: nothing known; 1: calm after calm -> hinted; 2: the huge frame was planned WITH the hint, found out, redone
+    # without it; 3 .. 7: quiet period (re-armed by frame 4); 8: three calm frames (5, 6, 7) later the hint is back
+    assert hinted == [False, True, False, False, False, False, False, False, True, True], hinted
 
 
 def test_medium_lists_hint_engages_and_changes_nothing():
