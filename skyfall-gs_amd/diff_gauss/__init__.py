@@ -335,8 +335,9 @@ class _Rasterize(torch.autograd.Function):
             pin, ev, pin_ptr, ev_handle, cnt = _pinned_counters(dev, stream)
             outs_ptr = outs.data_ptr()
             plane = 4 * H * W
-            tries, pool_grown = 0, False
+            tries, pool_grown, attempts = 0, False, 0
             while True:
+                attempts += 1
                 total = _layout(lib, N, W, H, cap, ccap, need_bwd)[0]
                 if total > _scratch_budget(dev):
                     # uniform per-coarse-bin slabs (ncb x fullest bin x 16 B): only a pathologically skewed frame
@@ -392,13 +393,17 @@ class _Rasterize(torch.autograd.Function):
                 hs["huge"] = HUGE_QUIET_FRAMES if cnt.num_huge_splats else max(hs["huge"] - 1, 0)
                 hs["cmax"] = int(cnt.max_bin_items)
                 hs["prefill_ran"] = False
+            # next frame's capacities: 25 % / 50 % of headroom over this frame, never growing on their own, and SHRINKING
+            # slowly (3 % per frame, down to twice / three times this frame's need): an overflowing plan costs a second plan +
+            # render, and a camera schedule that alternates between light and heavy views (the IDU stage's mixed elevations)
+            # must not overflow at every heavy one
             _cap_hint[(di, W, H)] = (cap if pool_grown else
-                                     max(int(D * 1.25) + 1024 + over, min(cap, 2 * D + 1024 + over)),
-                                     max(int(cmax * 1.5) + 256, min(ccap, 3 * cmax + 256)))
+                                     max(int(D * 1.25) + 1024 + over, min(cap, max(2 * D + 1024 + over, int(cap * 0.97)))),
+                                     max(int(cmax * 1.5) + 256, min(ccap, max(3 * cmax + 256, int(ccap * 0.97)))))
             global _last_counters
             _last_counters = dict(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
                                   num_visible=int(cnt.num_visible), max_coarse_bin=cmax, max_bin_items=int(cnt.max_bin_items),
-                                  num_huge_splats=int(cnt.num_huge_splats),
+                                  num_huge_splats=int(cnt.num_huge_splats), plan_attempts=attempts,
                                   max_tile_list=int(cnt.max_tile_list), N=N, W=W, H=H, dup_capacity=cap,
                                   coarse_capacity=ccap, fwd_hints=int(fwd_hints))   # published by reference assignment (atomic)
         finally:

@@ -110,6 +110,27 @@ def test_huge_splat_hint_waits_for_a_quiet_period(monkeypatch):
     assert hinted == [False, True, False, False, False, False, False, False, True, True], hinted
 
 
+def test_capacities_shrink_slowly_so_alternating_views_plan_once():
+    """The blobs of a frame are sized from the previous frames' counts; an overflowing plan is redone (a second plan +
+    render). After a heavy view the capacities shrink by 3 % per frame only, so a schedule that alternates between light
+    and heavy views -- 10x the duplicates here -- plans every frame ONCE after it has seen the heavy one."""
+    import diff_gauss
+    fr = {n: (f, g) for n, f, g in _frames()}
+    light, heavy = ("calm",) + fr["calm"], ("long_lists",) + fr["long_lists"]
+    diff_gauss._hint_state.clear()
+    diff_gauss._cap_hint.clear()
+    res = _run([light, heavy, light, heavy, light, light, heavy], 1)
+    att = [r["counters"]["plan_attempts"] for r in res]
+    dup = [r["counters"]["num_duplicates"] for r in res]
+    assert dup[1] > 8 * dup[0]
+    assert att[1] >= 2                      # the first heavy view does not fit the light view's blobs
+    assert att[2:] == [1, 1, 1, 1, 1], att  # ... nothing after it is planned twice
+    caps = [r["counters"]["dup_capacity"] for r in res]
+    # (frames 4, 5 are two light views in a row: the second runs with 97 % of the first one's capacity; every heavy view
+    # brings it back to 1.25 x its own need)
+    assert int(caps[4] * 0.97) - 1 <= caps[5] < caps[4] and caps[6] >= dup[6]
+
+
 def test_medium_lists_hint_engages_and_changes_nothing():
     """A frame whose longest list has 513 .. 1 024 entries (the reference's low-elevation IDU cameras): from the second
     frame on the wrapper asks for the fused kernel's 1 024-entry form (SHORT_LISTS | MEDIUM_LISTS) instead of falling back
