@@ -14,12 +14,14 @@ means2D.grad[:, 2] = magnitude of the summed absolute 2D gradients. depth = sum(
 (none are consumed). All arithmetic runs in the HIP library; this file only validates
 arguments, owns the scratch tensors (PyTorch caching allocator) and plumbs the current stream.
 """
+import os
 from typing import NamedTuple, Optional
 
 import torch
 import torch.nn as nn
 
 from sfgs import _lib as L
+from sfgs import features as _features, prepass, sh as _sh, viewdirs as _viewdirs   # the hooks' handle types (recognised below)
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_counters",
            "last_backward_hints", "collect_full_counters"]
@@ -75,17 +77,14 @@ PREFILL_PROBE_EVERY = 32   # backward passes between two launches of the dead-en
 
 
 def _hints_on():
-    import os
     return os.environ.get("SFGS_HINTS", "1") != "0"
 
 
 def _binning_direct():
-    import os
     return os.environ.get("SFGS_BINNING", "") == "direct"
 
 
 def _medium_on():
-    import os
     return os.environ.get("SFGS_MEDIUM_LISTS", "1") != "0"   # A/B switch: 0 = frames with lists of 513 .. 1 024 take the split route
 
 
@@ -296,9 +295,8 @@ class _Rasterize(torch.autograd.Function):
             if shs_rest is not None:
                 gs.shs_rest = shs_rest.data_ptr()
             if filter_3D is not None:
-                from sfgs.prepass import f64_mask
                 gs.filter_3D = filter_3D.data_ptr()
-                gs.raw_f64_mask = f64_mask(filter_3D, opacities)
+                gs.raw_f64_mask = prepass.f64_mask(filter_3D, opacities)
             # Neither the duplicate count D nor the fullest coarse bin is known before the plan: plan into blobs sized
             # from the previous frames (geometric growth) and redo the frame in the rare case it overflowed.
             hint = _cap_hint.get((di, W, H), (0, 0))
@@ -519,10 +517,9 @@ def _gaussians(N, means3D, scales, rotations, opacities, colors_precomp, shs, fi
     if filter_3D is None:
         return L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                                L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs))
-    from sfgs.prepass import f64_mask
     return L.SfgsGaussians(C_sizeof(L.SfgsGaussians), N, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                            L.ptr(opacities), L.ptr(colors_precomp), L.ptr(shs), L.ptr(filter_3D),
-                           f64_mask(filter_3D, opacities))
+                           prepass.f64_mask(filter_3D, opacities))
 
 
 class _HipBackend:
@@ -585,7 +582,6 @@ class GaussianRasterizer(nn.Module):
         if scales is None or rotations is None:
             raise ValueError("Please provide scales and rotations")
         N = int(means3D.shape[0])
-        from sfgs import viewdirs as _viewdirs
         means3D = _viewdirs.materialise(means3D)     # sfgs.viewdirs' handle on `_xyz` (render(): means3D = pc.get_xyz)
         means3D_given = means3D
         means3D = _f32c(means3D, "means3D")
@@ -595,7 +591,6 @@ class GaussianRasterizer(nn.Module):
             means2D = torch.zeros_like(means3D)
         # Deferred results of sfgs.prepass's patched getters (render() only passed them through .float()): the library
         # applies the activations itself, from the raw parameters. Anything else Deferred is materialised here.
-        from sfgs import prepass
         raw = prepass.raw_parameters(scales, opacities, rotations) if hasattr(_backend, "rasterize_raw") else None
         if raw is None:
             scales, opacities, rotations = (prepass.materialise(t) for t in (scales, opacities, rotations))
@@ -610,7 +605,6 @@ class GaussianRasterizer(nn.Module):
         # DeferredColor (sfgs.sh's patched eval_sh; render() added 0.5 and clamped it): the library evaluates
         # clamp_min(eval_sh(deg, sh, dirs) + 0.5, 0) inside preprocess / preprocess_bwd. Anything else is materialised.
         sh_fold = None
-        from sfgs import sh as _sh
         if isinstance(colors_precomp, _sh.DeferredColor):
             sh_fold = colors_precomp.folded_inputs() if getattr(_backend, "supports_sh_dirs", False) else None
             if sh_fold is None:
@@ -636,7 +630,6 @@ class GaussianRasterizer(nn.Module):
         if shs is not None:
             # DeferredFeatures (sfgs.features' patched get_features, handed over untouched): the library reads the model's
             # two coefficient parameters themselves; a handle something looked into is the ordinary tensor
-            from sfgs import features as _features
             if isinstance(shs, _features.DeferredFeatures):
                 parts = _features.split_parts(shs) if getattr(_backend, "supports_shs_rest", False) else None
                 if parts is not None and not parts[2]:
