@@ -221,6 +221,53 @@ __device__ __forceinline__ void phase2_grid_step(Phase2Grid& a, float u, float w
   }
 }
 
+// -DSFGS_BWD_PK2=1 (round 4, experiment): the same step with PACKED FP32 -- (S, X) advance in one v_pk_fma_f32 ((u, u) x
+// (1, cx) + (S, X): the (u, w) pair the LDS exchange returned is the first operand, op_sel takes u for both halves) and
+// (lx, ly) = (-cA, -cB) cx + (kx, ky) in another: 9 instead of 11 VALU instructions per pixel, the same values bit for bit
+// (u x 1 + S is S + u).
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+struct Phase2GridPk {
+  v2f32 SX0, SX1;
+  float XX0, XX1, ax, ay, r, g, b, d;
+};
+template <int I>
+__device__ __forceinline__ void phase2_grid_step_pk(Phase2GridPk& a, v2f32 uw, v2f32 ncAB, v2f32 k0, v2f32 k1, float g0,
+                                                    float g1, float g2, float g3) {
+  constexpr float cx = (float)(I & 7) - 3.5f;
+  const v2f32 c = {1.0f, cx};
+  const float u = uw.x, w = uw.y;
+  v2f32& SX = I < 8 ? a.SX0 : a.SX1;
+  float& XX = I < 8 ? a.XX0 : a.XX1;
+  if constexpr ((I & 7) == 0) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(SX) : "v"(uw), "s"(c));
+    XX = u * (cx * cx);
+  } else {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(SX) : "v"(uw), "s"(c));
+    XX = fmaf(u, cx * cx, XX);
+  }
+  v2f32 l;
+  if constexpr (I < 8) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(l) : "v"(ncAB), "s"(c), "v"(k0));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(l) : "v"(ncAB), "s"(c), "v"(k1));
+  if constexpr (I == 0) {
+    a.ax = fabsf(u) * fabsf(l.x);
+    a.ay = fabsf(u) * fabsf(l.y);
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.r) : "v"(g0), "v"(w), "n"(I));
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.g) : "v"(g1), "v"(w), "n"(I));
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.b) : "v"(g2), "v"(w), "n"(I));
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.d) : "v"(g3), "v"(w), "n"(I));
+  } else {
+    a.ax = fmaf(fabsf(u), fabsf(l.x), a.ax);
+    a.ay = fmaf(fabsf(u), fabsf(l.y), a.ay);
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(I));
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(I));
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(I));
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
+  }
+}
+#ifndef SFGS_BWD_PK2
+#define SFGS_BWD_PK2 0
+#endif
+
 // One pixel ROW (8 pixels) of a lane's group at once (-DSFGS_BWD_ROWSYM, round 4): the columns are symmetric about the
 // tile centre (cx_i = -cx_{7-i}), so with P_i = u_i + u_{7-i}, M_i = u_i - u_{7-i} (i = 0..3) the three raw moments are
 //   S = sum P_i,   X = sum cx_i M_i,   XX = sum cx_i^2 P_i          -- 8 + 3 + 4 + 4 = 19 instructions instead of 24.
@@ -658,6 +705,38 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         const float kx0 = fmaf(cA, mxl, cB * dy0), kx1 = fmaf(cA, mxl, cB * dy1);
         const float ky0 = fmaf(cC, dy0, cB * mxl), ky1 = fmaf(cC, dy1, cB * mxl);
         const float ncA = -cA, ncB = -cB;
+#if SFGS_BWD_PK2
+        {
+          const v2f32 ncAB = {ncA, ncB}, k0 = {kx0, ky0}, k1 = {kx1, ky1};
+          Phase2GridPk pk;
+          auto take = [&](int i) { const float2 t = uw_take(UWrow + i); v2f32 r; r.x = t.x; r.y = t.y; return r; };
+#define SFGS_PK_LOAD(A, Bq, C, D) const v2f32 pw##A = take(A), pw##Bq = take(Bq), pw##C = take(C), pw##D = take(D);
+#define SFGS_PK(I) phase2_grid_step_pk<I>(pk, pw##I, ncAB, k0, k1, g0, g1, g2, g3)
+#define SFGS_PK_DO(A, Bq, C, D) SFGS_PK(A); SFGS_PK(Bq); SFGS_PK(C); SFGS_PK(D);
+#define SFGS_PK_FENCE asm volatile("" ::: "memory");
+          SFGS_PK_LOAD(0, 1, 2, 3)
+          SFGS_PK_LOAD(4, 5, 6, 7)
+          SFGS_PK_FENCE
+          SFGS_PK_DO(0, 1, 2, 3)
+          SFGS_PK_FENCE
+          SFGS_PK_LOAD(8, 9, 10, 11)
+          SFGS_PK_FENCE
+          SFGS_PK_DO(4, 5, 6, 7)
+          SFGS_PK_FENCE
+          SFGS_PK_LOAD(12, 13, 14, 15)
+          SFGS_PK_FENCE
+          SFGS_PK_DO(8, 9, 10, 11)
+          SFGS_PK_DO(12, 13, 14, 15)
+#undef SFGS_PK_LOAD
+#undef SFGS_PK
+#undef SFGS_PK_DO
+#undef SFGS_PK_FENCE
+          Phase2Grid pgk;
+          pgk.S0 = pk.SX0.x; pgk.X0 = pk.SX0.y; pgk.S1 = pk.SX1.x; pgk.X1 = pk.SX1.y; pgk.XX0 = pk.XX0; pgk.XX1 = pk.XX1;
+          pgk.ax = pk.ax; pgk.ay = pk.ay; pgk.r = pk.r; pgk.g = pk.g; pgk.b = pk.b; pgk.d = pk.d;
+          pa = phase2_grid_finish(pgk, mxl, dy0, dy1);
+        }
+#else
         Phase2Grid pg;
         // straight line, four pixels per LDS round trip (the asm fences keep the compiler from hoisting all sixteen
         // 8-byte loads above the arithmetic, which would cost ~30 VGPRs and the fourth wave per SIMD)
@@ -712,6 +791,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #undef SFGS_P2_FENCE
 #undef SFGS_P2
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
+#endif
       } else {
         pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if defined(SFGS_BWD_XCHG)
