@@ -385,6 +385,25 @@ def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
 
 
+@pytest.mark.parametrize("case", ["cfg2_like", "sh1_ragged", "big_splats", "lists_800"])
+def test_the_zero_subpixel_tensor_of_render_equals_no_tensor(case):
+    """The reference's render() allocates an all-zero [H,W,2] subpixel_offset on every call when ray jitter is off
+    (gaussian_renderer/__init__.py:37-38) -- the call pattern of every shipped script -- while the benchmarks and most
+    tests here pass None. The kernels learn from the plan (subpix_bound_kernel: max |offset| = 0) that the sample points
+    sit on the pixel grid and take the same path: images, radii, counters and every gradient are equal bit for bit."""
+    c = CASES[case]
+    frame, g = scene(c["n"], c["W"], c["H"], seed=13, **c["kw"])
+    gc, gd = upstream_grads(c["W"], c["H"], 5)
+    a = run_hip(frame, g, gc, gd)
+    b = run_hip(dict(frame, subpix=torch.zeros(c["H"], c["W"], 2)), g, gc, gd)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in ("num_duplicates", "num_duplicates_ref", "num_visible", "max_bin_items", "max_tile_list"):
+        assert a["counters"][k] == b["counters"][k], k
+    for k in a["grads"]:
+        np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
+
+
 def test_a_skewed_frame_needs_no_per_bin_capacity():
     """ABI 14: the two-pass binning's items are stored bin-sorted and EXACTLY sized, so a distant view -- every Gaussian in
     a handful of coarse bins -- plans in one attempt with the minimal slab capacity and a scratch in proportion to the
