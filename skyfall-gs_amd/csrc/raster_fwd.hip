@@ -2073,6 +2073,26 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
   return SFGS_OK;
 }
 
+// The plan clears the head of the tiles blob (header, duplicate pools, the coarse bins' counter lines: 261 KB at 1080p).
+// A kernel of our own instead of hipMemsetAsync (-DSFGS_PLAN_MEMSET=1): the runtime's fill goes through its blit path,
+// which showed up in the kernel traces with 4 - 6 us of idle queue in front of it on every frame.
+#ifndef SFGS_PLAN_MEMSET
+#define SFGS_PLAN_MEMSET 0
+#endif
+__global__ void __launch_bounds__(256) zero_head_kernel(uint4* __restrict__ p, unsigned n16) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static hipError_t zero_head(void* p, size_t bytes, hipStream_t stream) {
+#if SFGS_PLAN_MEMSET
+  return hipMemsetAsync(p, 0, bytes, stream);
+#else
+  const unsigned n16 = (unsigned)(bytes / 16);   // zero_bytes is a multiple of 256
+  hipLaunchKernelGGL(zero_head_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (uint4*)p, n16);
+  return hipGetLastError();
+#endif
+}
+
 extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse_capacity,
                                  SfgsRasterSizes* out) {
   SFGS_REQUIRE(out && out->struct_size == sizeof(SfgsRasterSizes), SFGS_E_ARG, "SfgsRasterSizes.struct_size mismatch");
@@ -2121,7 +2141,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   const BinsView bv = bins_view_csr(bins, dup_capacity, NCB, coarse_capacity, N);
   const KFrame kf = make_kframe(frame);
   const int NB = (int)pre_blocks(N);
-  SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
+  SFGS_CHECK_HIP(zero_head(tiles, tv.zero_bytes, stream));
   if (frame->subpixel_offset) {
     const int64_t n = (int64_t)W * H * 2;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 512));
@@ -2312,7 +2332,7 @@ extern "C" int sfgs_raster_plan_merge(const SfgsFrame* frame, int32_t parts, con
                "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
   const GeomView gv = geom_view(geom, N);
   const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
-  SFGS_CHECK_HIP(hipMemsetAsync(tiles, 0, tv.zero_bytes, stream));
+  SFGS_CHECK_HIP(zero_head(tiles, tv.zero_bytes, stream));
   if (frame->subpixel_offset) {
     const int64_t n = (int64_t)W * H * 2;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 512));
