@@ -43,6 +43,8 @@ def lib():
         _lib.orc_get_n_contrib.argtypes = [C.c_void_p, C.c_void_p]
         _lib.orc_get_tile_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_get_geom.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_decision_margins.restype = None
+        _lib.orc_decision_margins.argtypes = [C.c_void_p, C.POINTER(OrcFrame), C.c_void_p]
         _lib.orc_ssim.restype = C.c_double
         _lib.orc_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p]
@@ -106,6 +108,14 @@ class OracleRender:
         out = np.zeros((self.H, self.W), np.uint32)
         lib().orc_get_n_contrib(self._st, _ptr(out))
         return out
+
+    def decision_margins(self):
+        """(alpha, T, power): the smallest relative distance of any per-pixel compositing decision to its threshold
+        (1/255, 1e-4, 0) -- see orc_decision_margins. A float32 implementation with another exponential may decide a pair
+        closer than a few 1e-6 the other way."""
+        out = np.zeros(3, np.float64)
+        lib().orc_decision_margins(self._st, C.byref(self.frame), _ptr(out))
+        return dict(alpha=float(out[0]), T=float(out[1]), power=float(out[2]))
 
     def tile_lists(self):
         starts = np.zeros(self.num_tiles + 1, np.int64)

@@ -361,6 +361,48 @@ OrcState* orc_forward(const OrcFrame* f, int32_t N, const float* means3D, const 
   return st;
 }
 
+/* Test diagnostics (not part of the restated algorithm): how close does ANY per-pixel decision of the compositing loop
+ * above come to its threshold? Re-walks the loop of orc_forward and returns the smallest relative distances
+ *   out[0]: |alpha * 255 - 1|          over the pairs that reach the alpha test  (skip if alpha < 1/255)
+ *   out[1]: |test_T / 1e-4 - 1|        over the pairs that reach the transmittance test (stop if test_T < 1e-4)
+ *   out[2]: |power|                    over the pairs with |power| < 1e-3 (skip if power > 0)
+ * A float32 implementation that evaluates alpha with another exponential (v_exp_f32 on 2^x vs expf) differs from this one
+ * by a few ulps: a decision closer than that to its threshold may legitimately fall the other way, and the gradients of
+ * the splat concerned then differ at the 1/255 level. tests/ uses this to tell such a flip from a defect. */
+void orc_decision_margins(const OrcState* st, const OrcFrame* f, double out[3]) {
+  const int W = st->W, H = st->H, TX = st->TX;
+  const int64_t T = (int64_t)st->TX * st->TY;
+  double m_alpha = 1e30, m_T = 1e30, m_pow = 1e30;
+  for (int64_t t = 0; t < T; ++t) {
+    int tx0 = (int)(t % TX) * TILE, ty0 = (int)(t / TX) * TILE;
+    int64_t s = st->tile_start[t], e = st->tile_start[t + 1];
+    for (int py = ty0; py < ty0 + TILE && py < H; ++py)
+      for (int px = tx0; px < tx0 + TILE && px < W; ++px) {
+        int64_t pix = (int64_t)py * W + px;
+        float sx = (float)px, sy = (float)py;
+        if (f->subpix) { sx += f->subpix[pix * 2 + 0]; sy += f->subpix[pix * 2 + 1]; }
+        float Tr = 1.0f;
+        for (int64_t k = s; k < e; ++k) {
+          const OrcGeom* g = &st->g[st->list[k]];
+          float dx = g->mx - sx, dy = g->my - sy;
+          float power = -0.5f * (g->ca * dx * dx + g->cc * dy * dy) - g->cb * dx * dy;
+          if (fabsf(power) < 1e-3f && fabs((double)power) < m_pow) m_pow = fabs((double)power);
+          if (power > 0.0f) continue;
+          float alpha = fminf(0.99f, g->op * expf(power));
+          double da = fabs((double)alpha * 255.0 - 1.0);
+          if (da < m_alpha) m_alpha = da;
+          if (alpha < 1.0f / 255.0f) continue;
+          float test_T = Tr * (1.0f - alpha);
+          double dt = fabs((double)test_T / 1e-4 - 1.0);
+          if (dt < m_T) m_T = dt;
+          if (test_T < 0.0001f) break;
+          Tr = test_T;
+        }
+      }
+  }
+  out[0] = m_alpha; out[1] = m_T; out[2] = m_pow;
+}
+
 /* introspection for tests */
 void orc_get_counts(const OrcState* st, int64_t out[4]) {
   int64_t nvis = 0, maxlen = 0;

@@ -181,3 +181,22 @@ def test_tiled_torch_restatement_matches_the_c_oracle():
         assert np.linalg.norm(got - ref) <= 5e-4 * np.linalg.norm(ref), k
     got, ref = means2D.grad.numpy()[:, :2], G["means2D"][:, :2]
     assert np.linalg.norm(got - ref) <= 5e-4 * np.linalg.norm(ref)
+
+
+def test_decision_margins_report_a_pair_on_the_alpha_threshold():
+    """orc_decision_margins (test diagnostics): a splat centred on a pixel whose alpha there is 1/255 (1 + 3e-7) is
+    reported as a decision within ~3e-7 of its threshold (and power = 0 at the centre); far from every threshold the
+    margins are large. tests/test_gpu_raster.py uses them to tell a legitimate float32 flip from a defect."""
+    W, H = 32, 24
+    frame, g = scene(1, W, H, seed=1, zrange=(5., 5.), scale_range=(0.2, 0.2))
+    # pixel centres sit at integer coordinates: mean2D = ((ndc + 1) W - 1) / 2, so ndc = (1 / W, 1 / H) lands on (W / 2, H / 2)
+    g["means3D"] = torch.tensor([[5.0 * frame["tanfovx"] / W, 5.0 * frame["tanfovy"] / H, 5.0]])
+    R = orc.OracleRender(frame, **g)
+    mx, my, op_eff = R.geom()[0][0], R.geom()[0][1], R.geom()[0][5]
+    assert abs(mx - round(float(mx))) < 1e-3 and abs(my - round(float(my))) < 1e-3
+    far = R.decision_margins()
+    assert far["alpha"] > 1e-3
+    g2 = dict(g, opacities=g["opacities"] * float((1.0 / 255.0) / op_eff * (1.0 + 3e-7)))
+    near = orc.OracleRender(frame, **g2).decision_margins()
+    assert near["alpha"] < 2e-6, near
+    assert near["power"] < 1e-6
