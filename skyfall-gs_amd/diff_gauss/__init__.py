@@ -88,6 +88,18 @@ def _medium_on():
     return os.environ.get("SFGS_MEDIUM_LISTS", "1") != "0"   # A/B switch: 0 = frames with lists of 513 .. 1 024 take the split route
 
 
+def _next_huge(prev, num_huge_splats):
+    """The wrapper's huge-splat state after a frame: > 0 = the next frame launches the walk kernel (no NO_HUGE_SPLATS hint)."""
+    return HUGE_QUIET_FRAMES if num_huge_splats else max(prev - 1, 0)
+
+
+def _next_capacities(cap, ccap, D, cmax, over, pool_grown):
+    """(duplicate capacity, slab capacity) to plan the next frame of this viewport with, from the capacities this frame ran
+    with and what it needed (D duplicates + `over` slots of list alignment, cmax directly appended items in the fullest bin)."""
+    return (cap if pool_grown else max(int(D * 1.25) + 1024 + over, min(cap, max(2 * D + 1024 + over, int(cap * 0.97)))),
+            max(int(cmax * 1.5) + 256, min(ccap, max(3 * cmax + 256, int(ccap * 0.97)))))
+
+
 def _scratch_budget(dev):
     b = _budget.get(dev.index)
     if b is None:
@@ -388,16 +400,14 @@ class _Rasterize(torch.autograd.Function):
                 # walk kernel (5 us when it finds nothing) stays in for HUGE_QUIET_FRAMES frames -- a camera schedule that
                 # alternates between views with and without such splats (the IDU stage's mixed elevations) must not redo
                 # every other frame
-                hs["huge"] = HUGE_QUIET_FRAMES if cnt.num_huge_splats else max(hs["huge"] - 1, 0)
+                hs["huge"] = _next_huge(hs["huge"], int(cnt.num_huge_splats))
                 hs["cmax"] = int(cnt.max_bin_items)
                 hs["prefill_ran"] = False
             # next frame's capacities: 25 % / 50 % of headroom over this frame, never growing on their own, and SHRINKING
             # slowly (3 % per frame, down to twice / three times this frame's need): an overflowing plan costs a second plan +
             # render, and a camera schedule that alternates between light and heavy views (the IDU stage's mixed elevations)
             # must not overflow at every heavy one
-            _cap_hint[(di, W, H)] = (cap if pool_grown else
-                                     max(int(D * 1.25) + 1024 + over, min(cap, max(2 * D + 1024 + over, int(cap * 0.97)))),
-                                     max(int(cmax * 1.5) + 256, min(ccap, max(3 * cmax + 256, int(ccap * 0.97)))))
+            _cap_hint[(di, W, H)] = _next_capacities(cap, ccap, D, cmax, over, pool_grown)
             global _last_counters
             _last_counters = dict(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
                                   num_visible=int(cnt.num_visible), max_coarse_bin=cmax, max_bin_items=int(cnt.max_bin_items),

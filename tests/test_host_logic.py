@@ -153,3 +153,29 @@ def test_launch_hint_bits_match_the_c_header():
     assert all(v & (v - 1) == 0 for v in vals) and len(set(vals)) == len(vals)
     assert diff_gauss.SHORT_LIST_MAX <= 512 and diff_gauss.MEDIUM_LIST_MAX <= 1024   # what select_sort_kernel<512 / 1024> sort
     assert int(re.search(r"#define\s+SFGS_ABI_VERSION\s+(\d+)", hdr).group(1)) == L.ABI_VERSION
+
+
+def test_capacity_and_huge_splat_hints_follow_their_rules():
+    """The wrapper's per-viewport capacity hints and its huge-splat state (diff_gauss: _next_capacities, _next_huge) as pure
+    functions: headroom over the frame's need, no growth on their own, slow shrinking (3 % per frame, floors at 2x / 3x
+    the need), a quiet period after a frame with huge splats. The GPU side: tests/test_gpu_launch_hints.py."""
+    import diff_gauss as dg
+    over = 1088 * 2040
+    cap, ccap = dg._next_capacities(30_000_000, 4096, 6_000_000, 0, over, False)
+    assert cap == int(30_000_000 * 0.97) and ccap == int(4096 * 0.97)          # shrinking slowly, not snapping to the need
+    assert dg._next_capacities(10_000_000, 4096, 6_000_000, 0, over, False)[0] == 10_000_000   # below the 2x floor: kept
+    c, cc = 50_000_000, 100_000
+    for _ in range(400):                                                        # ... down to the floors
+        c, cc = dg._next_capacities(c, cc, 6_000_000, 1000, over, False)
+    assert c == 2 * 6_000_000 + 1024 + over and cc == 3 * 1000 + 256
+    cap, ccap = dg._next_capacities(8_000_000, 300, 7_500_000, 290, over, False)  # a tight fit: 25 % / 50 % of headroom
+    assert cap == int(7_500_000 * 1.25) + 1024 + over and ccap == int(290 * 1.5) + 256
+    assert dg._next_capacities(8_000_000, 300, 100, 0, over, True)[0] == 8_000_000   # a pool overran: keep the doubled room
+    assert dg._next_capacities(0, 0, 0, 0, over, False) == (1024 + over, 256)
+    h = 1                                                                       # first frame: nothing known, walk launched
+    seq = []
+    for n in (0, 0, 5, 0, 0, 0):
+        h = dg._next_huge(h, n)
+        seq.append(h)
+    q = dg.HUGE_QUIET_FRAMES
+    assert seq == [0, 0, q, q - 1, q - 2, q - 3] and q >= 8
