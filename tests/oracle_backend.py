@@ -73,6 +73,45 @@ class OracleBackend:
                                       raster_settings)
 
 
+class _OracleRasterizeAnyDevice(torch.autograd.Function):
+    """The same double for tensors on ANY device (the oracle copies its inputs to the host; outputs and gradients go back
+    to the inputs' device): lets the reference's real code run on `cuda` around the C oracle, so that a GPU test can
+    compare the HIP library with the oracle through the reference's own torch graph (tests/ref_real_driver.py)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, settings):
+        dev = means3D.device
+        R = orc.OracleRender(frame_from_settings(settings), means3D, scales, rotations, opacities,
+                             colors_precomp=colors_precomp, shs=shs)
+        color, depth, alpha = (torch.from_numpy(a.copy()).to(dev) for a in (R.color, R.depth, R.alpha))
+        radii = torch.from_numpy(R.radii.copy()).to(dev)
+        norm = torch.zeros(1, 1, 1, device=dev).expand(3, R.H, R.W)
+        ctx.mark_non_differentiable(radii, norm)
+        ctx.set_materialize_grads(False)
+        ctx.R, ctx.has_colors, ctx.has_shs, ctx.dev = R, colors_precomp is not None, shs is not None, dev
+        return color, depth, norm, alpha, radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_norm, g_alpha, g_radii):
+        G = ctx.R.backward(g_color, g_depth, g_alpha)
+        t = lambda k: torch.from_numpy(G[k]).to(ctx.dev)
+        return (t("means3D"), t("means2D"), t("shs") if ctx.has_shs else None,
+                t("colors_precomp") if ctx.has_colors else None, t("opacities"), t("scales"), t("rotations"), None)
+
+
+class OracleBackendAnyDevice:
+    name = "oracle-cpu behind device tensors (test double)"
+
+    @staticmethod
+    def check_device(t, name):
+        pass
+
+    @staticmethod
+    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, raster_settings):
+        return _OracleRasterizeAnyDevice.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                               raster_settings)
+
+
 @contextlib.contextmanager
 def installed():
     import diff_gauss

@@ -22,6 +22,7 @@ for p in $PASSES; do
     kt) timeout 300 rocprofv3 --kernel-trace --stats -d "$R/kt" -o kt -- python bench.py $ARGS > "$R/kt.log" 2>&1 ;;
     fetch) timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$R/fetch" -o fetch -- python bench.py $ARGS > "$R/fetch.log" 2>&1; DBS="$DBS $R/fetch/fetch_results.db" ;;
     write) timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$R/write" -o write -- python bench.py $ARGS > "$R/write.log" 2>&1; DBS="$DBS $R/write/write_results.db" ;;
+    sq2) timeout 300 rocprofv3 --kernel-trace --pmc $SQ2 -d "$R/sq2" -o sq2 -- python bench.py $ARGS > "$R/sq2.log" 2>&1; DBS="$DBS $R/sq2/sq2_results.db" ;;
     sq)
       timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 -d "$R/sq1" -o sq1 -- python bench.py $ARGS > "$R/sq1.log" 2>&1; DBS="$DBS $R/sq1/sq1_results.db"
       timeout 300 rocprofv3 --kernel-trace --pmc $SQ2 -d "$R/sq2" -o sq2 -- python bench.py $ARGS > "$R/sq2.log" 2>&1; DBS="$DBS $R/sq2/sq2_results.db"
