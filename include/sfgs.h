@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 15
+#define SFGS_ABI_VERSION 16
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -224,6 +224,22 @@ typedef struct SfgsRasterCounters {
 int sfgs_abi_version(void);
 const char* sfgs_last_error(void);
 
+/* Process-wide ROUTE options (ABI 16; tests and A/B runs -- never needed for correctness: every route builds bit-identical
+ * results, tests/test_gpu_raster.py). They replace the getenv() calls the library used to make on every render: the
+ * environment is read ONCE, when the library is loaded (SFGS_SORT, SFGS_PLAN_SCAN, SFGS_BINNING, SFGS_PREFILL, SFGS_KNN: same
+ * values),
+ * and changed afterwards only through this call. Thread-safe: one atomic word per option; a render running on another
+ * thread sees the old or the new value, never a mixture.
+ *   key "sort"       "auto" (the frame's launch hints decide) | "fused" | "fused1024" | "split"
+ *   key "plan_scan"  "fused" (the plan's epilogues ride in the scatter launch) | "separate"
+ *   key "binning"    "auto" (two-pass below 65 536 coarse bins) | "direct"
+ *   key "prefill"    "auto" (dead-entry prefill decided per frame on the device) | "always" | "never"
+ *   key "knn"        "auto" (spatial search above 4 096 points) | "brute" (the exact all-pairs kernel at every size)
+ * sfgs_set_option returns SFGS_E_ARG for an unknown key or value; sfgs_get_option returns the current value's name
+ * (a string constant) or NULL for an unknown key. */
+int sfgs_set_option(const char* key, const char* value);
+const char* sfgs_get_option(const char* key);
+
 /* Optional per-kernel timing (bench.py's roofline leg): when enabled, every kernel launch of the
  * library is bracketed by HIP events recorded on the launch stream. sfgs_profile_collect waits for
  * the recorded events, returns per-kernel summed milliseconds and launch counts (arrays of
@@ -292,8 +308,8 @@ int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* ge
  * from 8 disjoint ranges of [0, dup_capacity), so it spans the capacity, not the count
  * (sfgs_raster_sizes(N, W, H, dup_capacity, ..).dupgrad_bytes; the gaps are never touched). Every gradient tensor in `grads` is
  * fully overwritten. Deterministic (no float atomics). Asynchronous. Writes one word of the `tiles` header (whether
- * this frame's dead list entries were zero-filled in bulk; decided per frame on the device, environment variable
- * SFGS_PREFILL=always|never forces either path for tests: the gradients are bit-identical). */
+ * this frame's dead list entries were zero-filled in bulk; decided per frame on the device,
+ * sfgs_set_option("prefill", "always" | "never") forces either path for tests: the gradients are bit-identical). */
 int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                          const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
                          int64_t coarse_capacity, int64_t num_duplicates, const void* image, const float* dL_dcolor,

@@ -4,6 +4,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -18,6 +22,30 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- route options (sfgs_set_option) ----------------------------------------------------------------
+struct OptSpec { const char* key; const char* env; const char* values[5]; };
+static const OptSpec kOpts[OPT_COUNT] = {
+    {"sort", "SFGS_SORT", {"auto", "fused", "fused1024", "split", nullptr}},
+    {"plan_scan", "SFGS_PLAN_SCAN", {"fused", "separate", nullptr}},
+    {"binning", "SFGS_BINNING", {"auto", "direct", nullptr}},
+    {"prefill", "SFGS_PREFILL", {"auto", "always", "never", nullptr}},
+    {"knn", "SFGS_KNN", {"auto", "brute", nullptr}}};
+static std::atomic<int> g_opt[OPT_COUNT];
+static int opt_value(int which, const char* v) {
+  for (int i = 0; v && kOpts[which].values[i]; ++i)
+    if (!strcmp(v, kOpts[which].values[i])) return i;
+  return -1;
+}
+// the environment is read once, at load time (a value the option does not know leaves the default)
+static const bool g_opt_init = [] {
+  for (int k = 0; k < OPT_COUNT; ++k) {
+    const int v = opt_value(k, getenv(kOpts[k].env));
+    g_opt[k].store(v < 0 ? 0 : v, std::memory_order_relaxed);
+  }
+  return true;
+}();
+int option(int which) { return g_opt[which].load(std::memory_order_relaxed); }
 
 // ---- profiler: HIP events recorded on the launch stream around every kernel ---------------------
 static const char* const kKernelNames[KID_COUNT] = {
@@ -64,6 +92,24 @@ using namespace sfgs;
 
 extern "C" int sfgs_abi_version(void) { return SFGS_ABI_VERSION; }
 extern "C" const char* sfgs_last_error(void) { return sfgs::g_err; }
+
+extern "C" int sfgs_set_option(const char* key, const char* value) {
+  SFGS_REQUIRE(key && value, SFGS_E_ARG, "sfgs_set_option: NULL key / value");
+  for (int k = 0; k < OPT_COUNT; ++k)
+    if (!strcmp(key, kOpts[k].key)) {
+      const int v = opt_value(k, value);
+      SFGS_REQUIRE(v >= 0, SFGS_E_ARG, "sfgs_set_option: option \"%s\" has no value \"%s\"", key, value);
+      g_opt[k].store(v, std::memory_order_relaxed);
+      return SFGS_OK;
+    }
+  SFGS_REQUIRE(false, SFGS_E_ARG, "sfgs_set_option: unknown option \"%s\"", key);
+  return SFGS_E_ARG;
+}
+extern "C" const char* sfgs_get_option(const char* key) {
+  for (int k = 0; key && k < OPT_COUNT; ++k)
+    if (!strcmp(key, kOpts[k].key)) return kOpts[k].values[option(k)];
+  return nullptr;
+}
 
 extern "C" int sfgs_profile_kernel_count(void) { return KID_COUNT; }
 extern "C" const char* sfgs_profile_kernel_name(int32_t id) {

@@ -389,9 +389,8 @@ extern "C" int sfgs_knn_dist2(const float* xyz, int32_t N, float* out, void* scr
   SFGS_REQUIRE(xyz && out, SFGS_E_ARG, "NULL argument");
   hipStream_t stream = (hipStream_t)stream_;
   ProfScope ps_(KID_KNN, stream);
-  // SFGS_KNN=brute: test knob (the exact reference every size is compared with)
-  const char* mode = getenv("SFGS_KNN");
-  if (N <= KNN_BRUTE_MAX || (mode && !strcmp(mode, "brute"))) {
+  // option "knn" = "brute" (sfgs_set_option): test knob (the exact reference every size is compared with)
+  if (N <= KNN_BRUTE_MAX || option(OPT_KNN) != 0) {
     hipLaunchKernelGGL(knn_dist2_kernel, dim3((N + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), 0, stream, xyz, N, out);
     SFGS_POST_LAUNCH("knn_dist2", stream, 0);
     return SFGS_OK;

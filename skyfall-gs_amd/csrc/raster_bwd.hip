@@ -12,74 +12,25 @@
 //
 // Compile with -ffp-contract=off (the forward's alpha/skip decisions must be reproduced exactly; FMA
 // only where spelled fmaf, identically to raster_fwd.hip).
-#include <stdlib.h>
-
-#include <cstdlib>
 #include <cstring>
-#include <type_traits>
 
 #include "act_math.h"
 #include "sfgs_internal.h"
 
-// Ablation builds (tools/ablate_bwd.sh; never the shipped library): -DSFGS_BWD_ABLATE=<bits> removes one part of
-// composite_bwd so that its cost INSIDE the kernel (with the overlap the other waves provide) can be read off a timing:
-//   1 no zero fill of UW   2 no phase 1 (no pixel has a blended entry)   4 no phase-2 slot loop   8 no record stores
-//  16 no record gathers (every batch reuses the first one's records)
-#ifndef SFGS_BWD_ABLATE
-#define SFGS_BWD_ABLATE 0
-#endif
-// Round-4 experiment knobs (tools/ablate_bwd.sh; profiles/r4_bwd_*_ab.txt hold what each measured):
-//   -DSFGS_BWD_LDS_PAD=<bytes>  extra LDS per wave: lowers the resident waves per CU without touching the code -- the
-//                               slope d(time) / d(waves) says what MORE waves could buy at most
-//   -DSFGS_BWD_PRIO=1|2         s_setprio: 1 = phase 1 (the dependent exp / rcp chains) runs at raised priority, 2 = phase 2
-//   -DSFGS_BWD_ZEROFILL         the round-3 scheme: the wave zero-fills the 16 x 65 (u, w) matrix before every batch and phase
-//                               2 reads it with plain ds_read_b64. Shipped since round 4: phase 2 fetches its pairs with
-//                               ds_wrxchg_rtn_b64 (exchange with zero), which leaves the matrix zeroed for the next batch --
-//                               17 LDS stores per batch less, 98 -> 93 VGPRs (profiles/r4_bwd_ab.txt: 0.397 -> 0.383 ms)
-#ifndef SFGS_BWD_LDS_PAD
-#define SFGS_BWD_LDS_PAD 0
-#endif
-#ifndef SFGS_BWD_PRIO
-#define SFGS_BWD_PRIO 0
-#endif
-#if !defined(SFGS_BWD_ZEROFILL)
-#define SFGS_BWD_XCHG 1
-#endif
-//   -DSFGS_BWD_ROWSYM=1         phase 2 (grid case) forms the raw moments of a pixel row from symmetric pairs (phase2_grid_row)
-//   -DSFGS_P1_TAIL=1            phase 1: two entries per iteration while any lane has two left, then ONE single-entry step
-//   -DSFGS_BWD_LDS18=1          VERDICT r3 item 1a, built to be MEASURED (needs -DSFGS_COMPOSITE_WG_WAVES=1): exactly 8 960 bytes of
-//                               LDS per one-wave workgroup = 7 allocation granules = 18 waves per CU instead of 16: 40-byte staged
-//                               records (no ex / ey), no dummy row and no dummy record -- the (u, w) rows are stored in REVERSE
-//                               order at offset 0, so the exhausted lanes' dummy writes land at NEGATIVE offsets, and the dummy
-//                               record lies right behind the last record = the end of the allocation: both out of range, where
-//                               the hardware drops writes and returns zeros (probed: tools/microbench/lds_probe.hip,
-//                               profiles/r4_lds_probe.txt). Rests on that undocumented behaviour: an experiment, never shipped.
-#ifndef SFGS_BWD_LDS18
-#define SFGS_BWD_LDS18 0
-#endif
-//   -DSFGS_BWD_STORE3=0         the round-3 record stores: the combine step left float 4 k + row of the record in lane (entry,
-//                               row) of register k, i.e. three dword stores 16 bytes apart per lane. Shipped since round 4
-//                               (STORE3 = 1): the network's inputs are permuted so that the lane holds floats 3 row .. 3 row + 2 --
-//                               ONE global_store_dwordx3 per lane, an entry's four lanes cover its 48 contiguous bytes with one
-//                               instruction. Same sums, same bits; composite_bwd 0.406 -> 0.353 ms (profiles/r4_bwd_store3_ab.txt):
-//                               the kernel was paying for 48 store instructions' worth of address processing per batch.
-#ifndef SFGS_BWD_STORE3
-#define SFGS_BWD_STORE3 1
-#endif
-//   -DSFGS_BWD_GATHER48=0       the round-3 gathers: three 16-byte loads per entry by 16 lanes and three LDS staging writes. Shipped
-//                               since round 4 (GATHER48 = 1): ONE gather instruction per batch -- 48 lanes = 16 entries x 3 pieces,
-//                               adjacent lanes on adjacent pieces, i.e. one 48-byte request per record instead of three 16-byte
-//                               ones -- staged with one contiguous LDS write; bit-identical, 0.364 -> 0.353 ms
-//                               (profiles/r4_gather48_ab.txt)
-#ifndef SFGS_BWD_GATHER48
-#define SFGS_BWD_GATHER48 (SFGS_BWD_LDS18 ? 0 : 1)
-#endif
-#ifndef SFGS_BWD_ROWSYM
-#define SFGS_BWD_ROWSYM 0
-#endif
-#ifndef SFGS_P1_TAIL
-#define SFGS_P1_TAIL 0
-#endif
+// Variants that were built, measured and NOT kept live as patches / A/B files, not in this source (tools/build_variant.sh
+// applies tools/variants/*.patch to a scratch copy):
+//   ablation bits (no phase 1 / phase 2 / stores / gathers / exp / rcp), registers instead of DPP for the upstream
+//     gradients                                                  tools/variants/bwd_lab_r5.patch, profiles/r5_bwd_ablation_matrix_ab.txt
+//   per-batch zero fill of UW instead of ds_wrxchg_rtn_b64        profiles/r4_bwd_ab.txt
+//   three dword record stores 16 B apart instead of one dwordx3   profiles/r4_bwd_store3_ab.txt
+//   three 16-byte gathers per entry instead of one 48-lane gather profiles/r4_gather48_ab.txt
+//   batches of 8 entries (20 waves / CU)                          profiles/r4_bwd_batch8_ab_not_kept.txt
+//   18 waves / CU on exactly 8 960 B of LDS (out-of-range dummies) profiles/r4_bwd_lds18_ab_not_kept.txt, r4_lds_probe.txt
+//   packed FP32 in phase 2 (v_pk_fma_f32)                         profiles/r4_bwd_pk2_ab_not_kept.txt
+//   row moments from symmetric pixel pairs, single-entry last phase-1 round, s_setprio around either phase, LDS padding
+//     (occupancy sensitivity)                                     profiles/r4_bwd_trims_ab.txt, r4_bwd_ab.txt
+//   1 / 2 / 8 / 16-wave workgroups                                profiles/r4_bwd_wg_waves_ab_not_kept.txt
+//   phase-1 software pipelining, 3 / 4 entries per iteration      profiles/r3_bwd_p1pipe_ab_not_kept.txt, r3_bwd_phase1_entries_per_iteration_ab_not_kept.txt
 
 namespace sfgs {
 
@@ -91,8 +42,10 @@ namespace sfgs {
 //            OWN set bits of the batch (most significant first = back to front), reads that entry's record from the
 //            LDS stage with a per-lane address, advances the pixel's transmittance / "colour behind" recurrences and
 //            stores the two scalars all 12 gradients derive from -- u = G dL/dalpha and w = alpha T -- into
-//            wave-private LDS matrices U[j][p], Wm[j][p] (zero-filled per batch; row stride 65: both the pixel-major
-//            writes and the entry-major reads below are bank-conflict free). The wave leaves the phase after
+//            the wave-private LDS matrix UW[j][p] (row stride 65 pairs: phase 2's entry-major reads are bank-conflict free;
+//            phase 1's writes are not -- every lane writes the row of ITS entry, bank = 2 (j_p + p) mod 32, ~3-way per
+//            16-lane group: all of the kernel's 21 % LDS conflict cycles, profiles/r5_bwd_ablation_matrix_ab.txt; a
+//            stride that fixes the writes makes the reads 16-way). The wave leaves the phase after
 //            max_p popcount steps: 0.44 B on the headline scene instead of B (tools/workmodel), and no pair is
 //            re-tested (no compare / select chain; the forward's decisions are replayed bit for bit).
 //   phase 2 (lane = entry j, 64/B lanes per entry each owning B pixels): accumulate the 12 sums over pixels in
@@ -104,28 +57,12 @@ template <int B>
 struct alignas(16) BwdLds {
   static constexpr int ROW = 65;
   // UW[j][p] = (u, w) of entry j at pixel p; row B is a dummy row (written by lanes that have no blended entry left in
-  // the batch, never read). Row stride 65 pairs: the pixel-major 8-byte writes and the entry-major 8-byte reads of
-  // phase 2 are both bank-conflict free on the 64-bank LDS.
-#if SFGS_BWD_LDS18
-  static constexpr int REC_BYTES = 40;          // (mx, my, qa, qb) (qc, op, r, g) (b, depth): what the backward reads
-  static constexpr bool REVERSED = true;        // UW row of entry j = B - 1 - j (see SFGS_BWD_LDS18 above)
-  float2 UW[B * ROW];
-  float recs[B * 10];
-#else
+  // the batch, never read). Row stride 65 pairs: the entry-major 8-byte reads of phase 2 are bank-conflict free on the
+  // 64-bank LDS.
   static constexpr int REC_BYTES = 48;
-  static constexpr bool REVERSED = false;
   float2 UW[(B + 1) * ROW];
   float4 recs[(B + 1) * 3];   // staged records of the batch; record B is all zeros (the dummy entry: alpha = 0)
-#endif
-#if SFGS_BWD_LDS_PAD > 0
-  float4 pad[SFGS_BWD_LDS_PAD / 16];   // occupancy experiment only
-#endif
-  // index of entry j's row in UW
-  static __device__ __forceinline__ constexpr int row_of(int j) { return REVERSED ? B - 1 - j : j; }
 };
-#if SFGS_BWD_LDS18
-static_assert(sizeof(BwdLds<16>) == 8960 && BWG_WAVES == 1, "SFGS_BWD_LDS18: 7 LDS granules per one-wave workgroup");
-#endif
 
 // value of lane I of the caller's 16-lane row, broadcast to the whole row (DPP row_newbcast; folds into
 // the consuming VALU instruction). Phase 2 uses it to read per-PIXEL registers (sample position, upstream
@@ -221,131 +158,6 @@ __device__ __forceinline__ void phase2_grid_step(Phase2Grid& a, float u, float w
   }
 }
 
-// -DSFGS_BWD_PK2=1 (round 4, experiment): the same step with PACKED FP32 -- (S, X) advance in one v_pk_fma_f32 ((u, u) x
-// (1, cx) + (S, X): the (u, w) pair the LDS exchange returned is the first operand, op_sel takes u for both halves) and
-// (lx, ly) = (-cA, -cB) cx + (kx, ky) in another: 9 instead of 11 VALU instructions per pixel, the same values bit for bit
-// (u x 1 + S is S + u).
-typedef float v2f32 __attribute__((ext_vector_type(2)));
-struct Phase2GridPk {
-  v2f32 SX0, SX1;
-  float XX0, XX1, ax, ay, r, g, b, d;
-};
-template <int I>
-__device__ __forceinline__ void phase2_grid_step_pk(Phase2GridPk& a, v2f32 uw, v2f32 ncAB, v2f32 k0, v2f32 k1, float g0,
-                                                    float g1, float g2, float g3) {
-  constexpr float cx = (float)(I & 7) - 3.5f;
-  const v2f32 c = {1.0f, cx};
-  const float u = uw.x, w = uw.y;
-  v2f32& SX = I < 8 ? a.SX0 : a.SX1;
-  float& XX = I < 8 ? a.XX0 : a.XX1;
-  if constexpr ((I & 7) == 0) {
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(SX) : "v"(uw), "s"(c));
-    XX = u * (cx * cx);
-  } else {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(SX) : "v"(uw), "s"(c));
-    XX = fmaf(u, cx * cx, XX);
-  }
-  v2f32 l;
-  if constexpr (I < 8) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(l) : "v"(ncAB), "s"(c), "v"(k0));
-  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(l) : "v"(ncAB), "s"(c), "v"(k1));
-  if constexpr (I == 0) {
-    a.ax = fabsf(u) * fabsf(l.x);
-    a.ay = fabsf(u) * fabsf(l.y);
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.r) : "v"(g0), "v"(w), "n"(I));
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.g) : "v"(g1), "v"(w), "n"(I));
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.b) : "v"(g2), "v"(w), "n"(I));
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.d) : "v"(g3), "v"(w), "n"(I));
-  } else {
-    a.ax = fmaf(fabsf(u), fabsf(l.x), a.ax);
-    a.ay = fmaf(fabsf(u), fabsf(l.y), a.ay);
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(I));
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(I));
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(I));
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(I));
-  }
-}
-#ifndef SFGS_BWD_PK2
-#define SFGS_BWD_PK2 0
-#endif
-
-// One pixel ROW (8 pixels) of a lane's group at once (-DSFGS_BWD_ROWSYM, round 4): the columns are symmetric about the
-// tile centre (cx_i = -cx_{7-i}), so with P_i = u_i + u_{7-i}, M_i = u_i - u_{7-i} (i = 0..3) the three raw moments are
-//   S = sum P_i,   X = sum cx_i M_i,   XX = sum cx_i^2 P_i          -- 8 + 3 + 4 + 4 = 19 instructions instead of 24.
-// The |.| sums and the colour sums stay per pixel (phase2_grid_step's forms).
-template <int R>
-__device__ __forceinline__ void phase2_grid_row(Phase2Grid& a, const float2 (&uw)[8], float ncA, float ncB, float kx,
-                                                float ky, float g0, float g1, float g2, float g3) {
-  const float P0 = uw[0].x + uw[7].x, P1 = uw[1].x + uw[6].x, P2 = uw[2].x + uw[5].x, P3 = uw[3].x + uw[4].x;
-  const float M0 = uw[0].x - uw[7].x, M1 = uw[1].x - uw[6].x, M2 = uw[2].x - uw[5].x, M3 = uw[3].x - uw[4].x;
-  const float S = (P0 + P1) + (P2 + P3);
-  const float X = fmaf(-3.5f, M0, fmaf(-2.5f, M1, fmaf(-1.5f, M2, -0.5f * M3)));
-  const float XX = fmaf(12.25f, P0, fmaf(6.25f, P1, fmaf(2.25f, P2, 0.25f * P3)));
-  if constexpr (R == 0) { a.S0 = S; a.X0 = X; a.XX0 = XX; } else { a.S1 = S; a.X1 = X; a.XX1 = XX; }
-#define SFGS_ROWPX(I)                                                                                                  \
-  {                                                                                                                    \
-    constexpr float cx = (float)(I) - 3.5f;                                                                            \
-    const float lx = fmaf(ncA, cx, kx), ly = fmaf(ncB, cx, ky);                                                        \
-    const float u = uw[I].x, w = uw[I].y;                                                                              \
-    if constexpr (R == 0 && (I) == 0) {                                                                                \
-      a.ax = fabsf(u) * fabsf(lx); a.ay = fabsf(u) * fabsf(ly);                                                        \
-      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.r) : "v"(g0), "v"(w), "n"(R * 8 + (I))); \
-      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.g) : "v"(g1), "v"(w), "n"(R * 8 + (I))); \
-      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.b) : "v"(g2), "v"(w), "n"(R * 8 + (I))); \
-      asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a.d) : "v"(g3), "v"(w), "n"(R * 8 + (I))); \
-    } else {                                                                                                           \
-      a.ax = fmaf(fabsf(u), fabsf(lx), a.ax); a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);                                  \
-      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.r) : "v"(g0), "v"(w), "n"(R * 8 + (I))); \
-      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.g) : "v"(g1), "v"(w), "n"(R * 8 + (I))); \
-      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.b) : "v"(g2), "v"(w), "n"(R * 8 + (I))); \
-      asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a.d) : "v"(g3), "v"(w), "n"(R * 8 + (I))); \
-    }                                                                                                                  \
-  }
-  SFGS_ROWPX(0) SFGS_ROWPX(1) SFGS_ROWPX(2) SFGS_ROWPX(3) SFGS_ROWPX(4) SFGS_ROWPX(5) SFGS_ROWPX(6) SFGS_ROWPX(7)
-#undef SFGS_ROWPX
-}
-
-// ---- batches of EIGHT entries (composite_bwd_kernel<8>; VERDICT r3 item 1b: built to be MEASURED) ---------------------------
-// 8 entries x 8 pixel groups: lane = (entry ej = lane & 7, pixel row grp = lane >> 3), eight pixels per lane. The (u, w)
-// matrix is 9 x 65 pairs = 4.7 KB per wave (LDS no longer limits the occupancy: the registers do, at 5 waves per SIMD), but
-// a DPP row of 16 lanes now hosts TWO pixel rows, so the upstream gradients of pixel (grp, I) come from lane I of the row
-// for the even group and from lane 8 + I for the odd one: two bank-masked v_fmac_dpp per (pixel, channel) instead of one.
-struct Phase2Grid8 {
-  float S, X, XX, ax, ay, r, g, b, d;
-};
-
-template <int I>
-__device__ __forceinline__ void phase2_grid8_step(Phase2Grid8& a, float u, float w, float ncA, float ncB, float kx,
-                                                  float ky, float g0, float g1, float g2, float g3) {
-  constexpr float cx = (float)I - 3.5f;
-  const float lx = fmaf(ncA, cx, kx), ly = fmaf(ncB, cx, ky);
-  if constexpr (I == 0) {
-    a.S = u; a.X = u * cx; a.XX = u * (cx * cx);
-    a.ax = fabsf(u) * fabsf(lx); a.ay = fabsf(u) * fabsf(ly);
-  } else {
-    a.S += u; a.X = fmaf(u, cx, a.X); a.XX = fmaf(u, cx * cx, a.XX);
-    a.ax = fmaf(fabsf(u), fabsf(lx), a.ax); a.ay = fmaf(fabsf(u), fabsf(ly), a.ay);
-  }
-  // even pixel rows sit in lanes 0..7 of their DPP row (banks 0, 1), odd ones in lanes 8..15 (banks 2, 3)
-#define SFGS_FMAC8(ACC, G)                                                                                              \
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3" : "+v"(ACC) : "v"(G), "v"(w), "n"(I));     \
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xc" : "+v"(ACC) : "v"(G), "v"(w), "n"(8 + I));
-  SFGS_FMAC8(a.r, g0) SFGS_FMAC8(a.g, g1) SFGS_FMAC8(a.b, g2) SFGS_FMAC8(a.d, g3)
-#undef SFGS_FMAC8
-}
-
-__device__ __forceinline__ Phase2Acc phase2_grid8_finish(const Phase2Grid8& a, float mxl, float dy0) {
-  Phase2Acc o;
-  const float t = mxl * a.S - a.X;   // sum u dx
-  o.u = a.S;
-  o.x = t;
-  o.y = dy0 * a.S;
-  o.xx = mxl * (t - a.X) + a.XX;
-  o.xy = dy0 * t;
-  o.yy = (dy0 * dy0) * a.S;
-  o.ax = a.ax; o.ay = a.ay; o.r = a.r; o.g = a.g; o.b = a.b; o.d = a.d;
-  return o;
-}
-
 // raw moments -> the sums about the mean that Phase2Acc carries (mxl = m_x - tile centre x, dy_r = m_y - y of row r)
 __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, float mxl, float dy0, float dy1) {
   Phase2Acc o;
@@ -372,12 +184,11 @@ __device__ __forceinline__ Phase2Acc phase2_grid_finish(const Phase2Grid& a, flo
 // recs_top / uw_top: LDS byte offsets (the low 32 bits of a generic LDS address) of record B - 1 and of this pixel's slot
 // in row B - 1; both live in VGPRs across the loop (v_mad_i32_i24 takes one scalar operand: left to itself the compiler
 // re-materialises the wave's LDS base with a v_mov in every iteration).
-template <int K, int ROW, bool HAS_BG, int REC_BYTES, bool REVERSED>
+template <int K, int ROW, bool HAS_BG, int REC_BYTES>
 __device__ __forceinline__ void phase1_iter(PixelBwd& ps, unsigned& pm, unsigned recs_top, unsigned uw_top, float sx,
                                             float sy) {
-  typedef float v4f_a16 __attribute__((ext_vector_type(4)));
-  typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 40-byte records (SFGS_BWD_LDS18) are only 8-byte aligned
-  using v4f = std::conditional_t<REC_BYTES % 16 == 0, v4f_a16, v4f_a8>;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  static_assert(REC_BYTES % 16 == 0, "16-byte aligned staged records");
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) v4f* lds_c4;
   typedef const __attribute__((address_space(3))) v2f* lds_c2;
@@ -408,39 +219,27 @@ __device__ __forceinline__ void phase1_iter(PixelBwd& ps, unsigned& pm, unsigned
 #pragma unroll
   for (int q = 0; q < K; ++q) {
     v2f uw; uw.x = u[q]; uw.y = w[q];
-    *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], REVERSED ? 8 * ROW : -8 * ROW)) = uw;
+    *(lds_p2)(uintptr_t)(uw_top + (unsigned)__mul24(fb[q], -8 * ROW)) = uw;
   }
 }
 
 template <int B, bool HAS_BG>
 __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsigned pm, float sx, float sy, int lane) {
   constexpr int ROW = BwdLds<B>::ROW;
-#ifndef SFGS_P1_K
-#define SFGS_P1_K 2
-#endif
-  constexpr int K = SFGS_P1_K;
-  static_assert(B == 16 || B == 8, "left-aligned batch masks of B bits");
+  constexpr int K = 2;   // entries per iteration (3 and 4 measured slower: profiles/r3_bwd_phase1_entries_per_iteration_ab_not_kept.txt)
+  static_assert(B == 16, "left-aligned batch masks of B bits");
   constexpr int RB = BwdLds<B>::REC_BYTES;
-  constexpr bool REV = BwdLds<B>::REVERSED;
   unsigned recs_top = (unsigned)(uintptr_t)lds.recs + (unsigned)((B - 1) * RB);
-  unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(REV ? 0 : (B - 1) * ROW) + lane];   // row of entry B - 1 (fb = 0)
+  unsigned uw_top = (unsigned)(uintptr_t)&lds.UW[(B - 1) * ROW + lane];   // row of entry B - 1 (fb = 0)
   asm volatile("" : "+v"(recs_top), "+v"(uw_top));
   // the caller only enters with at least one blended entry in the wave (a batch without any skips the phase)
-#if SFGS_P1_TAIL
-  // pairs while ANY lane still has two entries; the odd last round is a single-entry step (half the instructions) instead of
-  // a pair whose second entry is a dummy in every lane
-  static_assert(K == 2, "SFGS_P1_TAIL pairs entries");
-  while (__ballot((pm & (pm - 1u)) != 0u) != 0ull) phase1_iter<2, ROW, HAS_BG, RB, REV>(ps, pm, recs_top, uw_top, sx, sy);
-  if (__ballot(pm != 0u) != 0ull) phase1_iter<1, ROW, HAS_BG, RB, REV>(ps, pm, recs_top, uw_top, sx, sy);
-#else
   do {
-    phase1_iter<K, ROW, HAS_BG, RB, REV>(ps, pm, recs_top, uw_top, sx, sy);
+    phase1_iter<K, ROW, HAS_BG, RB>(ps, pm, recs_top, uw_top, sx, sy);
   } while (__ballot(pm != 0u) != 0ull);
-#endif
 }
 
 template <int B>
-__global__ void __launch_bounds__(64 * BWG_WAVES, (B == 8 ? 20 : 16) / BWG_WAVES)   // 16 waves per CU (B = 8: 20, by registers)
+__global__ void __launch_bounds__(64 * BWG_WAVES, 16 / BWG_WAVES)   // 16 waves per CU (the LDS allows no more)
 composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
@@ -460,9 +259,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int tx = (int)(sb % SX) * BE + (wave % BE), ty = (int)(sb / SX) * BE + (wave / BE);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[lw];
-#if !SFGS_BWD_LDS18
   if (lane < 3) lds.recs[B * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy entry (see phase 1)
-#endif
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
@@ -491,7 +288,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
     pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
   }
-  static_assert(B == 16 || B == 8, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 row pairs, or 8 entries x 8 rows");
+  static_assert(B == 16, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 row pairs");
   // wave-uniform (same for the whole frame): with a black background the bg term of dL/dalpha vanishes identically
   const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
 
@@ -522,19 +319,16 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f);
   [[maybe_unused]] float4 n1 = n0, n2 = n0;
   unsigned dup_cur = 0, id_next = 0;
-#if SFGS_BWD_GATHER48
   // one gather INSTRUCTION per batch: lane = (entry g_rec = lane / 3, 16-byte piece g_piece = lane % 3) for lanes < 3 B, so
   // adjacent lanes fetch adjacent pieces of a record (one 48-byte request per record instead of three 16-byte ones from
   // three instructions) and the LDS stage is written with one contiguous ds_write_b128 (float4 index = lane)
-  static_assert(3 * B <= 64 && REC_F4 == 3 && !SFGS_BWD_LDS18, "GATHER48: 48-byte records, at most 21 entries per batch");
+  static_assert(3 * B <= 64 && REC_F4 == 3, "one gather instruction per batch: 48-byte records, at most 21 entries");
   const int g_rec = lane / 3, g_piece = lane - 3 * g_rec;
-#endif
   {
     const unsigned b0 = (unsigned)(nbatch - 1) * B;
     // the duplicate index of entry ej is needed by all four lanes (ej, row) of the entry: each stores a quarter of
     // the entry's gradient record (see the combine step)
     if ((unsigned)ej < kmax - b0) dup_cur = sorted_dup[s + b0 + ej];
-#if SFGS_BWD_GATHER48
     if (lane < 3 * B && (unsigned)g_rec < kmax - b0) {
       const unsigned id = sorted_id[s + b0 + g_rec];
       n0 = rec[REC_F4 * (size_t)id + g_piece];
@@ -542,15 +336,6 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     if (nbatch >= 2) {
       if (lane < 3 * B) id_next = sorted_id[s + b0 - B + g_rec];
     }
-#else
-    if ((unsigned)lane < kmax - b0) {
-      const unsigned id = sorted_id[s + b0 + lane];
-      n0 = rec[REC_F4 * (size_t)id]; n1 = rec[REC_F4 * (size_t)id + 1]; n2 = rec[REC_F4 * (size_t)id + 2];
-    }
-    if (nbatch >= 2) {
-      if (lane < B) id_next = sorted_id[s + b0 - B + lane];
-    }
-#endif
   }
   // hit-mask words of the tile's 64-entry groups (one uint2 per pixel and group), fetched one group ahead
   static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
@@ -563,9 +348,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   // prefetch loads: the s_waitcnt vmcnt(0) the compiler places at the loop's back edge (for the prefetched registers)
   // then only sees memory operations that had a whole batch of arithmetic to complete. Issued at the end of their own
   // iteration, the stores were waited for every batch (measured: the kernel had a 0.08 ms floor of pure store latency).
-#if defined(SFGS_BWD_XCHG)
   for (int i = lane; i < B * ROW; i += 64) lds.UW[i] = make_float2(0.f, 0.f);
-#endif
   float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats 3 row .. 3 row + 2 (row = lane >> 4)
   unsigned p_dup = 0;
   bool p_valid = false;
@@ -581,65 +364,27 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // this pixel's blended entries of the batch, LEFT-ALIGNED (phase1_walk): bit 32 - B + j <=> entry b0 + j
     const int moff = (bi % BPG) * B;   // the batch's first bit in the group's 64-bit word (wave-uniform)
     unsigned pm = (((moff & 32) ? mw.y : mw.x) >> (moff & 31)) << (32 - B);
-    if (SFGS_BWD_ABLATE & 2) pm = 0u;
-#if SFGS_BWD_LDS18
-    if ((unsigned)lane < cnt) {
-      float* rr = lds.recs + lane * 10;
-      rr[0] = n0.x; rr[1] = n0.y; rr[2] = n0.z; rr[3] = n0.w; rr[4] = n1.x; rr[5] = n1.y; rr[6] = n1.z; rr[7] = n1.w;
-      rr[8] = n2.x; rr[9] = n2.y;
-    }
-#elif SFGS_BWD_GATHER48
     if (lane < 3 * B && (unsigned)g_rec < cnt) lds.recs[lane] = n0;
-#else
-    if ((unsigned)lane < cnt) { lds.recs[lane * 3] = n0; lds.recs[lane * 3 + 1] = n1; lds.recs[lane * 3 + 2] = n2; }
-#endif
     if (bi >= 1) {  // batches below the last one are always full
-      if (!(SFGS_BWD_ABLATE & 16))
-#if SFGS_BWD_GATHER48
       if (lane < 3 * B) n0 = rec[REC_F4 * (size_t)id_next + g_piece];
-#else
-      if (lane < B) { n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2]; }
-#endif
       // the duplicate indices of the NEXT batch (needed only when its records are stored): loaded one batch ahead into
       // the register whose old value was copied (my_dup) at the top of this iteration. A two-deep rotation
       // (cur <- next <- load) made the compiler copy the freshly loaded value right away: an s_waitcnt vmcnt(0) directly
       // behind the record gathers, i.e. every wave sat out the full gather latency once per batch.
       dup_cur = sorted_dup[s + b0 - B + ej];
       if (bi >= 2) {
-#if SFGS_BWD_GATHER48
         if (lane < 3 * B) id_next = sorted_id[s + b0 - 2 * B + g_rec];
-#else
-        if (lane < B) id_next = sorted_id[s + b0 - 2 * B + lane];
-#endif
       }
     }
-    if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {  // the previous batch's gradient records
+    if (p_valid) {  // the previous batch's gradient records
       if constexpr (DG_F4 == 4) {   // one 16-byte quarter per lane: the entry's four lanes fill a 64-byte sector
         dupgrad[(size_t)p_dup * 4 + orow] = make_float4(pq0, pq1, pq2, 0.f);
       } else {
-#if SFGS_BWD_STORE3
         typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
         v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
         *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
-#else
-        float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + orow;
-        dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
-#endif
       }
     }
-#if !defined(SFGS_BWD_XCHG)
-    if (!(SFGS_BWD_ABLATE & 1))
-    {  // zero the B real rows of UW: pairs that were not blended contribute nothing in phase 2.
-       // (ds_write_addtid_b32 would do this at twice the LDS store rate -- the kernel drops from 0.49 to 0.46 ms -- but
-       // on gfx950 it does NOT add the workgroup's LDS base: with several workgroups per CU it writes into its
-       // neighbours' memory; tools/microbench/addtid_probe.hip)
-      float2* z = lds.UW;
-      constexpr int NZ = B * ROW;
-#pragma unroll
-      for (int i = 0; i < (NZ + 63) / 64; ++i)
-        if (i * 64 + lane < NZ) z[i * 64 + lane] = make_float2(0.f, 0.f);
-    }
-#endif
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 1: lane = pixel, each lane walks its own blended entries back to front -------------------------
@@ -648,18 +393,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     // then a no-op because last_alpha becomes 0; its (u, w) goes to the dummy row). No exec masking, no state copies:
     // the loop body is one straight basic block.
     if (__ballot(pm != 0u) != 0ull) {
-#if SFGS_BWD_PRIO == 1
-      __builtin_amdgcn_s_setprio(2);
-#endif
       if (has_bg) phase1_walk<B, true>(lds, ps, pm, sx, sy, lane);
       else phase1_walk<B, false>(lds, ps, pm, sx, sy, lane);
-#if SFGS_BWD_PRIO == 1
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
-#if SFGS_BWD_PRIO == 2
-    __builtin_amdgcn_s_setprio(2);
-#endif
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- phase 2: lane = (entry ej, pixel group grp) ------------------------------------------------
@@ -668,35 +404,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     Phase2Acc pa;
     float cA, cB, cC;
     {
-#if SFGS_BWD_LDS18
-      const float* rr = lds.recs + ej * 10;
-      const float4 r0 = make_float4(rr[0], rr[1], rr[2], rr[3]), r1 = make_float4(rr[4], 0.f, 0.f, 0.f);
-#else
       const float4 r0 = lds.recs[ej * 3], r1 = lds.recs[ej * 3 + 1];
-#endif
       const float mx = r0.x, my = r0.y;
       cA = -2.0f * LN2 * r0.z; cB = -LN2 * r0.w; cC = -2.0f * LN2 * r1.x;
-      const float2* UWrow = &lds.UW[BwdLds<B>::row_of(ej) * ROW + grp * B];   // the lane's B pixels: rows 2 grp, 2 grp + 1 (B = 16) / row grp (B = 8)
+      const float2* UWrow = &lds.UW[ej * ROW + grp * B];   // the lane's 16 pixels: rows 2 grp, 2 grp + 1
       const float g0 = ps.gch[0], g1 = ps.gch[1], g2 = ps.gch[2], g3 = ps.gch[3];
-      if constexpr (B == 8) {
-        // (batches of 8 are an on-grid-only experiment: the host launches <8> only without a subpixel_offset tensor)
-        const float mxl = mx - ocx, dy0 = (my - ocy) - ((float)grp - 3.5f);
-        const float kx = fmaf(cA, mxl, cB * dy0), ky = fmaf(cC, dy0, cB * mxl);
-        const float ncA = -cA, ncB = -cB;
-        const float2 uw0 = uw_take(UWrow + 0), uw1 = uw_take(UWrow + 1), uw2 = uw_take(UWrow + 2), uw3 = uw_take(UWrow + 3);
-        const float2 uw4 = uw_take(UWrow + 4), uw5 = uw_take(UWrow + 5), uw6 = uw_take(UWrow + 6), uw7 = uw_take(UWrow + 7);
-        Phase2Grid8 p8;
-        p8.r = 0.f; p8.g = 0.f; p8.b = 0.f; p8.d = 0.f;
-        phase2_grid8_step<0>(p8, uw0.x, uw0.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<1>(p8, uw1.x, uw1.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<2>(p8, uw2.x, uw2.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<3>(p8, uw3.x, uw3.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<4>(p8, uw4.x, uw4.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<5>(p8, uw5.x, uw5.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<6>(p8, uw6.x, uw6.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        phase2_grid8_step<7>(p8, uw7.x, uw7.y, ncA, ncB, kx, ky, g0, g1, g2, g3);
-        pa = phase2_grid8_finish(p8, mxl, dy0);
-      } else
       // rolled loops over four 4-pixel groups (DPP controls are immediates, hence the switch): keeps the
       // compiler from hoisting all 32 LDS loads above the arithmetic, which costs ~30 VGPRs
       if (on_grid) {
@@ -705,70 +417,14 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
         const float kx0 = fmaf(cA, mxl, cB * dy0), kx1 = fmaf(cA, mxl, cB * dy1);
         const float ky0 = fmaf(cC, dy0, cB * mxl), ky1 = fmaf(cC, dy1, cB * mxl);
         const float ncA = -cA, ncB = -cB;
-#if SFGS_BWD_PK2
-        {
-          const v2f32 ncAB = {ncA, ncB}, k0 = {kx0, ky0}, k1 = {kx1, ky1};
-          Phase2GridPk pk;
-          auto take = [&](int i) { const float2 t = uw_take(UWrow + i); v2f32 r; r.x = t.x; r.y = t.y; return r; };
-#define SFGS_PK_LOAD(A, Bq, C, D) const v2f32 pw##A = take(A), pw##Bq = take(Bq), pw##C = take(C), pw##D = take(D);
-#define SFGS_PK(I) phase2_grid_step_pk<I>(pk, pw##I, ncAB, k0, k1, g0, g1, g2, g3)
-#define SFGS_PK_DO(A, Bq, C, D) SFGS_PK(A); SFGS_PK(Bq); SFGS_PK(C); SFGS_PK(D);
-#define SFGS_PK_FENCE asm volatile("" ::: "memory");
-          SFGS_PK_LOAD(0, 1, 2, 3)
-          SFGS_PK_LOAD(4, 5, 6, 7)
-          SFGS_PK_FENCE
-          SFGS_PK_DO(0, 1, 2, 3)
-          SFGS_PK_FENCE
-          SFGS_PK_LOAD(8, 9, 10, 11)
-          SFGS_PK_FENCE
-          SFGS_PK_DO(4, 5, 6, 7)
-          SFGS_PK_FENCE
-          SFGS_PK_LOAD(12, 13, 14, 15)
-          SFGS_PK_FENCE
-          SFGS_PK_DO(8, 9, 10, 11)
-          SFGS_PK_DO(12, 13, 14, 15)
-#undef SFGS_PK_LOAD
-#undef SFGS_PK
-#undef SFGS_PK_DO
-#undef SFGS_PK_FENCE
-          Phase2Grid pgk;
-          pgk.S0 = pk.SX0.x; pgk.X0 = pk.SX0.y; pgk.S1 = pk.SX1.x; pgk.X1 = pk.SX1.y; pgk.XX0 = pk.XX0; pgk.XX1 = pk.XX1;
-          pgk.ax = pk.ax; pgk.ay = pk.ay; pgk.r = pk.r; pgk.g = pk.g; pgk.b = pk.b; pgk.d = pk.d;
-          pa = phase2_grid_finish(pgk, mxl, dy0, dy1);
-        }
-#else
         Phase2Grid pg;
         // straight line, four pixels per LDS round trip (the asm fences keep the compiler from hoisting all sixteen
         // 8-byte loads above the arithmetic, which would cost ~30 VGPRs and the fourth wave per SIMD)
 #define SFGS_P2(I) phase2_grid_step<I>(pg, uw##I.x, uw##I.y, ncA, ncB, kx0, kx1, ky0, ky1, g0, g1, g2, g3)
-#if defined(SFGS_BWD_XCHG)
 #define SFGS_P2_LOAD(A, Bq, C, D) const float2 uw##A = uw_take(UWrow + A), uw##Bq = uw_take(UWrow + Bq), uw##C = uw_take(UWrow + C), uw##D = uw_take(UWrow + D);
-#else
-#define SFGS_P2_LOAD(A, Bq, C, D) const float2 uw##A = UWrow[A], uw##Bq = UWrow[Bq], uw##C = UWrow[C], uw##D = UWrow[D];
-#endif
 #define SFGS_P2_DO(A, Bq, C, D) SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D);
 #define SFGS_P2_FENCE asm volatile("" ::: "memory");
-        if (SFGS_BWD_ABLATE & 4) {
-          const float2 uw = UWrow[0];
-          pg = {uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y, uw.x, uw.y};
-        } else if (SFGS_BWD_ROWSYM) {
-          // a pixel row at a time: all 8 pairs of row 0 in flight, then row 1's while row 0 is consumed
-          SFGS_P2_LOAD(0, 1, 2, 3)
-          SFGS_P2_LOAD(4, 5, 6, 7)
-          SFGS_P2_FENCE
-          SFGS_P2_LOAD(8, 9, 10, 11)
-          SFGS_P2_LOAD(12, 13, 14, 15)
-          SFGS_P2_FENCE
-          {
-            const float2 row0[8] = {uw0, uw1, uw2, uw3, uw4, uw5, uw6, uw7};
-            phase2_grid_row<0>(pg, row0, ncA, ncB, kx0, ky0, g0, g1, g2, g3);
-          }
-          SFGS_P2_FENCE
-          {
-            const float2 row1[8] = {uw8, uw9, uw10, uw11, uw12, uw13, uw14, uw15};
-            phase2_grid_row<1>(pg, row1, ncA, ncB, kx1, ky1, g0, g1, g2, g3);
-          }
-        } else {
+        {
           // software-pipelined by hand: the next four pairs are in flight while four are consumed (8 more live registers;
           // the kernel's occupancy is set by its LDS, 4 waves per SIMD = 128 VGPRs each). The fences pin the order: left
           // alone the compiler issues every group's loads right in front of their first use.
@@ -791,14 +447,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #undef SFGS_P2_FENCE
 #undef SFGS_P2
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
-#endif
       } else {
         pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if defined(SFGS_BWD_XCHG)
 #define SFGS_P2(I) { const float2 t_ = uw_take(UWrow + I); phase2_step<I>(pa, t_.x, t_.y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3); }
-#else
-#define SFGS_P2(I) phase2_step<I>(pa, UWrow[I].x, UWrow[I].y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
-#endif
 #pragma nounroll
         for (int c = 0; c < 4; ++c) {
           switch (c) {
@@ -825,40 +476,25 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         // halves: lanes 0..31 get O[4k] summed over (row r, row r + 2), lanes 32..63 get O[4k+2]; likewise O[4k+1] / O[4k+3]
-#if SFGS_BWD_STORE3
         // rows 0..3 end up with O[k], O[3 + k], O[6 + k], O[9 + k]: lane (ej, row) holds floats 3 row .. 3 row + 2 of the record in
         // q[0..2] -- ONE 12-byte store per lane, the entry's four lanes cover its 48 contiguous bytes with one instruction
         const float s02 = swap32_add(O[k], O[6 + k]);
         const float s13 = swap32_add(O[3 + k], O[9 + k]);
-#else
-        const float s02 = swap32_add(O[4 * k], O[4 * k + 2]);
-        const float s13 = swap32_add(O[4 * k + 1], O[4 * k + 3]);
-#endif
         // rows: row 0 = O[4k], row 1 = O[4k+1], row 2 = O[4k+2], row 3 = O[4k+3], each summed over the four rows
         q[k] = swap16_add(s02, s13);
-        if constexpr (B == 8)   // ... and over the two pixel rows that share a DPP row (lanes i and i + 8)
-          q[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q[k]), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
       }
       pq0 = q[0]; pq1 = q[1]; pq2 = q[2]; p_dup = my_dup;
     }
-    p_valid = (unsigned)ej < cnt && (B == 16 || (grp & 1) == 0);   // B = 8: the even row's lanes store the (duplicated) sums
-#if SFGS_BWD_PRIO == 2
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    p_valid = (unsigned)ej < cnt;
     __builtin_amdgcn_wave_barrier();
   }
-  if (p_valid && (!(SFGS_BWD_ABLATE & 8) || pq0 == 1234.56f)) {
+  if (p_valid) {
     if constexpr (DG_F4 == 4) {
       dupgrad[(size_t)p_dup * 4 + orow] = make_float4(pq0, pq1, pq2, 0.f);
     } else {
-#if SFGS_BWD_STORE3
       typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
       v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
       *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
-#else
-      float* dst = reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + orow;
-      dst[0] = pq0; dst[4] = pq1; dst[8] = pq2;
-#endif
     }
   }
 }
@@ -1162,13 +798,10 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
 
 using namespace sfgs;
 
-// SFGS_PREFILL=always|never forces / forbids the dead-entry prefill (default: decided per frame on the device). Both
-// paths produce bit-identical gradients (tests/test_gpu_raster.py); the knob exists so that the tests can run each.
-static int prefill_mode() {
-  const char* e = getenv("SFGS_PREFILL");
-  if (!e) return 0;
-  return !strcmp(e, "always") ? 1 : !strcmp(e, "never") ? 2 : 0;
-}
+// option "prefill" = "always" | "never" (sfgs_set_option) forces / forbids the dead-entry prefill (default: decided per
+// frame on the device). Both paths produce bit-identical gradients (tests/test_gpu_raster.py); the option exists so that
+// the tests can run each. The kernel takes 0 = decide, 1 = always, 2 = never.
+static int prefill_mode() { return option(OPT_PREFILL); }
 
 extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                                     const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
@@ -1218,15 +851,10 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                        (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
                        (unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
-    // SFGS_BWD_B=8: the batches-of-8 form (experiment; sample points on the pixel grid only), see composite_bwd_kernel
-    static const bool b8 = [] { const char* e = getenv("SFGS_BWD_B"); return e && !strcmp(e, "8"); }();
-#define SFGS_LAUNCH_CBWD(BB)                                                                                               \
-    hipLaunchKernelGGL(composite_bwd_kernel<BB>, dim3(nblk * (BE * BE / BWG_WAVES)), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX, \
-                       nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth, \
-                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr,                                      \
-                       (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0)
-    if (b8 && !frame->subpixel_offset) SFGS_LAUNCH_CBWD(8); else SFGS_LAUNCH_CBWD(16);
-#undef SFGS_LAUNCH_CBWD
+    hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(nblk * (BE * BE / BWG_WAVES)), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX,
+                       nblk, tv.tile_range, bv.sorted_id, bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth,
+                       dL_dalpha, iv.hitmask, iv.tile_kmax, (float4*)dupgrad, tv.hdr,
+                       (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0);
   }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);

@@ -25,15 +25,11 @@
 
 namespace sfgs {
 
-#ifndef SFGS_PRE_REC_TRANSPOSE
-#define SFGS_PRE_REC_TRANSPOSE 0   // preprocess: the wave's records leave through LDS as lane-contiguous stores (A/B knob, round 4)
-#endif
-#ifndef SFGS_FWD_GATHER3
-#define SFGS_FWD_GATHER3 0   // composite_fwd: the batch's records fetched in piece order (adjacent lanes on adjacent 16-byte pieces)
-#endif
-#ifndef SFGS_FWD_STRIP_EXACT
-#define SFGS_FWD_STRIP_EXACT 0   // composite_fwd: exact ellipse-vs-pixel-row strip test (A/B knob, round 4)
-#endif
+// Variants built, measured and not kept (A/B files; the code is in the history, not in this source):
+//   preprocess: records leave through LDS as lane-contiguous stores         profiles/r4_preprocess_rec_transpose_ab_not_kept.txt
+//   composite_fwd: records gathered in piece order (the backward's trick)   profiles/r4_fwd_gather3_ab_not_kept.txt
+//   composite_fwd: exact ellipse-vs-pixel-row strip test                     profiles/r4_fwd_strip_exact_ab_not_kept.txt
+//   the plan's head cleared by hipMemsetAsync instead of zero_head_kernel    profiles/r4_plan_memset_ab.txt
 constexpr int REG_SORT_SMALL = 512;  // lists up to here: sort_tiles_reg_kernel (<= 8 keys per lane, 8 waves per SIMD)
 constexpr int REG_SORT_MAX = 1024;   // lists up to here: register network too (16 keys per lane), separate kernel
 
@@ -159,11 +155,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   bool big = false;                  // walk handled cooperatively by the wave (BIG_WALK < coarse bins < 64)
   bool huge = false;                 // >= 64 coarse bins: walked by big_walk_kernel
   const int lane = threadIdx.x & 63;
-#if SFGS_PRE_REC_TRANSPOSE
-  SplatRec r = {};   // every lane's record is stored
-#else
   SplatRec r;
-#endif
   BinRange br;
   float thr = 0.f;
   int cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;
@@ -220,13 +212,11 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         }
       }
       r = make_record(pr, opacity_in, rgb);
-#if !SFGS_PRE_REC_TRANSPOSE
       rec_out[REC_F4 * (size_t)g + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
       // (r, g) and (b, depth) sit in aligned pairs: the compositing loops fetch them with one 16-byte and one 8-byte
       // LDS read into the register pairs their packed multiply-adds take
       rec_out[REC_F4 * (size_t)g + 1] = make_float4(r.qc, r.op, r.r, r.g);
       rec_out[REC_F4 * (size_t)g + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
-#endif
       depth_bits = __float_as_uint(r.depth);
       br = bin_range(r, f.W, f.H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, bound);
       br.y0 = imax(br.y0, kf.band0); br.y1 = imax(br.y0, imin(br.y1, kf.band1));  // band rendering
@@ -256,28 +246,6 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
       }
     }
   }
-#if SFGS_PRE_REC_TRANSPOSE
-  {
-    // The wave's 64 records (48 bytes each, 3 KB contiguous in rec_out) leave through LDS so that every store instruction
-    // writes 64 ADJACENT 16-byte pieces (whole lines) instead of 64 pieces 48 bytes apart (experiment knob, round 4; the
-    // records of Gaussians that are not visible are written too -- nobody reads them)
-    static_assert(REC_F4 == 3, "48-byte records");
-    __shared__ float4 s_rec[PRE_BLOCK / 64][64 * 3];
-    float4* st = s_rec[threadIdx.x >> 6];
-    st[lane * 3 + 0] = make_float4(r.mx, r.my, r.qa, r.qb);
-    st[lane * 3 + 1] = make_float4(r.qc, r.op, r.r, r.g);
-    st[lane * 3 + 2] = make_float4(r.b, r.depth, r.ex, r.ey);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const size_t w0 = (size_t)(blockIdx.x * PRE_BLOCK + (threadIdx.x & ~63)) * 3;   // first float4 of the wave's records
-    const size_t wend = (size_t)N * 3;
-    if (__ballot(vis != 0u) != 0ull) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (w0 + (size_t)(k * 64 + lane) < wend) rec_out[w0 + k * 64 + lane] = st[k * 64 + lane];
-    }
-  }
-#endif
   // Mid-size splats (more than BIG_WALK, fewer than 64 coarse bins) are walked by the whole wave, lane = tile, instead
   // of serially by their owner thread.
   const unsigned long long big_lanes = __ballot(big);
@@ -452,13 +420,8 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
 // With one returning device atomic per (workgroup, bin) instead (first version of this round: 0.5 M atomics, all
 // workgroups hitting the same 2 040 counter lines at the same moment) the reservation alone took 36 of the pass's 73 us
 // (profiles/r3_bin_scatter_ablation.txt). The order of a bin's items is irrelevant (its tiles are sorted afterwards).
-#ifndef SFGS_SCATTER_ABLATE   // experiment builds only: 2 no sorted stores, 4 no position / store sweeps, 8 no counting
-#define SFGS_SCATTER_ABLATE 0
-#endif
-#ifndef SFGS_SCATTER_MLP
-#define SFGS_SCATTER_MLP 4
-#endif
-constexpr int SCATTER_NT = 1024, SCATTER_BINS = 4096, SCATTER_IDX = 15360, SCATTER_MLP = SFGS_SCATTER_MLP;
+// (ablation builds of this kernel -- no sorted stores / no sweeps / no counting: profiles/r3_bin_scatter_ablation.txt)
+constexpr int SCATTER_NT = 1024, SCATTER_BINS = 4096, SCATTER_IDX = 15360, SCATTER_MLP = 4;
 static_assert(SCATTER_BLOCKS * PAIRS_PER_BLOCK <= 65536, "16-bit pair indices");
 static_assert(SCATTER_BLOCKS <= 64, "one wave scans the block counts");
 
@@ -499,7 +462,6 @@ bin_count_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint32_
     const int nbins = min(SCATTER_BINS, NCB - r0);
     for (int i = tid; i < nbins; i += SCATTER_NT) { s_items[i] = 0u; s_hits[i] = 0u; }
     __syncthreads();
-    if (!(SFGS_SCATTER_ABLATE & 8))
     for (unsigned i0 = tid; i0 < total; i0 += SCATTER_MLP * SCATTER_NT) {   // independent loads in flight per thread
       unsigned w[SCATTER_MLP];
 #pragma unroll
@@ -529,11 +491,8 @@ constexpr int RANK_COLS = 16, RANK_GROUPS = 64;
 // Rank ORDER of the scatter workgroups inside a bin's slab: XCD-major (workgroup w runs on XCD w mod 8), so that the ~31
 // workgroups of one XCD own ONE contiguous stretch of every slab and its partial lines are completed inside that XCD's L2
 // instead of being written back piecemeal from eight of them. k-th in rank order -> workgroup (matrix row).
-#ifndef SFGS_RANK_XCD
-#define SFGS_RANK_XCD 1
-#endif
+// (rank order = workgroup order measured slower: profiles/r3_bin_rank_xcd_major_ab.txt)
 __device__ __forceinline__ int rank_row(int k, int NWG) {
-#if SFGS_RANK_XCD
   const int q = NWG >> 3, r = NWG & 7;               // XCDs x < r have q + 1 workgroups, the others q
   int x = 0, first = 0;                              // (compares instead of integer divisions)
 #pragma unroll
@@ -542,9 +501,6 @@ __device__ __forceinline__ int rank_row(int k, int NWG) {
     if (k >= st) { x = t; first = st; }
   }
   return (k - first) * 8 + x;
-#else
-  return k;
-#endif
 }
 __global__ void __launch_bounds__(RANK_COLS * RANK_GROUPS)
 bin_rank_kernel(int NWG, int NCB, const uint32_t* __restrict__ sc_cnt, const uint32_t* __restrict__ sc_hits,
@@ -671,7 +627,6 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
     __syncthreads();
     // sorted position of every pair; those beyond the index buffer (a workgroup with > 15 360 pairs in this round of bins)
     // are written at once, unsorted
-    if (!(SFGS_SCATTER_ABLATE & 4))
     for (unsigned i0 = tid; i0 < total; i0 += SCATTER_MLP * SCATTER_NT) {
       uint4 it[SCATTER_MLP];
 #pragma unroll
@@ -695,7 +650,7 @@ bin_scatter_kernel(int NB, int NCB, const uint4* __restrict__ pairs, const uint3
       }
     }
     __syncthreads();
-    const unsigned nsorted = (SFGS_SCATTER_ABLATE & 6) ? 0u : min(round_total, (unsigned)SCATTER_IDX);
+    const unsigned nsorted = min(round_total, (unsigned)SCATTER_IDX);
     for (unsigned q0 = tid; q0 < nsorted; q0 += SCATTER_MLP * SCATTER_NT) {
       uint4 it[SCATTER_MLP];
 #pragma unroll
@@ -1177,119 +1132,15 @@ sort_tiles_reg_kernel(int T8, const uint2* __restrict__ tile_range, const uint4*
 // per lane: the SHORT_LISTS form) or 1 024 (round 4: 48 KB, three workgroups per CU, the 16-key network for the lists
 // beyond 512 -- the MEDIUM_LISTS form for frames whose lists reach 513..1 024 entries, e.g. the reference's 45 / 25 degree
 // IDU cameras (arguments/__init__.py:238-249), which otherwise fell back to fine_bin + two sort kernels).
-// -DSFGS_SS_RADIX_MIN=256: select_sort_kernel<1024> sorts lists longer than that with the wave-level LDS radix sort below
-// instead of the register network (round 4 experiment, measured and NOT kept: profiles/r4_radix_sort_ab_not_kept.txt --
-// correct on every test and 150 soak configurations, low-elevation sort 0.325 -> 0.403 ms, dense 8 M 0.514 -> 0.492: its 64
-// serialised LDS round trips per list cost what the network's extra stages do). Default: never.
-#ifndef SFGS_SS_RADIX_MIN
-#define SFGS_SS_RADIX_MIN (1 << 30)
-#endif
+// (A wave-level LDS radix sort for the lists beyond 256 entries was built and measured in round 4 -- slower below ~700
+// entries, not kept: profiles/r4_radix_sort_ab_not_kept.txt.)
 template <int SS_CAP>
 struct alignas(16) SelectSortLds {
   unsigned long long key[SS_CAP];
   uint32_t pay[SS_CAP];
-  uint32_t cnt[(SS_CAP > 512 && SFGS_SS_RADIX_MIN < (1 << 30)) ? 256 : 4];   // digit counters of the radix sort (experiment builds)
+  uint32_t pad_[4];
 };
 
-// ---- wave-level LSD radix sort of a tile's list in LDS (round 4; select_sort_kernel<1024>, lists of 257 .. 1 024 entries) -----
-// The register bitonic network costs O(n log^2 n): 55 stages x 16 keys per lane for 1 024 entries (~8 800 instructions per
-// wave); a counting sort on the 32 depth bits is 4 passes of 8-bit digits at ~60 instructions per key and pass, and a pass
-// in which every key has the same digit (the top byte of depths that differ by less than a factor of two ...) is skipped.
-// One pass, stable: the wave holds the list in registers (element r of a lane = list position 64 r + lane), (1) counts the
-// digits with LDS atomics, (2) scans the 256 counters (4 per lane), (3) ranks position by position -- for every r the 64
-// lanes find their same-digit peers with 8 ballots (match-any), rank = the digit's running base + the number of peers in
-// lower lanes, the group's first lane advances the base --, (4) writes every element to its new position in the LDS list
-// (which nobody reads during the pass: the registers hold everything) and reads its strided elements back.
-// Equal depths (a clone sits exactly on its parent until the optimiser moves it) leave the order inside a run to the
-// arrival order of the LDS list; a final odd-even pass over neighbours with equal depth bits puts them in id order, which
-// makes the result the same total order as the network's: (depth bits, id).
-__device__ __forceinline__ unsigned long long match_any8(unsigned d, bool valid) {
-  unsigned long long peers = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long bal = __ballot(valid && bit);
-    peers &= bit ? bal : ~bal;
-  }
-  return peers;
-}
-
-template <int EPL, int SS_CAP>
-__device__ __forceinline__ void wave_radix_sort_lds(SelectSortLds<SS_CAP>& lds, int L, int lane) {
-  unsigned long long key[EPL];
-  unsigned pay[EPL];
-#pragma unroll
-  for (int r = 0; r < EPL; ++r) {
-    const int i = min(r * 64 + lane, SS_CAP - 1);
-    key[r] = lds.key[i]; pay[r] = lds.pay[i];
-  }
-  uint32_t* cnt = lds.cnt;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 32 + 8 * pass;
-    *reinterpret_cast<uint4*>(cnt + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int r = 0; r < EPL; ++r)
-      if (r * 64 + lane < L) atomicAdd(&cnt[(unsigned)(key[r] >> shift) & 0xffu], 1u);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const uint4 c = *reinterpret_cast<const uint4*>(cnt + 4 * lane);
-    const unsigned uL = (unsigned)L;
-    if (__ballot(c.x == uL || c.y == uL || c.z == uL || c.w == uL) != 0ull) continue;   // one digit holds every key
-    const unsigned tot = c.x + c.y + c.z + c.w;
-    const unsigned ex = wave_incl_scan_u32(tot) - tot;
-    __builtin_amdgcn_wave_barrier();
-    *reinterpret_cast<uint4*>(cnt + 4 * lane) = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    unsigned pos[EPL];
-#pragma unroll
-    for (int r = 0; r < EPL; ++r) {
-      const bool valid = r * 64 + lane < L;
-      const unsigned d = (unsigned)(key[r] >> shift) & 0xffu;
-      const unsigned long long peers = match_any8(d, valid);
-      const unsigned lower = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
-      const unsigned base = cnt[d];
-      pos[r] = base + lower;
-      __builtin_amdgcn_wave_barrier();                      // every peer has read the base before the group's first lane
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // moves it on
-      if (valid && lower == 0u) cnt[d] = base + (unsigned)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-#pragma unroll
-    for (int r = 0; r < EPL; ++r)
-      if (r * 64 + lane < L) { lds.key[pos[r]] = key[r]; lds.pay[pos[r]] = pay[r]; }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int r = 0; r < EPL; ++r) {
-      const int i = min(r * 64 + lane, SS_CAP - 1);
-      key[r] = lds.key[i]; pay[r] = lds.pay[i];
-    }
-  }
-  // the LDS list now holds the registers' content (also when every pass was skipped: it was never overwritten)
-  // ---- ties: neighbours with equal depth bits in id order (odd-even transposition, until a round swaps nothing) ----------
-  for (;;) {
-    bool swapped = false;
-#pragma unroll
-    for (int phase = 0; phase < 2; ++phase) {
-      for (int k = lane; 2 * k + phase + 1 < L; k += 64) {
-        const int p = 2 * k + phase;
-        const unsigned long long a = lds.key[p], b = lds.key[p + 1];
-        if ((unsigned)(a >> 32) == (unsigned)(b >> 32) && (unsigned)a > (unsigned)b) {
-          const unsigned pa = lds.pay[p], pb = lds.pay[p + 1];
-          lds.key[p] = b; lds.key[p + 1] = a; lds.pay[p] = pb; lds.pay[p + 1] = pa;
-          swapped = true;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    if (__ballot(swapped) == 0ull) break;
-  }
-}
 
 template <int SS_CAP>
 __global__ void __launch_bounds__(256)
@@ -1385,19 +1236,6 @@ select_sort_kernel(int TX8, int TY8, int CX, int NCB, uint32_t* __restrict__ coa
         store_list_entries<EPL>(sorted_dup + s + lane * EPL, pay);
       }
     };
-    if constexpr (SS_CAP > 512 && SFGS_SS_RADIX_MIN < (1 << 30)) {
-      if (L > SFGS_SS_RADIX_MIN) {   // the radix sort of the long lists (wave_radix_sort_lds above): sorted IN the LDS list
-        if (L <= 512) wave_radix_sort_lds<8, SS_CAP>(lds, L, lane);
-        else wave_radix_sort_lds<16, SS_CAP>(lds, L, lane);
-        const unsigned s = (unsigned)bin_base + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
-        if (lane == 0) tile_range[t] = make_uint2(s, c);
-        for (int i = lane; i < L; i += 64) {
-          sorted_id[s + i] = (unsigned)(lds.key[i] & 0xffffffffull);
-          sorted_dup[s + i] = lds.pay[i];
-        }
-        return;
-      }
-    }
     if (L <= 64) finish(std::integral_constant<int, 1>{});
     else if (L <= 128) finish(std::integral_constant<int, 2>{});
     else if (L <= 256) finish(std::integral_constant<int, 4>{});
@@ -1509,10 +1347,7 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
   // barrier-separated LDS steps, over 8 192 entries 23 of its 91 steps went through global memory; this needs three
   // barriers and log^2(512) = 45 register steps per segment. Falls back to the network when one bin alone exceeds SEG
   // (a list concentrated in < 0.4 % of its own depth range) or all depths are equal.
-#ifndef SFGS_BK_SEG
-#define SFGS_BK_SEG 512
-#endif
-  constexpr int BK_BINS = 256, SEG = SFGS_BK_SEG, BK_CAP = 2 * CAP;
+  constexpr int BK_BINS = 256, SEG = 512, BK_CAP = 2 * CAP;
   uint32_t* bk_depth = reinterpret_cast<uint32_t*>(k);          // [BK_CAP] depth bits, grouped by bin
   uint16_t* bk_pos = reinterpret_cast<uint16_t*>(pl);           // [BK_CAP] position in the tile's item segment
   __shared__ unsigned bk_hist[BK_BINS], bk_start[BK_BINS + 1], bk_red[2 * (NT / 64)];
@@ -1797,26 +1632,6 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   float4* st = stage[lw];
   // Software pipeline over batches of 64 list entries: the (dependent) id -> record gathers of batch i+1
   // are issued before batch i is composited, so their latency hides behind ~1600 VALU instructions.
-#if SFGS_FWD_GATHER3
-  // The batch's 64 records = 192 sixteen-byte pieces, fetched by three instructions in PIECE order: lane holds pieces
-  // 64 k + lane (k = 0, 1, 2), i.e. adjacent lanes fetch adjacent pieces of a record -- one 48-byte request per record
-  // instead of three 16-byte ones from three instructions -- and the LDS stage is written contiguously (float4 index =
-  // piece index). Round 4, with composite_bwd's GATHER48 (profiles/r4_gather48_ab.txt).
-  static_assert(REC_F4 == 3 && !SFGS_FWD_STRIP_EXACT, "48-byte records");
-  float4 nq[3];
-  unsigned idq[3];
-  unsigned q_rec[3], q_piece[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const unsigned q = 64u * k + (unsigned)lane;
-    q_rec[k] = q / 3u; q_piece[k] = q - 3u * q_rec[k];
-    nq[k] = make_float4(0.f, 0.f, 0.f, 0.f); idq[k] = 0u;
-    if (s + q_rec[k] < e) nq[k] = rec[REC_F4 * (size_t)sorted_id[s + q_rec[k]] + q_piece[k]];
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    if (s + 64 + q_rec[k] < e) idq[k] = sorted_id[s + 64 + q_rec[k]];
-#else
   float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
   unsigned id_next = 0;
   if (s + lane < e) {
@@ -1824,37 +1639,17 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     n0 = rec[REC_F4 * (size_t)id]; n1 = rec[REC_F4 * (size_t)id + 1]; n2 = rec[REC_F4 * (size_t)id + 2];
   }
   if (s + 64 + lane < e) id_next = sorted_id[s + 64 + lane];
-#endif
   for (unsigned b = s; b < e; b += 64) {
     if (__ballot(ps.T > 0.f) == 0ull) break;  // every pixel of the tile is saturated
     const unsigned cnt = min(64u, e - b);
-#if SFGS_FWD_GATHER3
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st[64 * k + lane] = nq[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)   // prefetch: records of the next batch, ids of the one after
-      if (b + 64 + q_rec[k] < e) nq[k] = rec[REC_F4 * (size_t)idq[k] + q_piece[k]];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (b + 128 + q_rec[k] < e) idq[k] = sorted_id[b + 128 + q_rec[k]];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // this lane's STAGED entry (entry index = lane): centre y and y-extent, for the strip lists
-    const float stage_my = reinterpret_cast<const float*>(st)[lane * 12 + 1];
-    const float stage_ey = reinterpret_cast<const float*>(st)[lane * 12 + 11];
-#else
     st[lane * 3] = n0; st[lane * 3 + 1] = n1; st[lane * 3 + 2] = n2;
     const float stage_my = n0.y, stage_ey = n2.w;
-#if SFGS_FWD_STRIP_EXACT
-    const float stage_mx = n0.x, stage_qa = n0.z, stage_qb = n0.w, stage_qc = n1.x, stage_op = n1.y;
-#endif
     if (b + 64 + lane < e) {  // prefetch: records of the next batch, ids of the one after
       n0 = rec[REC_F4 * (size_t)id_next]; n1 = rec[REC_F4 * (size_t)id_next + 1]; n2 = rec[REC_F4 * (size_t)id_next + 2];
     }
     if (b + 128 + lane < e) id_next = sorted_id[b + 128 + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
     const unsigned k0 = b - s;
     // Strip skipping. Only ~25 % of the (pixel, splat) pairs of a tile list hit (splats of a few pixels on an 8x8
     // tile), and a wave cannot skip per lane -- but it can per strip: lanes 16r..16r+15 (one DPP row) own pixel rows
@@ -1866,44 +1661,10 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
     const float my = stage_my, ey = stage_ey;   // this lane's STAGED entry (entry index = lane)
     const float ylo = (float)(ty * 8) - bound, yhi = (float)(ty * 8 + 1) + bound;
     const bool live = (unsigned)lane < cnt;
-#if SFGS_FWD_STRIP_EXACT
-    // Exact strip test (round 4; tools/workmodel: list steps 0.707 -> 0.643 of the list). Sample points on the pixel grid
-    // (the wave-uniform default): a strip is two pixel ROWS, and on a row y the exponent p2(dx, dy) is a concave parabola
-    // in dx, so its maximum over the tile's 8 columns is at the stationary point clamped to the row's x range -- the same
-    // evaluation, threshold and margins as the binning's tile test (raster_math.h: tile_can_contribute /
-    // alpha_threshold_log2: 0.1 % in alpha + 2e-3 in p2 against the per-pixel fmaf sequence), applied to an 8 x 1 instead of
-    // an 8 x 8 sample rectangle: an entry is dropped from a strip only if alpha < 1/255 on BOTH of its rows, i.e. only
-    // pairs the per-pixel test rejects anyway. Jittered sample points keep the y-extent test alone.
-    unsigned long long b0, b1, b2, b3;
-    if (bound == 0.f) {
-      const float thr = __builtin_amdgcn_logf(0.999f / 255.0f) - __builtin_amdgcn_logf(stage_op) - 2e-3f;   // v_log_f32 = log2
-      const float dxl = stage_mx - (float)(tx * 8 + 7), dxh = stage_mx - (float)(tx * 8);
-      const float inv2a = -0.5f * __builtin_amdgcn_rcpf(stage_qa);
-      const bool concave = stage_qa < 0.f && stage_mx == stage_mx;   // else (degenerate / NaN conic, NaN mean): keep every row
-      auto row_keeps = [&](int r) {
-        const float dy = my - (float)(ty * 8 + r);
-        const float t = stage_qb * dy;
-        const float dx = __builtin_amdgcn_fmed3f(t * inv2a, dxl, dxh);
-        const float p2 = fmaf(fmaf(stage_qa, dx, t), dx, (stage_qc * dy) * dy);
-        return !(p2 < thr) || !concave;              // NaN keeps the entry
-      };
-      const bool yk = !(my + ey < ylo) && !(my - ey > yhi + 6.f);   // the whole tile's y-extent test first
-      b0 = __ballot(live && yk && (row_keeps(0) || row_keeps(1)));
-      b1 = __ballot(live && yk && (row_keeps(2) || row_keeps(3)));
-      b2 = __ballot(live && yk && (row_keeps(4) || row_keeps(5)));
-      b3 = __ballot(live && yk && (row_keeps(6) || row_keeps(7)));
-    } else {
-      b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
-      b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
-      b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
-      b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
-    }
-#else
     const unsigned long long b0 = __ballot(live && !(my + ey < ylo) && !(my - ey > yhi));
     const unsigned long long b1 = __ballot(live && !(my + ey < ylo + 2.f) && !(my - ey > yhi + 2.f));
     const unsigned long long b2 = __ballot(live && !(my + ey < ylo + 4.f) && !(my - ey > yhi + 4.f));
     const unsigned long long b3 = __ballot(live && !(my + ey < ylo + 6.f) && !(my - ey > yhi + 6.f));
-#endif
     // per-row compact entry lists (bytes) in LDS
     unsigned char* Lw = &rowlist[lw][0][0];
     const int row = lane >> 4;
@@ -2026,27 +1787,23 @@ static int check_frame(const SfgsFrame* f) {
   return SFGS_OK;
 }
 
-// Route of the render stage's fine binning + short-list sort: SFGS_SORT=fused | split forces one (tests, A/B runs);
-// otherwise the caller's SHORT_LISTS hint picks the fused kernel. Both routes build bit-identical lists.
-// Returns 0 (split), 512 or 1024 (the fused kernel's list capacity: SFGS_SORT=fused1024 / the MEDIUM_LISTS hint).
+// Route of the render stage's fine binning + short-list sort: the "sort" option (sfgs_set_option) forces one (tests, A/B
+// runs); otherwise the caller's SHORT_LISTS hint picks the fused kernel. Both routes build bit-identical lists.
+// Returns 0 (split), 512 or 1024 (the fused kernel's list capacity: "fused1024" / the MEDIUM_LISTS hint).
 static int sort_fused(uint32_t launch_hints) {
-  const char* e = getenv("SFGS_SORT");
-  if (e && !strcmp(e, "split")) return 0;
-  if (e && !strcmp(e, "fused")) return 512;
-  if (e && !strcmp(e, "fused1024")) return 1024;
+  switch (option(OPT_SORT)) {
+    case SORT_SPLIT: return 0;
+    case SORT_FUSED: return 512;
+    case SORT_FUSED1024: return 1024;
+    default: break;
+  }
   if (launch_hints & SFGS_HINT_MEDIUM_LISTS) return 1024;
   return (launch_hints & SFGS_HINT_SHORT_LISTS) ? 512 : 0;
 }
 
-static bool plan_scan_separate() {   // SFGS_PLAN_SCAN=separate: the plan's epilogues as a launch of their own (A/B, tests)
-  const char* e = getenv("SFGS_PLAN_SCAN");
-  return e && !strcmp(e, "separate");
-}
+static bool plan_scan_separate() { return option(OPT_PLAN_SCAN) != 0; }   // the plan's epilogues as a launch of their own (A/B, tests)
 
-static bool binning_direct() {
-  const char* e = getenv("SFGS_BINNING");
-  return e && !strcmp(e, "direct");
-}
+static bool binning_direct() { return option(OPT_BINNING) != 0; }
 
 static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
   SFGS_REQUIRE(g != nullptr, SFGS_E_ARG, "gaussians is NULL");
@@ -2074,23 +1831,16 @@ static int check_gaussians(const SfgsFrame* f, const SfgsGaussians* g) {
 }
 
 // The plan clears the head of the tiles blob (header, duplicate pools, the coarse bins' counter lines: 261 KB at 1080p).
-// A kernel of our own instead of hipMemsetAsync (-DSFGS_PLAN_MEMSET=1): the runtime's fill goes through its blit path,
+// A kernel of our own instead of hipMemsetAsync (profiles/r4_plan_memset_ab.txt): the runtime's fill goes through its blit path,
 // which showed up in the kernel traces with 4 - 6 us of idle queue in front of it on every frame.
-#ifndef SFGS_PLAN_MEMSET
-#define SFGS_PLAN_MEMSET 0
-#endif
 __global__ void __launch_bounds__(256) zero_head_kernel(uint4* __restrict__ p, unsigned n16) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 static hipError_t zero_head(void* p, size_t bytes, hipStream_t stream) {
-#if SFGS_PLAN_MEMSET
-  return hipMemsetAsync(p, 0, bytes, stream);
-#else
   const unsigned n16 = (unsigned)(bytes / 16);   // zero_bytes is a multiple of 256
   hipLaunchKernelGGL(zero_head_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (uint4*)p, n16);
   return hipGetLastError();
-#endif
 }
 
 extern "C" int sfgs_raster_sizes(int32_t N, int32_t W, int32_t H, int64_t D, int64_t coarse_capacity,

@@ -36,6 +36,11 @@ enum KernelId {
   KID_COMPOSITE_FWD, KID_COMPOSITE_BWD, KID_PREPROCESS_BWD, KID_SSIM_FWD, KID_SSIM_MEAN, KID_SSIM_BWD, KID_KNN, KID_PREPASS_FWD, KID_PREPASS_BWD, KID_FILTER3D, KID_DENSIFY_STATS, KID_ADAM, KID_SH_EVAL_FWD, KID_SH_EVAL_BWD, KID_COMPACT_SCAN, KID_COMPACT_GATHER, KID_DENSIFY,
   KID_COUNT
 };
+// process-wide route options (include/sfgs.h: sfgs_set_option; api.cpp): one relaxed atomic load per query
+enum { OPT_SORT, OPT_PLAN_SCAN, OPT_BINNING, OPT_PREFILL, OPT_KNN, OPT_COUNT };
+enum { SORT_AUTO = 0, SORT_FUSED = 1, SORT_FUSED1024 = 2, SORT_SPLIT = 3 };
+enum { PREFILL_AUTO = 0, PREFILL_ALWAYS = 1, PREFILL_NEVER = 2 };
+int option(int which);
 bool prof_enabled();
 bool prof_selected(int id);
 void* prof_begin(int id, hipStream_t stream);
@@ -127,10 +132,7 @@ enum HeaderSlot {
 
 // float4s per compositing record in global memory: 3 = packed 48-byte records; 4 = 64-byte stride (the fourth is never
 // touched): every id -> record gather then falls into ONE 64-byte sector instead of 1.5 on average
-#ifndef SFGS_REC_F4
-#define SFGS_REC_F4 3
-#endif
-constexpr int REC_F4 = SFGS_REC_F4;
+constexpr int REC_F4 = 3;
 
 struct GeomView {
   float4* rec;      // [N][REC_F4] float4: (mx, my, qa, qb) (qc, op, r, g) (b, depth, ex, ey) -- SplatRec with (r, g), (b, depth) paired
@@ -200,10 +202,7 @@ struct TilesView {
   // and -- after the column scan -- the first slab rank of its run ([scatter_groups(N)][N_cb] each, fully rewritten per frame)
   uint32_t *sc_cnt, *sc_hits, *sc_base;
 };
-#ifndef SFGS_SCATTER_BLOCKS
-#define SFGS_SCATTER_BLOCKS 32
-#endif
-constexpr int SCATTER_BLOCKS = SFGS_SCATTER_BLOCKS;   // preprocess workgroups per scatter workgroup
+constexpr int SCATTER_BLOCKS = 32;   // preprocess workgroups per scatter workgroup
 static inline int tiles8_x(int W) { return (W + TILE_BIN - 1) / TILE_BIN; }
 static inline int tiles8_y(int H) { return (H + TILE_BIN - 1) / TILE_BIN; }
 static inline int64_t tiles8(int W, int H) { return (int64_t)tiles8_x(W) * tiles8_y(H); }
@@ -346,13 +345,10 @@ static inline ImageView image_view(void* base, int W, int H, int64_t D) {
 // the whole record array with streaming stores and composite_bwd skips its per-entry zero records.
 __host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned long long n_dup) { return dead * 10ull > n_dup * 3ull; }
 
-// per-duplicate gradient record. SFGS_DUPGRAD_F4 = 3: 48 bytes, floats in Grad2D order. 4: 64 bytes, float 3 k + r of the
+// per-duplicate gradient record. DG_F4 = 3: 48 bytes, floats in Grad2D order. 4: 64 bytes, float 3 k + r of the
 // record at position 4 r + k (every fourth float is padding): lane (entry, row r) of composite_bwd then owns one whole
 // 16-byte quarter and the four lanes of an entry write a full 64-byte sector with ONE store instruction
-#ifndef SFGS_DUPGRAD_F4
-#define SFGS_DUPGRAD_F4 3
-#endif
-constexpr int DG_F4 = SFGS_DUPGRAD_F4;
+constexpr int DG_F4 = 3;
 constexpr int DUPGRAD_FLOATS = 4 * DG_F4;
 static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
 
@@ -379,20 +375,14 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
   return base + idx;
 }
 
-// Waves per workgroup of the two compositing kernels (compile-time experiment knob; the shipped value is 4 = one 16x16
+// Waves per workgroup of the two compositing kernels (compile-time constant; 4 = one 16x16
 // super-tile per workgroup). With 1 every 8x8 tile is a workgroup of its own: the four waves of a super-tile never
 // synchronise anyway, and a one-wave workgroup gives its LDS and wave slot back the moment ITS list is done instead of
 // when the longest of four lists is (2: half a super-tile). Workgroups stay XCD-contiguous in super-tile order.
-#ifndef SFGS_COMPOSITE_WG_WAVES
-#define SFGS_COMPOSITE_WG_WAVES 4
-#endif
-constexpr int CWG_WAVES = SFGS_COMPOSITE_WG_WAVES;
+constexpr int CWG_WAVES = 4;
 // composite_bwd's own value (round 4 experiment: 8 = 4x2 tiles, 16 = 4x4 tiles = a coarse bin per workgroup, so that the
 // tiles that gather the same records share a CU's L1; one-wave workgroups measured +3.8 %: profiles/r4_bwd_lds18_ab_not_kept.txt)
-#ifndef SFGS_BWD_WG_WAVES
-#define SFGS_BWD_WG_WAVES SFGS_COMPOSITE_WG_WAVES
-#endif
-constexpr int BWG_WAVES = SFGS_BWD_WG_WAVES;
+constexpr int BWG_WAVES = CWG_WAVES;
 static_assert(CWG_WAVES == 4 || CWG_WAVES == 2 || CWG_WAVES == 1, "compositing workgroups: 4, 2 or 1 of a super-tile's tiles");
 static_assert(BWG_WAVES == 16 || BWG_WAVES == 8 || BWG_WAVES == 4 || BWG_WAVES == 2 || BWG_WAVES == 1, "composite_bwd workgroups");
 // A workgroup's tiles come from a BLOCK of CBLK x CBLK tiles (2 x 2 = the 16x16-pixel super-tile; 4 x 4 for workgroups of

@@ -81,7 +81,7 @@ def _hints_on():
 
 
 def _binning_direct():
-    return os.environ.get("SFGS_BINNING", "") == "direct"
+    return L.get_option("binning") == "direct"   # the library's own route option (sfgs_set_option), not the environment
 
 
 def _medium_on():
@@ -317,7 +317,7 @@ class _Rasterize(torch.autograd.Function):
             cap = max(hint[0], 4 * N + over)
             # coarse_capacity holds only the items appended DIRECTLY to a coarse bin's slab -- those of splats reaching more
             # than 6 coarse bins, none in most frames -- since the two-pass binning stores its items bin-sorted and exactly
-            # sized (ABI 14); with one-pass binning (images beyond 65 536 coarse bins, SFGS_BINNING=direct) every item goes there
+            # sized (ABI 14); with one-pass binning (images beyond 65 536 coarse bins, option "binning" = "direct") every item goes there
             ccap = max(hint[1], 8 * N // ncb if (ncb > 65536 or _binning_direct()) else 0, 256)
             # few, large allocations: the Python time before the first launch is GPU idle time
             # band rendering (tile_rows extension) leaves the pixels outside the band untouched: start from zeros there

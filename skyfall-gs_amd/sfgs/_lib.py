@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -84,6 +84,8 @@ SYMBOLS = {
     "sfgs_last_error": (C.c_char_p, []),
     "sfgs_profile_enable": (C.c_int, [_I32]),
     "sfgs_profile_select": (C.c_int, [C.c_uint64]),
+    "sfgs_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "sfgs_get_option": (C.c_char_p, [C.c_char_p]),
     "sfgs_profile_kernel_count": (C.c_int, []),
     "sfgs_profile_kernel_name": (C.c_char_p, [_I32]),
     "sfgs_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
@@ -163,6 +165,22 @@ def check(rc):
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def set_option(key, value):
+    """Process-wide route option of the library (include/sfgs.h: sfgs_set_option): "sort", "plan_scan", "binning",
+    "prefill", "knn". Tests and A/B runs only -- every route builds bit-identical results. Returns the previous value."""
+    lib = load()
+    old = lib.sfgs_get_option(str(key).encode())
+    check(lib.sfgs_set_option(str(key).encode(), str(value).encode()))   # raises for an unknown key or value
+    return old.decode()
+
+
+def get_option(key):
+    v = load().sfgs_get_option(str(key).encode())
+    if v is None:
+        raise KeyError(f"libsfgs.so has no option {key!r}")
+    return v.decode()
 
 
 def profile_enable(on=True):

@@ -22,3 +22,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def sfgs_option():
+    """set a process-wide route option of libsfgs.so (sfgs_set_option) for the duration of one test:
+    `sfgs_option("sort", "split")`. Every option goes back to what it was when the test ends."""
+    from sfgs import _lib as L
+    saved = {}
+
+    def set_(key, value):
+        old = L.set_option(key, value)
+        saved.setdefault(key, old)
+    yield set_
+    for key, old in saved.items():
+        L.set_option(key, old)

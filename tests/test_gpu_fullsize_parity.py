@@ -18,7 +18,7 @@ NO_BIG_CHUNKS) and with the mid-frame counter read. Each case therefore starts f
 frame three times (forward + backward: frame 1 runs hint-less, frame 2 with what frame 1's plan taught, frame 3 with what
 frame 2's plan reported about frame 1's render / backward stages -- the steady state), asserts from the hint words which
 route frame 3 took, and compares FRAME 3 with the oracle. cfg 2 additionally runs with the route forced either way
-(SFGS_SORT=fused | split)."""
+(option "sort" = fused | split)."""
 import json
 import os
 
@@ -66,15 +66,12 @@ HINT_MEDIUM_LISTS = 32
 PARAMS = [(c, None) for c in CASES] + [("cfg2_2M_1080p", "fused"), ("cfg2_2M_1080p", "split")]
 
 
-@pytest.mark.parametrize("case,sort_route", PARAMS, ids=[c if r is None else f"{c}-SFGS_SORT={r}" for c, r in PARAMS])
-def test_full_size_oracle_parity(case, sort_route, monkeypatch):
+@pytest.mark.parametrize("case,sort_route", PARAMS, ids=[c if r is None else f"{c}-sort={r}" for c, r in PARAMS])
+def test_full_size_oracle_parity(case, sort_route, monkeypatch, sfgs_option):
     import diff_gauss
     c = CASES[case]
     os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
-    if sort_route is not None:
-        monkeypatch.setenv("SFGS_SORT", sort_route)   # read by the library on every render (getenv)
-    else:
-        monkeypatch.delenv("SFGS_SORT", raising=False)
+    sfgs_option("sort", sort_route if sort_route is not None else "auto")   # the library's route option (sfgs_set_option)
     monkeypatch.delenv("SFGS_HINTS", raising=False)
     if "city" in c:
         frame, g = city_scene(c["n"], c["W"], c["H"], c["city"], seed=0)

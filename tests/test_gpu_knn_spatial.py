@@ -1,5 +1,5 @@
 """simple_knn._C.distCUDA2 above the brute-force limit (csrc/knn.hip: Z-curve counting sort + box-pruned search; call
-site scene/gaussian_model.py:324-325): EXACT -- bit-identical to the library's own brute-force kernel (SFGS_KNN=brute, the
+site scene/gaussian_model.py:324-325): EXACT -- bit-identical to the library's own brute-force kernel (option "knn" = "brute", the
 same float32 distance expression) on clouds that stress the spatial structure, and equal to scipy.spatial.cKDTree
 (float64) within float32 rounding. Also records the timing at 1e6 points (252 ms brute force)."""
 import json
@@ -42,17 +42,14 @@ def _cloud(kind, n, seed=0):
 
 def _run(pts, brute=False):
     from simple_knn._C import distCUDA2
-    old = os.environ.pop("SFGS_KNN", None)
-    if brute:
-        os.environ["SFGS_KNN"] = "brute"
+    from sfgs import _lib as L
+    old = L.set_option("knn", "brute" if brute else "auto")   # the library's route option (sfgs_set_option)
     try:
         out = distCUDA2(torch.from_numpy(pts).to(DEV))
         torch.cuda.synchronize()
         return out.cpu().numpy()
     finally:
-        os.environ.pop("SFGS_KNN", None)
-        if old is not None:
-            os.environ["SFGS_KNN"] = old
+        L.set_option("knn", old)
 
 
 @pytest.mark.parametrize("kind,n", [("uniform", 40_000), ("satellite_surface", 200_000), ("clusters", 100_000),

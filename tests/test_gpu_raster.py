@@ -317,7 +317,7 @@ def test_random_configurations(i):
                                  mx=parity.GRAD_RTOL_MAX * scale * few * (6.0 if flipped else 1.0))
 
 
-def test_dead_entry_prefill_paths_bit_identical(monkeypatch):
+def test_dead_entry_prefill_paths_bit_identical(sfgs_option):
     """Entries behind a tile's last contributor get zero gradient records either one by one (composite_bwd) or from the
     streaming prefill (dupgrad_prefill_kernel, chosen per frame on the device when > 30 % are dead). Both forced in
     turn: every gradient must come out bit-identical, and identical to the automatic choice."""
@@ -325,10 +325,7 @@ def test_dead_entry_prefill_paths_bit_identical(monkeypatch):
     gc, gd = upstream_grads(256, 192, 3)
     outs = {}
     for mode in ("always", "never", ""):
-        if mode:
-            monkeypatch.setenv("SFGS_PREFILL", mode)
-        else:
-            monkeypatch.delenv("SFGS_PREFILL", raising=False)
+        sfgs_option("prefill", mode or "auto")
         outs[mode] = run_hip(frame, g, gc, gd)["grads"]
     for k in outs["always"]:
         np.testing.assert_array_equal(outs["always"][k], outs["never"][k], err_msg=k)
@@ -380,15 +377,15 @@ def test_skewed_workgroups_and_the_duplicate_index_pools():
 
 @pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p", "uhd_two_bin_rounds",
                                   "mid_splats_many_items", "skewed_far_view"])
-def test_two_pass_binning_equals_the_direct_path(case, monkeypatch):
+def test_two_pass_binning_equals_the_direct_path(case, sfgs_option):
     """Two-pass binning (pair list + bin_scatter_kernel, the default) and the one-pass path with one device atomic per
-    coarse item (SFGS_BINNING=direct) build the same frame: duplicate indices come from the same scan and every tile list
+    coarse item (option "binning" = "direct") build the same frame: duplicate indices come from the same scan and every tile list
     is sorted by (depth, id), so images, radii, counters and every gradient are equal bit for bit."""
     c = CASES.get(case) or BINNING_CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=11, **c["kw"])
     gc, gd = upstream_grads(c["W"], c["H"], 4)
     a = run_hip(frame, g, gc, gd)
-    monkeypatch.setenv("SFGS_BINNING", "direct")
+    sfgs_option("binning", "direct")
     b = run_hip(frame, g, gc, gd)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
@@ -447,10 +444,10 @@ def test_a_skewed_frame_needs_no_per_bin_capacity():
 @pytest.mark.parametrize("route", ["fused", "fused1024"])
 @pytest.mark.parametrize("case", ["precomp_small", "sh1_ragged", "cfg2_like", "big_splats", "screen_filling", "lists_800",
                                   "lists_2k", "lists_6k", "lists_10k", "cfg2_200k_1080p", "uhd_two_bin_rounds"])
-def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, monkeypatch):
+def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, sfgs_option):
     """select_sort_kernel (a workgroup hands a coarse bin's items to the LDS lists of a row of tiles, every wave sorts its
     tile in registers and writes the final lists; the route the SHORT_LISTS hint selects, forced here) and the two-kernel route with the per-tile items in memory between them
-    (SFGS_SORT=split: fine_bin + sort_tiles_reg) build the same lists -- same members, same (depth, id) order, same
+    (option "sort" = "split": fine_bin + sort_tiles_reg) build the same lists -- same members, same (depth, id) order, same
     duplicate indices; only WHERE a tile's list sits inside its bin's slot range may differ -- so images, radii,
     counters (incl. the longest list) and every gradient are equal bit for bit. Long lists (> 512) take the second scan
     and the long-list kernels in the fused route. route fused1024 = the MEDIUM_LISTS form of the kernel (lists up to 1 024
@@ -458,9 +455,9 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, monkeypatch):
     c = CASES.get(case) or BINNING_CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=5, **c["kw"])
     gc, gd = upstream_grads(c["W"], c["H"], 2)
-    monkeypatch.setenv("SFGS_SORT", route)
+    sfgs_option("sort", route)
     a = run_hip(frame, g, gc, gd)
-    monkeypatch.setenv("SFGS_SORT", "split")
+    sfgs_option("sort", "split")
     b = run_hip(frame, g, gc, gd)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
@@ -471,7 +468,7 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, monkeypatch):
 
 
 @pytest.mark.parametrize("route", ["fused", "fused1024"])
-def test_equal_depths_keep_the_id_order_on_every_route(route, monkeypatch):
+def test_equal_depths_keep_the_id_order_on_every_route(route, sfgs_option):
     """Clones sit exactly on their parents until the optimiser moves them (scene/gaussian_model.py: densify_and_clone):
     every Gaussian here exists three times with the same mean, i.e. the same depth bits, in lists of ~800 entries. The
     order inside a tile is (depth bits, id) on every route -- the register network sorts the 64-bit key, the radix sort of
@@ -490,9 +487,9 @@ def test_equal_depths_keep_the_id_order_on_every_route(route, monkeypatch):
     gc, gd = upstream_grads(24, 24, 2)
     R = orc.OracleRender(frame, **g3)
     assert 256 < R.max_tile_list
-    monkeypatch.setenv("SFGS_SORT", route)
+    sfgs_option("sort", route)
     a = run_hip(frame, g3, gc, gd)
-    monkeypatch.setenv("SFGS_SORT", "split")
+    sfgs_option("sort", "split")
     b = run_hip(frame, g3, gc, gd)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)

@@ -179,3 +179,36 @@ def test_capacity_and_huge_splat_hints_follow_their_rules():
         seq.append(h)
     q = dg.HUGE_QUIET_FRAMES
     assert seq == [0, 0, q, q - 1, q - 2, q - 3] and q >= 8
+
+
+def test_route_options_are_set_through_the_abi_not_the_environment():
+    """ABI 16: the library no longer calls getenv() on every render. The route options are process-wide
+    atomics, read from the environment ONCE at load time and changed only through sfgs_set_option (host code: runs here)."""
+    import subprocess
+    import sys
+    for key, values in (("sort", ["auto", "fused", "fused1024", "split"]), ("plan_scan", ["fused", "separate"]),
+                        ("binning", ["auto", "direct"]), ("prefill", ["auto", "always", "never"]), ("knn", ["auto", "brute"])):
+        first = L.get_option(key)
+        assert first == values[0]                       # the defaults (this process's environment sets none)
+        for v in values[::-1]:
+            assert L.set_option(key, v) in values and L.get_option(key) == v
+        with pytest.raises(RuntimeError, match="has no value"):
+            L.set_option(key, "bogus")
+        assert L.get_option(key) == values[0]           # a rejected value changes nothing
+    with pytest.raises(RuntimeError, match="unknown option"):
+        L.set_option("no_such_option", "1")
+    with pytest.raises(KeyError):
+        L.get_option("no_such_option")
+    # the environment is honoured at LOAD time (a fresh process), never afterwards
+    os.environ["SFGS_SORT"] = "split"
+    try:
+        assert L.get_option("sort") == "auto"
+        code = ("import sys; sys.path.insert(0, %r); from sfgs import _lib as L; "
+                "print(L.get_option('sort'), L.get_option('prefill'))" % os.path.join(ROOT, "skyfall-gs_amd"))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, SFGS_PREFILL="never"))
+        assert r.stdout.split() == ["split", "never"], r.stdout + r.stderr
+    finally:
+        del os.environ["SFGS_SORT"]
+    src = "".join(open(os.path.join(ROOT, "skyfall-gs_amd", "csrc", f)).read() for f in ("raster_fwd.hip", "raster_bwd.hip", "knn.hip"))
+    assert "getenv" not in src

@@ -1,18 +1,32 @@
 #!/bin/bash
-# Builds a whole experiment variant of libsfgs.so with extra -D flags into skyfall-gs_amd/sfgs/_exp/lib_<name>.so
-# (git-ignored, travels to the GPU box); compare with tools/ab.sh.   usage: tools/build_variant.sh <name> "<flags>"
+# Builds an EXPERIMENT variant of libsfgs.so into skyfall-gs_amd/sfgs/_exp/lib_<name>.so (git-ignored; travels to the GPU box;
+# compare with tools/ab.sh). The shipped sources carry no experiment knobs: a variant is the sources + patches + -D flags,
+# built in a scratch copy of skyfall-gs_amd/csrc.
+# usage: tools/build_variant.sh <name> "<-D flags>" [patch ...]        (patches: tools/variants/*.patch, applied with -p1
+#        from the repo root, in order; "" for no flags)
+#   tools/build_variant.sh nop1 "-DSFGS_BWD_ABLATE=2" tools/variants/bwd_lab_r5.patch
 set -e
-name=$1; defs=${2:-}
-cd "$(dirname "$0")/../skyfall-gs_amd/csrc"
-mkdir -p ../sfgs/_exp _obj/var_$name
+name=$1; defs=${2:-}; shift; [ $# -gt 0 ] && shift
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+SRC=$ROOT/skyfall-gs_amd/csrc
+W=$SRC/_obj/var_$name
+rm -rf "$W"; mkdir -p "$W/skyfall-gs_amd/csrc" "$W/include" "$ROOT/skyfall-gs_amd/sfgs/_exp"
+cp "$SRC"/*.hip "$SRC"/*.cpp "$SRC"/*.h "$W/skyfall-gs_amd/csrc/"; cp "$ROOT"/include/*.h "$W/include/"
+for p in "$@"; do ( cd "$W" && patch -s -p1 < "$ROOT/$p" ); done
+cd "$W/skyfall-gs_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
 SRCS="api.cpp raster_fwd.hip raster_bwd.hip ssim.hip knn.hip prepass.hip filter3d.hip densify_stats.hip adam.hip sh_eval.hip compact.hip densify.hip"
+mkdir -p o
 for f in $SRCS; do
   extra=""; [ $f = raster_bwd.hip ] && extra="-fno-slp-vectorize"
-  # only the rasterizer sources see the experiment flags; the other objects are reused from the main build
-  case $f in api.cpp|raster_fwd.hip|raster_bwd.hip) ( /opt/rocm/bin/hipcc $FLAGS $extra $defs -x hip -c $f -o _obj/var_$name/$f.o ) & ;;
-    *) cp _obj/$f.o _obj/var_$name/$f.o ;; esac
+  # only what the patches / flags can touch is recompiled; the other objects come from the main build (make first)
+  if cmp -s $f "$SRC/$f" && [ -z "$defs" -o \( $f != raster_fwd.hip -a $f != raster_bwd.hip -a $f != api.cpp \) ] && \
+     cmp -s raster_math.h "$SRC/raster_math.h" && cmp -s sfgs_internal.h "$SRC/sfgs_internal.h" && [ -f "$SRC/_obj/$f.o" ]; then
+    cp "$SRC/_obj/$f.o" o/$f.o
+  else
+    ( /opt/rocm/bin/hipcc $FLAGS $extra $defs -x hip -c $f -o o/$f.o 2>&1 | grep -v "hip-link" || true ) &
+  fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../sfgs/_exp/lib_$name.so _obj/var_$name/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/skyfall-gs_amd/sfgs/_exp/lib_$name.so" o/*.o
 echo built skyfall-gs_amd/sfgs/_exp/lib_$name.so
