@@ -76,10 +76,11 @@ def main():
                          "--n / --width / --height override the config's size")
     ap.add_argument("--zrange", type=float, nargs=2, default=None, metavar=("ZMIN", "ZMAX"),
                     help="view depth range of the synthetic scene (default: the config's)")
-    ap.add_argument("--subpixel-offset", choices=["none", "zeros"], default="none",
-                    help="'zeros': hand the rasterizer an all-zero [H,W,2] subpixel_offset tensor, which is what the reference's "
-                         "render() allocates on every call when ray jitter is off (gaussian_renderer/__init__.py:37-38); "
-                         "'none' (the headline since round 1): no tensor")
+    ap.add_argument("--subpixel-offset", choices=["none", "zeros"], default="zeros",
+                    help="'zeros' (the headline since round 5): hand the rasterizer an all-zero [H,W,2] subpixel_offset tensor, "
+                         "which is what the reference's render() allocates on every call when ray jitter is off "
+                         "(gaussian_renderer/__init__.py:37-38) -- the shape the reference actually calls; 'none' (the "
+                         "headline of rounds 1-4): no tensor")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: initialise torch.distributed over RCCL (backend nccl, world size 1) and run the "
                          "24 966-float device all-reduce every step, as the N > 1 runs do")
@@ -249,15 +250,16 @@ def main():
     if ar_events:
         allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
     ar_events = None
-    # every bracketed launch carries the cost of its own event pair: measure it (empty pairs on the same stream) and take
-    # it out of the per-kernel figures, so that they add up to no more than the step
+    # every bracketed launch carries the cost of its own event pair: measure it (empty pairs on the same stream). The
+    # per-kernel figures reported below are the RAW event times (they agree with rocprofv3's kernel trace to ~1 %, VERDICT
+    # r4: the subtraction over-corrected by 3 %); only `gpu_busy_ms_per_step` takes the pairs' cost out, so that it stays
+    # comparable with the un-bracketed step time
     cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
     for a_, b_ in cal:
         a_.record(); b_.record()
     torch.cuda.synchronize(dev)
     event_pair_ms = sorted(a_.elapsed_time(b_) for a_, b_ in cal)[len(cal) // 2]
     warm_prof = L.profile_collect() if args.warmup else {}
-    warm_prof = {k: (max(ms - event_pair_ms * n, 0.0), n) for k, (ms, n) in warm_prof.items()}
     L.profile_enable(True)
 
     def group(prof, nsteps):
@@ -288,7 +290,6 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = L.profile_collect()
-    prof = {k: (max(ms - event_pair_ms * n, 0.0), n) for k, (ms, n) in prof.items()}
     L.profile_enable(False)
     L.profile_select(None)
 
@@ -370,9 +371,12 @@ def main():
     roofline_step = {"bound": "hbm", "achieved": round(step_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(step_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(B_step),
                      "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(per_kernel.items())},
-                     "kernel_ms_source": "HIP events on the launch stream minus the measured cost of an empty event pair "
-                                         f"({event_pair_ms * 1e3:.1f} us); dominant kernel: timed region; others: warm-up steps",
-                     "gpu_busy_ms_per_step": round(sum(v["ms_per_step"] for v in per_kernel.values()), 4)}
+                     "kernel_ms_source": "raw HIP-event brackets on the launch stream (dominant kernel: timed region; others: "
+                                         "warm-up steps, where every kernel is bracketed)",
+                     "event_pair_us": round(event_pair_ms * 1e3, 2),
+                     "gpu_busy_ms_per_step": round(sum(max(v["ms_per_step"] - event_pair_ms * v["launches"] / max(
+                         args.steps if k == dom else n_prof, 1), 0.0) for k, v in per_kernel.items()), 4),
+                     "gpu_busy_source": "sum of the brackets minus the measured cost of an empty event pair per launch"}
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only and args.config == "cfg2":

@@ -377,7 +377,8 @@ int sfgs_ssim_backward(const float* img1, const float* img2, int32_t B, int32_t 
  *                            order -- ascending (depth bits, id) -- is the single-process one and
  *                            sfgs_raster_forward_render (num_duplicates = -1, any tile-row band) produces the same pixels
  *                            bit for bit. Forward only: a merged plan carries no duplicate indices for a backward.
- * Up to 16 parts. Asynchronous on `stream`. */
+ * Up to 16 parts. Asynchronous on `stream`. `bins` of sfgs_raster_plan_export is the blob the plan was given, in full
+ * (sfgs_raster_sizes().bins_bytes: the bin-sorted items it reads lie at the blob's end; the call takes no size to check). */
 int sfgs_raster_plan_export(const SfgsFrame* frame, int32_t N, const void* geom, const void* tiles, const void* bins,
                             int64_t dup_capacity, int64_t coarse_capacity, int64_t export_capacity, float* rec_out,
                             uint32_t* count_out, void* items_out, void* stream);

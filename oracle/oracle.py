@@ -35,6 +35,8 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_forward.restype = C.c_void_p
         _lib.orc_forward.argtypes = [C.POINTER(OrcFrame), C.c_int32] + [C.c_void_p] * 10
+        _lib.orc_forward_rows.restype = C.c_void_p
+        _lib.orc_forward_rows.argtypes = [C.POINTER(OrcFrame), C.c_int32] + [C.c_void_p] * 10 + [C.c_int32, C.c_int32]
         _lib.orc_backward.restype = C.c_int
         _lib.orc_backward.argtypes = [C.c_void_p, C.POINTER(OrcFrame)] + [C.c_void_p] * 17
         _lib.orc_free.argtypes = [C.c_void_p]
@@ -71,7 +73,9 @@ def _ptr(a):
 class OracleRender:
     """One forward pass of the oracle; keeps the state the backward needs."""
 
-    def __init__(self, frame, means3D, scales, rotations, opacities, colors_precomp=None, shs=None):
+    def __init__(self, frame, means3D, scales, rotations, opacities, colors_precomp=None, shs=None, tile_rows=None):
+        """tile_rows = (row0, row1): render only those rows of 16x16 tiles (orc_forward_rows; forward-only checks of very
+        large frames -- every Gaussian is still projected, `radii` is complete; the other pixels stay zero)."""
         L = lib()
         self.H, self.W = int(frame["H"]), int(frame["W"])
         self.N = int(means3D.shape[0])
@@ -91,9 +95,11 @@ class OracleRender:
         self.depth = np.zeros((1, self.H, self.W), np.float32)
         self.alpha = np.zeros((1, self.H, self.W), np.float32)
         self.radii = np.zeros((self.N,), np.int32)
-        self._st = L.orc_forward(C.byref(self.frame), self.N, _ptr(k["means3D"]), _ptr(k["scales"]),
-                                 _ptr(k["rotations"]), _ptr(k["opacities"]), _ptr(k["colors"]), _ptr(k["shs"]),
-                                 _ptr(self.color), _ptr(self.depth), _ptr(self.alpha), _ptr(self.radii))
+        args = (C.byref(self.frame), self.N, _ptr(k["means3D"]), _ptr(k["scales"]),
+                _ptr(k["rotations"]), _ptr(k["opacities"]), _ptr(k["colors"]), _ptr(k["shs"]),
+                _ptr(self.color), _ptr(self.depth), _ptr(self.alpha), _ptr(self.radii))
+        self.tile_rows = tile_rows
+        self._st = L.orc_forward(*args) if tile_rows is None else L.orc_forward_rows(*args, int(tile_rows[0]), int(tile_rows[1]))
         cnt = np.zeros(4, np.int64)
         L.orc_get_counts(self._st, _ptr(cnt))
         self.num_duplicates, self.num_visible, self.max_tile_list, self.num_tiles = [int(v) for v in cnt]

@@ -261,11 +261,30 @@ void orc_free(OrcState* st) {
 }
 
 /* ---- forward: A.2 - A.4 ------------------------------------------------------------------ */
+/* orc_forward_rows: the same algorithm restricted to the 16x16 tile rows [row0, row1) -- every Gaussian is projected
+ * (radii are complete), only the tiles of those rows get lists and pixels; the other pixels keep what the output arrays
+ * held. Lets a test check two bands of a 16 M-Gaussian joint frame (BASELINE.json configs[4]) in seconds. D counts the
+ * band's duplicates. orc_forward = all rows. */
+OrcState* orc_forward_rows(const OrcFrame* f, int32_t N, const float* means3D, const float* scales,
+                           const float* rots, const float* opac, const float* colors, const float* shs,
+                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii, int32_t row0,
+                           int32_t row1);
+
 OrcState* orc_forward(const OrcFrame* f, int32_t N, const float* means3D, const float* scales,
                       const float* rots, const float* opac, const float* colors, const float* shs,
                       float* out_color, float* out_depth, float* out_alpha, int32_t* radii) {
+  return orc_forward_rows(f, N, means3D, scales, rots, opac, colors, shs, out_color, out_depth, out_alpha, radii, 0,
+                          (f->H + TILE - 1) / TILE);
+}
+
+OrcState* orc_forward_rows(const OrcFrame* f, int32_t N, const float* means3D, const float* scales,
+                           const float* rots, const float* opac, const float* colors, const float* shs,
+                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii, int32_t row0,
+                           int32_t row1) {
   const int W = f->W, H = f->H;
   const int TX = (W + TILE - 1) / TILE, TY = (H + TILE - 1) / TILE;
+  if (row0 < 0) row0 = 0;
+  if (row1 > TY) row1 = TY;
   const int64_t T = (int64_t)TX * TY, P = (int64_t)W * H;
   OrcState* st = (OrcState*)calloc(1, sizeof(OrcState));
   st->N = N; st->W = W; st->H = H; st->TX = TX; st->TY = TY;
@@ -288,7 +307,7 @@ OrcState* orc_forward(const OrcFrame* f, int32_t N, const float* means3D, const 
   for (int32_t i = 0; i < N; ++i) {
     const OrcGeom* g = &st->g[i];
     if (g->radius <= 0) continue;
-    for (int y = g->rminy; y < g->rmaxy; ++y)
+    for (int y = imax(g->rminy, row0); y < imin(g->rmaxy, row1); ++y)
       for (int x = g->rminx; x < g->rmaxx; ++x) cnt[(int64_t)y * TX + x]++;
   }
   int64_t D = 0;
@@ -301,7 +320,7 @@ OrcState* orc_forward(const OrcFrame* f, int32_t N, const float* means3D, const 
     const OrcGeom* g = &st->g[i];
     if (g->radius <= 0) continue;
     uint32_t kb; memcpy(&kb, &g->depth, 4);
-    for (int y = g->rminy; y < g->rmaxy; ++y)
+    for (int y = imax(g->rminy, row0); y < imin(g->rmaxy, row1); ++y)
       for (int x = g->rminx; x < g->rmaxx; ++x) {
         int64_t t = (int64_t)y * TX + x;
         int64_t pos = st->tile_start[t] + cnt[t]++;
@@ -321,7 +340,7 @@ OrcState* orc_forward(const OrcFrame* f, int32_t N, const float* means3D, const 
   /* A.4 composite */
   const float bg0 = f->bg[0], bg1 = f->bg[1], bg2 = f->bg[2];
 #pragma omp parallel for schedule(dynamic, 4)
-  for (int64_t t = 0; t < T; ++t) {
+  for (int64_t t = (int64_t)row0 * TX; t < (int64_t)row1 * TX; ++t) {
     int tx0 = (int)(t % TX) * TILE, ty0 = (int)(t / TX) * TILE;
     int64_t s = st->tile_start[t], e = st->tile_start[t + 1];
     for (int py = ty0; py < ty0 + TILE && py < H; ++py)

@@ -2078,8 +2078,10 @@ extern "C" int sfgs_raster_plan_merge(const SfgsFrame* frame, int32_t parts, con
   SFGS_REQUIRE(geom_sz >= geom_bytes(N), SFGS_E_CAPACITY, "geom blob: %zu bytes given, %zu needed", geom_sz, geom_bytes(N));
   SFGS_REQUIRE(dup_capacity >= 0 && dup_capacity < (1ll << 32) && coarse_capacity >= 0 && coarse_capacity < (1ll << 31),
                SFGS_E_ARG, "bad dup_capacity / coarse_capacity");
-  SFGS_REQUIRE(bins_sz >= bins_bytes(dup_capacity, NCB, coarse_capacity), SFGS_E_CAPACITY,
-               "bins blob: %zu bytes given, %zu needed", bins_sz, bins_bytes(dup_capacity, NCB, coarse_capacity));
+  // (the plan-sized blob: the render stage reads the bin-sorted items of the two-pass binning, which lie at its END)
+  SFGS_REQUIRE(bins_sz >= bins_bytes_plan(dup_capacity, NCB, coarse_capacity, N), SFGS_E_CAPACITY,
+               "bins blob: %zu bytes given, %zu needed (the blob the plan was given: sfgs_raster_sizes().bins_bytes)", bins_sz,
+               bins_bytes_plan(dup_capacity, NCB, coarse_capacity, N));
   const GeomView gv = geom_view(geom, N);
   const BinsView bv = bins_view(bins, dup_capacity, NCB, coarse_capacity);
   SFGS_CHECK_HIP(zero_head(tiles, tv.zero_bytes, stream));

@@ -247,13 +247,18 @@ def _raw_stream(dev_index):
 
 def _cached_frame(settings, dev, sh_coeffs):
     """(SfgsFrame prototype, tensors it points into) of a settings tuple: rebuilt only when a different tuple object, device
-    or SH layout arrives. Per host thread (the backward's autograd worker copies the prototype it was handed)."""
+    or SH layout arrives. Per host thread (the backward's autograd worker copies the prototype it was handed).
+    Cached ONLY when the prototype points into the caller's own tensors: a settings tensor that had to be copied to make
+    it contiguous (the reference's world_view_transform is a transposed view, scene/cameras.py:62) would freeze its values
+    at first use while the uncopied ones alias live memory -- a caller that edits its camera tensors in place and re-uses
+    the tuple would render a stale view matrix with a fresh camera centre. Such a tuple is rebuilt per call."""
     c = getattr(_tls, "frame", None)
     if c is not None and c[0] is settings and c[1] == dev and c[2] == sh_coeffs:
         return c[3], c[4]
     keep = []
     proto = _frame(settings, dev, sh_coeffs, keep)
-    _tls.frame = (settings, dev, sh_coeffs, proto, keep)
+    given = (settings.subpixel_offset, settings.bg, settings.viewmatrix, settings.projmatrix, settings.campos)
+    _tls.frame = (settings, dev, sh_coeffs, proto, keep) if all(a is b for a, b in zip(keep, given)) else None
     return proto, keep
 
 

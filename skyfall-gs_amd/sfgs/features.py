@@ -18,6 +18,8 @@ dtype and device of the concatenated tensor, no storage. What render() does with
 """
 import torch
 
+from . import _handles
+
 __all__ = ["DeferredFeatures", "split_parts", "materialise", "install", "uninstall"]
 
 _METADATA = frozenset(("dim", "ndimension", "numel", "nelement", "size", "__len__", "is_contiguous", "element_size",
@@ -60,6 +62,9 @@ class DeferredFeatures(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", "")
+        if name == "__get__" and not _handles.answered_by_wrapper(func):
+            # .grad, .grad_fn, ._version, .data ...: properties of the tensor the handle stands for, read from it
+            return getattr(args[0].materialise(), _handles.property_name(func))
         if name == "__get__" or name in _METADATA:   # shape, dtype, device, ...: answered by the wrapper's metadata
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)

@@ -14,6 +14,8 @@ Two ways to use it:
 """
 import torch
 
+from . import _handles
+
 from . import _lib as L
 
 __all__ = ["fused_activations", "install", "uninstall", "Deferred", "raw_parameters", "materialise", "f64_mask"]
@@ -142,6 +144,9 @@ class Deferred(torch.Tensor):
         name = getattr(func, "__name__", "")
         if func is torch.Tensor.float and len(args) == 1 and not kwargs:
             return args[0]                       # already float32: .float() returns the tensor itself, like torch
+        if name == "__get__" and not _handles.answered_by_wrapper(func):
+            # .grad, .grad_fn, ._version, .data ...: properties of the tensor the handle stands for, read from it
+            return getattr(args[0].materialise(), _handles.property_name(func))
         if name == "__get__" or name in _METADATA:   # shape, dtype, device, ...: answered by the wrapper's metadata
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)

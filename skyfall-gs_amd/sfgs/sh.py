@@ -7,6 +7,8 @@ looks up, so the reference's source stays untouched; semantics are the reference
 sh[..., 3, K], only the first (deg+1)^2 coefficients used, no normalisation / offset / clamp)."""
 import torch
 
+from . import _handles
+
 from . import _lib as L
 
 __all__ = ["eval_sh", "eval_sh_deferred", "DeferredColor", "materialise", "install", "uninstall"]
@@ -147,6 +149,9 @@ class DeferredColor(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", "")
+        if name == "__get__" and not _handles.answered_by_wrapper(func):
+            # .grad, .grad_fn, ._version, .data ...: properties of the tensor the handle stands for, read from it
+            return getattr(args[0].materialise(), _handles.property_name(func))
         if name == "__get__" or name in _METADATA:   # shape, dtype, device, ...: answered by the wrapper's metadata
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)

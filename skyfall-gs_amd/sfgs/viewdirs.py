@@ -18,6 +18,8 @@ another norm, printing -- runs the recorded statements as ordinary torch operati
 proceeds on the result; the handle on `_xyz` itself simply stands for the parameter."""
 import torch
 
+from . import _handles
+
 __all__ = ["LazyDirs", "centers_of", "materialise", "install", "uninstall"]
 
 _METADATA = frozenset(("dim", "ndimension", "numel", "nelement", "size", "__len__", "is_contiguous", "element_size",
@@ -67,6 +69,10 @@ class LazyDirs(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", "")
+        if name == "__get__" and not _handles.answered_by_wrapper(func):
+            # .grad, .grad_fn, ._version, .data ...: properties of the tensor the handle stands for, read from it
+            h0 = args[0]   # (the handle on `_xyz` reads its parameter without counting as "looked into")
+            return getattr(h0._sfgs_src if h0._sfgs_kind == XYZ else h0.materialise(), _handles.property_name(func))
         if name == "__get__" or name in _METADATA:   # shape, dtype, device, ...: answered by the wrapper's metadata
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)

@@ -27,6 +27,9 @@ CASES = {
     "screen_filling": dict(n=60, W=640, H=400, kw=dict(zrange=(3., 6.), scale_range=(0.5, 3.0), opacity_range=(0.01, 0.05))),
     # more huge splats than big_walk_kernel has waves (1 024): its persistent loop takes a second round
     "many_huge": dict(n=1500, W=512, H=384, kw=dict(zrange=(3., 6.), scale_range=(0.6, 3.0), opacity_range=(0.004, 0.02))),
+    # BASELINE.json configs[0] exactly (sfgs.synth.cfg1: 50 000 random Gaussians, one 800x800 pinhole camera, z ~ U(4, 8),
+    # scales exp(U(ln 0.005, ln 0.05)), SURVEY 8d cfg 1) -- the case bench.py's cpu_baseline.cfg1_full times on the host
+    "configs0_50k_800sq": dict(n=50000, W=800, H=800, seed=0, kw=dict(zrange=(4.0, 8.0), scale_range=(0.005, 0.05))),
     # the headline scene generator at its full viewport, 1/10 of the Gaussians (the oracle needs ~1 s for it)
     "cfg2_200k_1080p": dict(n=200000, W=1920, H=1080, kw=dict()),
     "cfg4_like_1440p": dict(n=150000, W=2560, H=1440, kw=dict(zrange=(500., 700.))),
@@ -87,7 +90,7 @@ def run_hip(frame, g, gc=None, gd=None, backward=True, debug=True, depth_mode=0,
 @pytest.mark.parametrize("case", list(CASES))
 def test_forward_backward_parity(case):
     c = CASES[case]
-    frame, g = scene(c["n"], c["W"], c["H"], seed=7, **c["kw"])
+    frame, g = scene(c["n"], c["W"], c["H"], seed=c.get("seed", 7), **c["kw"])
     if c.get("zcurve"):
         from sfgs.synth import morton_order
         perm = morton_order(g["means3D"])

@@ -68,7 +68,8 @@ def test_training_loop_of_the_real_classes_hooks_on_equals_hooks_off():
     iteration, densify_and_prune + compute_3D_filter every 10 iterations, reset_opacity once): every hook on == no hook."""
     out, rows = _run("--mode", "train", "--iters", "50", timeout=1200)
     assert "REF-REAL OK 1" in out, out[-2000:]
-    rep = rows[-1]
+    rep = [r for r in rows if r.get("case") == "train"][-1]
     assert rep["iters"] == 50 and len(rep["densify_log"]) >= 3, rep
+    assert rows[-1]["case"] == "train-ok", rows[-1]
     with open(os.path.join(ROOT, "gpurun_out", "reference_real_train.json"), "w") as f:
         json.dump(rep, f)

@@ -49,3 +49,49 @@ def test_all_invisible_and_empty_frames():
     np.testing.assert_array_equal(out["color"], np.zeros_like(out["color"]))   # black background
     for k, v in out["grads"].items():
         assert not np.any(v), k
+
+
+def test_a_reused_settings_tuple_sees_in_place_edits_of_its_camera_tensors():
+    """the wrapper caches the SfgsFrame of a settings tuple that comes back (video / benchmark loops). The
+    reference's world_view_transform is a TRANSPOSED view (scene/cameras.py:62), which the wrapper has to copy to make it
+    contiguous -- a cached copy would freeze the view matrix while campos / bg alias live memory. Moving the camera by
+    editing the tuple's tensors in place must move the picture: same frame as a freshly built tuple."""
+    from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = 192, 128
+    frame, g = scene(3000, W, H, seed=6, zrange=(4., 9.), scale_range=(0.02, 0.3))
+    dev = "cuda"
+    t = {k: v.to(dev) for k, v in g.items() if v is not None}
+
+    def settings(view_t, proj, campos):
+        return GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"], kernel_size=0.1,
+            subpixel_offset=None, bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=view_t, projmatrix=proj,
+            sh_degree=0, campos=campos, prefiltered=False, debug=False)
+
+    def render(s):
+        with torch.no_grad():
+            out = GaussianRasterizer(s)(means3D=t["means3D"], means2D=None, opacities=t["opacities"],
+                                        colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"])
+        return out[0].cpu().numpy()
+    base_view = frame["view"].to(dev)                       # stored transposed, as the reference stores it
+    store = base_view.t().contiguous()                      # ... so that `.t()` of the storage is NON-contiguous
+    view_nc = store.t()
+    assert not view_nc.is_contiguous() and torch.equal(view_nc, base_view)
+    proj, campos = frame["proj"].to(dev).clone(), frame["campos"].to(dev).clone()
+    s = settings(view_nc, proj, campos)
+    a0 = render(s)
+    a1 = render(s)                                          # the same tuple object again
+    np.testing.assert_array_equal(a0, a1)
+    # move the camera 0.3 to the right IN PLACE (world -> view translation row of the transposed matrix, the centre, the
+    # full projection), keeping the tuple
+    shift = torch.tensor([0.3, 0.0, 0.0], device=dev)
+    new_view = base_view.clone()
+    new_view[3, :3] -= shift
+    store.copy_(new_view.t())
+    campos += shift
+    P = torch.linalg.solve(base_view, frame["proj"].to(dev))     # proj = view @ P  (full_proj_transform, cameras.py:73)
+    proj.copy_(new_view @ P)
+    moved_same_tuple = render(s)
+    moved_fresh = render(settings(new_view.contiguous(), proj.clone(), campos.clone()))
+    assert np.abs(moved_fresh - a0).max() > 1e-3            # the picture really changed
+    np.testing.assert_array_equal(moved_same_tuple, moved_fresh)

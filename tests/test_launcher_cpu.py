@@ -36,7 +36,7 @@ import torch
 from torch import nn
 import gm_shim
 scene, plan, out = sys.argv[1], PLANS[sys.argv[2]], sys.argv[3]
-rank = {"A": 0, "B": 1, "C": 2}[scene]
+rank = globals().get("RANKS", {"A": 0, "B": 1, "C": 2})[scene]
 torch.manual_seed(100 + rank)          # DIFFERENT initial MLPs per scene: the launcher must broadcast rank 0's
 orig_to = nn.Module.to
 nn.Module.to = lambda self, *a, **k: self if (a and str(a[0]).startswith("cuda")) else orig_to(self, *a, **k)
@@ -151,3 +151,59 @@ def test_default_is_independent_scenes(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     A, B = (np.load(str(tmp_path / f"{s}.npy")) for s in "AB")
     assert not np.array_equal(A[0], B[0]) and "answered" not in r.stdout
+
+
+JAX_SCENES = ["JAX_004", "JAX_068", "JAX_164", "JAX_168", "JAX_175", "JAX_214", "JAX_260", "JAX_264"]   # data/README.md
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (authoring container)")
+def test_eight_scenes_on_eight_ranks(tmp_path):
+    """N = 8 before a node exists: the farm the launcher replaces runs the 8 JAX scenes on 8 GPUs
+    (scripts/run_jax.py:52-87). Eight ranks over gloo, one scene each, scenes of DIFFERENT length (2 .. 6 steps), the
+    shared-MLP protocol on: every scene starts from rank 0's MLP, all eight stay in lock step while all eight train, every
+    shorter scene drains instead of hanging, the longest finishes alone."""
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    (ref / "gm_shim.py").write_text(SHIM.format(golden=os.path.join(ROOT, "tests", "golden"), ref=REF))
+    steps = dict(zip(JAX_SCENES, [2, 3, 4, 5, 2, 3, 4, 6]))
+    prelude = ("PLANS = %r\nRANKS = %r\n" % ({k: [v] for k, v in steps.items()}, {k: i for i, k in enumerate(JAX_SCENES)}))
+    (ref / "fake_train.py").write_text(prelude + textwrap.dedent(TRAIN))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "launch_scenes.py"), "--reference", str(ref), "--gpus", "8",
+           "--scenes", *JAX_SCENES, "--no-fused", "--shared-mlp", "--model-module", "gm_shim", "--",
+           "fake_train.py", "{scene}", "{scene}", str(tmp_path / "{scene}.npy")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    H = {s: np.load(str(tmp_path / f"{s}.npy")) for s in JAX_SCENES}
+    for s in JAX_SCENES:
+        assert H[s].shape == (steps[s] + 1, 24966), (s, H[s].shape)
+        np.testing.assert_array_equal(H[s][0], H[JAX_SCENES[0]][0], err_msg=f"{s}: did not start from rank 0's MLP")
+    for k in range(min(steps.values()) + 1):                       # all eight train: lock step, bit for bit
+        for s in JAX_SCENES[1:]:
+            np.testing.assert_array_equal(H[s][k], H[JAX_SCENES[0]][k], err_msg=f"{s} step {k}")
+    # while a subset still trains, the subset stays in lock step (the average is over the ranks training in that round)
+    for k in range(min(steps.values()) + 1, 5):
+        alive = [s for s in JAX_SCENES if steps[s] >= k]
+        for s in alive[1:]:
+            np.testing.assert_array_equal(H[s][k], H[alive[0]][k], err_msg=f"{s} step {k} (ranks alive: {len(alive)})")
+    longest = max(steps, key=steps.get)
+    assert not np.array_equal(H[longest][-2], H[longest][-1])
+    assert r.stdout.count("answered") == 8                         # every rank drained at its end (the last one: 0 rounds)
+    for i, s in enumerate(JAX_SCENES):
+        assert f"[launch_scenes rank {i}] {s}:" in r.stdout        # scene i ran on rank i, one scene per rank
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (authoring container)")
+def test_eight_independent_scenes_need_no_process_group(tmp_path):
+    """The default (what the reference's farm does): 8 processes, no collective at all, 8 different MLPs."""
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    (ref / "gm_shim.py").write_text(SHIM.format(golden=os.path.join(ROOT, "tests", "golden"), ref=REF))
+    prelude = ("PLANS = %r\nRANKS = %r\n" % ({k: [1] for k in JAX_SCENES}, {k: i for i, k in enumerate(JAX_SCENES)}))
+    (ref / "fake_train.py").write_text(prelude + textwrap.dedent(TRAIN))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "launch_scenes.py"), "--reference", str(ref), "--gpus", "8",
+           "--scenes", *JAX_SCENES, "--no-fused", "--model-module", "gm_shim", "--",
+           "fake_train.py", "{scene}", "{scene}", str(tmp_path / "{scene}.npy")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    first = [np.load(str(tmp_path / f"{s}.npy"))[0] for s in JAX_SCENES]
+    assert all(not np.array_equal(first[0], f) for f in first[1:]) and "answered" not in r.stdout

@@ -79,3 +79,21 @@ def test_install_patches_get_xyz_and_uninstall_restores():
     finally:
         vd.uninstall(Model)
     assert Model.__dict__["get_xyz"] is orig and Model().get_xyz.__class__ is torch.nn.Parameter
+
+
+def test_attribute_reads_other_than_metadata_come_from_the_tensor_the_handle_stands_for():
+    """the patched `get_xyz` must behave like the reference's `return self._xyz` for `.grad`, `.grad_fn`,
+    `._version`, `.data` too -- and reading them must not switch the recording off."""
+    import torch
+    from sfgs import features, viewdirs
+    p = torch.nn.Parameter(torch.randn(6, 3))
+    p.grad = torch.ones(6, 3)
+    h = viewdirs.LazyDirs(viewdirs.XYZ, p, (6, 3), p)
+    assert h.grad is p.grad and h.grad_fn is None and h._version == p._version and h.is_leaf and h.requires_grad
+    assert h.data.data_ptr() == p.data.data_ptr()
+    d = h - torch.zeros(6, 3)
+    assert isinstance(d, viewdirs.LazyDirs) and d._sfgs_kind == viewdirs.DIRPP          # still recording
+    assert d.grad_fn is not None and d._sfgs_real is not None                             # a result's grad_fn: materialised
+    dc, rest = torch.nn.Parameter(torch.randn(6, 1, 3)), torch.nn.Parameter(torch.randn(6, 3, 3))
+    f = features.DeferredFeatures(dc, rest) if hasattr(features, "DeferredFeatures") else None
+    assert tuple(f.shape) == (6, 4, 3) and f.grad_fn is not None      # cat's node, like the reference's getter
