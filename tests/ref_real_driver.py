@@ -343,6 +343,9 @@ def mode_render(ref, only=None):
 
 
 # ---- mode train --------------------------------------------------------------------------------------------------------
+CHECKPOINTS = (1, 5, 10, 19, 29)     # before the first densification (20) and before reset_opacity (30)
+
+
 def train(ref, hooks, iters, seed=11):
     """The statements of train.py:176-340 on the real classes. Returns (state dict of numpy arrays, losses, log)."""
     import random
@@ -390,6 +393,11 @@ def train(ref, hooks, iters, seed=11):
                     model.reset_opacity()
                 model.optimizer.step()                                                       # :339-340
                 model.optimizer.zero_grad(set_to_none=True)
+                if iteration in CHECKPOINTS:
+                    ck = {k: getattr(model, k).detach().double().cpu().numpy() for k in
+                          ("_xyz", "_features_dc", "_opacity", "_embeddings")}
+                    ck["mlp.2.weight"] = dict(model.appearance_mlp.named_parameters())["mlp.2.weight"].detach().double().cpu().numpy()
+                    log.append(("ckpt", iteration, ck))
         st = {k: getattr(model, k).detach().double().cpu().numpy() for k in
               ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_embeddings",
                "appearance_embeddings", "filter_3D", "xyz_gradient_accum", "xyz_gradient_accum_abs",
@@ -407,6 +415,14 @@ def train(ref, hooks, iters, seed=11):
 def mode_train(ref, iters):
     ref_st, ref_losses, ref_log = train(ref, False, iters)
     got_st, got_losses, got_log = train(ref, True, iters)
+    # how the two trajectories separate over the iterations (diagnostics: a defect shows at iteration 1, the amplification of
+    # float32 rounding by Adam's sign-like steps grows with the iteration count)
+    growth = {}
+    for a, b in zip([e for e in ref_log if e[0] == "ckpt"], [e for e in got_log if e[0] == "ckpt"]):
+        growth[a[1]] = {k: float(np.abs(a[2][k] - b[2][k]).max() / max(np.abs(a[2][k]).max(), 1e-30)) for k in a[2]}
+    print(json.dumps({"case": "train-growth", "max_rel_diff_by_iteration": growth}), flush=True)
+    ref_log = [e for e in ref_log if e[0] != "ckpt"]
+    got_log = [e for e in got_log if e[0] != "ckpt"]
     rep = {"case": "train", "iters": iters, "densify_log": got_log, "final_n": int(got_st["_xyz"].shape[0])}
     assert got_log == ref_log, ("densify_and_prune produced different row counts", got_log, ref_log)
     assert len(ref_log) >= 2 and any(a != b for _, a, b in ref_log), ref_log      # densification really changed the model

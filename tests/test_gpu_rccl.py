@@ -97,3 +97,28 @@ def test_bench_two_ranks_emit_the_line_the_scale_parser_reads():
     rows = line["per_rank_counts"]["rows"]
     assert rows[0] != rows[1] and all(v > 0 for v in rows[0] + rows[1])
     assert line["allreduce_ms_per_step"] is not None
+
+
+def test_bench_eight_ranks_on_the_one_gpu():
+    """N = 8 made boring before a node exists: `bench.py --gpus 8` -- the invocation the driver's
+    scaling run makes -- with the eight ranks sharing this box's one GPU and the collectives over gloo. What is checked
+    is everything but the interconnect: eight processes spawned, eight scenes (seed = rank), the all-reduce in every step
+    paired across eight ranks, one gather of eight rows, ONE JSON line whose value is the eight scenes' Gaussians over the
+    slowest rank's step."""
+    env = dict(_env(), SFGS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--n", "50000", "--width", "480",
+                        "--height", "270", "--steps", "4", "--warmup", "2", "--prewarm-steps", "2", "--settle-steps", "2",
+                        "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["parallelism"] == "scene-per-gpu x8"
+    assert line["rccl"]["world_size"] == 8 and line["rccl"]["ranks_reporting"] == 8 and line["rccl"]["backend"] == "gloo"
+    assert len(line["per_rank_ms_per_step"]) == 8 and len(line["per_rank_counts"]["rows"]) == 8
+    assert len({tuple(r_) for r_ in line["per_rank_counts"]["rows"]}) == 8          # eight different scenes
+    assert abs(line["value"] - 8 * 50000 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 1e-3
+    assert line["allreduce_ms_per_step"] is not None
