@@ -443,12 +443,16 @@ def mode_train(ref, iters):
     np.testing.assert_allclose(got_losses, ref_losses, rtol=5e-5)
     np.testing.assert_array_equal(got_st["denom"], ref_st["denom"])
     # 2. SHORT horizon (iterations 1 and 5): the fused operators are drop-ins, not approximations -- every checkpointed
-    #    tensor agrees to 2e-5 of its range. `_opacity` gets 2e-3: Adam with eps = 1e-15 (scene/gaussian_model.py:382)
-    #    steps lr g / (|g| + eps'), and a handful of nearly invisible Gaussians have |g| ~ 1e-15, where a 1e-7-relative
-    #    difference between two correct float32 gradients moves the step by several per cent of lr = 0.05
+    #    tensor agrees to 2e-5 of its range. The per-Gaussian parameters whose gradient can be ARBITRARILY small (`_opacity`,
+    #    `_embeddings` of nearly invisible Gaussians) get a quarter of one Adam step instead: Adam with eps = 1e-15
+    #    (scene/gaussian_model.py:382) steps lr g / (|g| + eps'), and at |g| ~ 1e-15 a 1e-7-relative difference between two
+    #    correct float32 gradients moves the step by several per cent of lr (measured at iteration 1: 7 % / 5 % of a step)
+    eps_level = {"_opacity": 0.25 * 0.05, "_embeddings": 0.25 * 0.005}          # 0.25 x the group's learning rate
+    ranges = {k: max(float(np.abs(ref_st[k]).max()), 1e-30) for k in ("_opacity", "_embeddings")}
     for it in (1, 5):
         for k, v in growth[it].items():
-            assert v <= (2e-3 if k == "_opacity" else 2e-5), (it, k, v, growth)
+            bar = max(2e-5, eps_level[k] / ranges[k]) if k in eps_level else 2e-5
+            assert v <= bar, (it, k, v, bar, growth)
     # 3. LONG horizon: the two runs are two trajectories of a sensitive dynamical system (Adam's sign-like steps on the
     #    appearance MLP, whose weights feed every Gaussian's colour): float32 rounding differences grow ~10x per 5 iterations
     #    (measured, `max_rel_diff_by_iteration`: mlp.2.weight 1e-8, 1e-6, 3e-4, 1.4e-3, 5e-3 at iterations 1, 5, 10, 19, 29;

@@ -38,12 +38,13 @@ def main():
     m, s, r, o = f32(g["means3D"]), f32(g["scales"]), f32(g["rotations"]), f32(g["opacities"]).reshape(-1)
     TX, TY = (a.width + 7) // 8, (a.height + 7) // 8
     tx0, ty0 = (TX - a.window) // 2, (TY - a.window) // 2
-    out = np.zeros(128, np.float64)
+    out = np.zeros(160, np.float64)
     p = lambda x: x.ctypes.data_as(C.c_void_p)
-    nv = lib.wm_run(C.byref(fr), a.n, p(m), p(s), p(r), p(o), tx0, tx0 + a.window, ty0, ty0 + a.window, p(out), 128)
+    nv = lib.wm_run(C.byref(fr), a.n, p(m), p(s), p(r), p(o), tx0, tx0 + a.window, ty0, ty0 + a.window, p(out), 160)
     names = ["n_tiles", "sumL", "sumK", "hits", "dense16", "sp16", "sp32", "sp64", "spInf", "q16", "q64", "strip16",
              "dead_entries", "live_entries", "behind", "task_nonzero", "task_total", "D_all", "all16_batches",
-             "live16_batches", "f64_bbox", "f64_xy", "f64_exact", "f64_ideal", "f32_bbox", "f32_xy", "f32_exact", "f32_ideal"]
+             "live16_batches", "f64_bbox", "f64_xy", "f64_exact", "f64_ideal", "f32_bbox", "f32_xy", "f32_exact", "f32_ideal",
+             "fwd_steps", "fwd_steps_no_accept", "row_task_nonzero", "row_task_total", "p2_groups_zero", "p2_groups", "sp16_ahead"]
     v = dict(zip(names, out[:nv]))
     T = v["n_tiles"]
     print(f"tiles {T:.0f}  mean list {v['sumL']/T:.1f}  mean kmax {v['sumK']/T:.1f}  D_all {v['D_all']:.0f}")
@@ -56,6 +57,14 @@ def main():
     for k in ("f64_bbox", "f64_xy", "f64_exact", "f64_ideal", "f32_bbox", "f32_xy", "f32_exact", "f32_ideal"):
         print(f"  forward strip-list steps {k:10s}: {v[k]/v['sumK']:.3f} of kmax")
     print(f"16-batches after dropping dead entries: {v['live16_batches']/v['all16_batches']:.3f}")
+    # round 5: what the "skip work nobody needs" ideas could skip
+    print(f"forward (TRAIN, 32-entry halves): strip-list steps in which NO lane of the wave blends its entry: "
+          f"{v['fwd_steps_no_accept']/v['fwd_steps']:.4f} of {v['fwd_steps']/K:.3f} kmax steps  (wave-uniform early-out of the blend block)")
+    print(f"phase 2: 4-pixel groups that are zero in every lane of a 16-entry batch: {v['p2_groups_zero']/v['p2_groups']:.4f}  "
+          f"(skip by a scalar branch on the batch's hit bits)")
+    print(f"phase 2 compaction: live (entry, 2 pixel rows) tasks {v['task_nonzero']/v['task_total']:.3f}, live (entry, 1 pixel row) tasks "
+          f"{v['row_task_nonzero']/v['row_task_total']:.3f}  (a pass of 64 lanes is saved only below 0.5)")
+    print(f"phase 1, batches of 16, an idle lane may take ONE hit of the next batch early: {v['sp16_ahead']/K:.3f} of kmax (now {v['sp16']/K:.3f})")
     h = out[nv:nv + 65]
     cum = np.cumsum(h) / h.sum()
     print("hits/entry quantiles:", {q: int(np.searchsorted(cum, q)) for q in (0.1, 0.25, 0.5, 0.75, 0.9, 0.99)})

@@ -64,6 +64,12 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
   double hist_hits[65] = {0};
   double live16_batches = 0, all16_batches = 0;           // batches (of 16) after dropping dead entries
   double fstrip64[4] = {0, 0, 0, 0}, fstrip32[4] = {0, 0, 0, 0};   // forward strip-list steps (see below)
+  // round 5:
+  double fwd_steps = 0, fwd_steps_no_accept = 0;   // strip-list steps of the forward (32-entry halves, bbox lists) / those in
+                                                   // which NO lane of the wave blends (a wave-uniform early-out could skip the blend)
+  double row_task_nonzero = 0, row_task_total = 0; // (entry, single pixel row) tasks of phase 2 with at least one blended pixel
+  double p2_groups_zero = 0, p2_groups = 0;        // phase 2's 4-pixel groups (per batch of 16: 4 groups x 64 lanes) that are zero in EVERY lane
+  double sp16_ahead = 0;                           // phase-1 steps with batches of 16 when an idle lane may take ONE hit of the next batch early
   for (int ty = 0; ty < wy; ++ty)
     for (int tx = 0; tx < wx; ++tx) {
       auto& l = lists[(size_t)ty * wx + tx];
@@ -99,6 +105,29 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
         for (int p = 0; p < 64; ++p) pixhits[p] += (emask[k] >> p) & 1;
       }
       all16_batches += (kmax + 15) / 16; live16_batches += (nlive + 15) / 16;
+      for (int k = 0; k < kmax; ++k)
+        for (int r = 0; r < 8; ++r) { row_task_total += 1; if ((emask[k] >> (8 * r)) & 0xffull) row_task_nonzero += 1; }
+      // phase 2: lane (entry e, quarter q) of a 16-entry batch handles pixels 16 q + I; group g = steps I in [4g, 4g+4)
+      for (int b0 = 0; b0 < kmax; b0 += 16)
+        for (int grp = 0; grp < 4; ++grp) {
+          bool any = false;
+          for (int k = b0; k < std::min(kmax, b0 + 16) && !any; ++k)
+            for (int q = 0; q < 4 && !any; ++q)
+              if ((emask[k] >> (16 * q + 4 * grp)) & 0xfull) any = true;
+          p2_groups += 1; if (!any) p2_groups_zero += 1;
+        }
+      {   // one-hit-ahead phase 1: walk the batches back to front like the kernel does
+        int ahead[64] = {0};
+        for (int b0 = ((kmax - 1) / 16) * 16; b0 >= 0; b0 -= 16) {
+          int cnt[64] = {0}, nxt[64] = {0};
+          for (int k = b0; k < std::min(kmax, b0 + 16); ++k) for (int p = 0; p < 64; ++p) cnt[p] += (emask[k] >> p) & 1;
+          if (b0 >= 16) for (int k = b0 - 16; k < b0; ++k) for (int p = 0; p < 64; ++p) nxt[p] += (emask[k] >> p) & 1;
+          int steps = 0;
+          for (int p = 0; p < 64; ++p) steps = std::max(steps, cnt[p] - ahead[p]);
+          sp16_ahead += steps;
+          for (int p = 0; p < 64; ++p) { const int mine = cnt[p] - ahead[p]; ahead[p] = (mine < steps && nxt[p] > 0) ? 1 : 0; }
+        }
+      }
       spInf += *std::max_element(pixhits, pixhits + 64);
       auto sparse = [&](int B) {
         double steps = 0;
@@ -171,10 +200,33 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
         return steps;
       };
       for (int m = 0; m < 4; ++m) { fstrip64[m] += fwd(64, m); fstrip32[m] += fwd(32, m); }
+      {   // the forward as shipped (TRAIN: halves of 32 entries, y-extent strip lists in lockstep): in how many of its steps does
+          // no lane of the wave accept its entry? (each strip is on ITS i-th entry of the half)
+        const float Y0 = (float)((ty0 + ty) * 8);
+        for (int b0 = 0; b0 < kmax; b0 += 32) {
+          std::vector<int> lst[4];
+          for (int k = b0; k < std::min(kmax, b0 + 32); ++k) {
+            const SplatRec& r = recs[(unsigned)(l[k] & 0xffffffffull)];
+            for (int q = 0; q < 4; ++q) {
+              const float y0 = Y0 + 2.f * q, y1 = y0 + 1.f;
+              if (!(r.my + r.ey < y0) && !(r.my - r.ey > y1)) lst[q].push_back(k);
+            }
+          }
+          size_t ml = 0;
+          for (int q = 0; q < 4; ++q) ml = std::max(ml, lst[q].size());
+          for (size_t i = 0; i < ml; ++i) {
+            bool any = false;
+            for (int q = 0; q < 4; ++q)
+              if (i < lst[q].size() && ((emask[lst[q][i]] >> (16 * q)) & 0xffffull)) any = true;
+            fwd_steps += 1; if (!any) fwd_steps_no_accept += 1;
+          }
+        }
+      }
     }
   double vals[] = {n_tiles, sumL, sumK, hits, dense16, sp16, sp32, sp64, spInf, q16, q64, strip16, dead_entries,
                    live_entries, behind, task_nonzero, task_total, (double)D_all, all16_batches, live16_batches,
-                   fstrip64[0], fstrip64[1], fstrip64[2], fstrip64[3], fstrip32[0], fstrip32[1], fstrip32[2], fstrip32[3]};
+                   fstrip64[0], fstrip64[1], fstrip64[2], fstrip64[3], fstrip32[0], fstrip32[1], fstrip32[2], fstrip32[3],
+                   fwd_steps, fwd_steps_no_accept, row_task_nonzero, row_task_total, p2_groups_zero, p2_groups, sp16_ahead};
   int nv = (int)(sizeof(vals) / sizeof(vals[0]));
   for (int i = 0; i < nv && i < n_out; ++i) out[i] = vals[i];
   for (int i = 0; i < 65 && nv + i < n_out; ++i) out[nv + i] = hist_hits[i];
