@@ -2,7 +2,11 @@
 (the reference's save_fused_ply format, scene/gaussian_model.py:438-481) -> sfgs.ply.merge_fused_plys with world
 offsets -> load_standard_ply (render_video_from_ply.py:229-275) -> band-sharded render. The assembled frame must equal
 the single-GPU frame BIT FOR BIT, both with the ranks emulated in one process (world = 8) and through
-sfgs.shard.render_joint / gather_bands on real processes (gloo, bands staged through host memory)."""
+sfgs.shard.render_joint / gather_bands on real processes (gloo, bands staged through host memory).
+
+ROUTE-EQUALITY tests (HIP vs HIP): they establish sharded == single pass. The single pass is pinned to the C oracle by
+tests/test_gpu_raster.py / test_gpu_fullsize_parity.py (up to 5 M Gaussians), and the sharded routes themselves are compared
+with the oracle AT SIZE -- 16 M Gaussians, both shardings -- by tests/test_gpu_joint_fullsize.py."""
 import os
 import socket
 import types

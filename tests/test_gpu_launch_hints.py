@@ -3,7 +3,12 @@ kernels -- huge-splat walk, long-list sorts, dead-entry prefill, chunk pre-reduc
 previous frames say they have work. A WRONG prediction must never change a result: the huge-splat hint is verified
 against the plan's own count and the frame redone, the others are correct by construction. Every case renders a
 sequence of frames whose character changes abruptly, once with the mechanism on and once with SFGS_HINTS=0, and compares
-bit for bit (images, radii, every gradient)."""
+bit for bit (images, radii, every gradient).
+
+These are ROUTE-EQUALITY tests: both sides are the HIP library. What they establish is that the hinted route equals the
+unhinted one; the unhinted route (every optional kernel launched, two-kernel sort) is the one pinned to the C oracle --
+tests/test_gpu_raster.py::test_forward_backward_parity (first frame of a process: no hint learnt yet) and, for the hinted
+routes at size, tests/test_gpu_fullsize_parity.py (frame 3, route asserted from the hint word)."""
 import os
 
 import numpy as np

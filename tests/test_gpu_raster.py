@@ -381,7 +381,8 @@ def test_skewed_workgroups_and_the_duplicate_index_pools():
 @pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p", "uhd_two_bin_rounds",
                                   "mid_splats_many_items", "skewed_far_view"])
 def test_two_pass_binning_equals_the_direct_path(case, sfgs_option):
-    """Two-pass binning (pair list + bin_scatter_kernel, the default) and the one-pass path with one device atomic per
+    """ROUTE-EQUALITY test (HIP vs HIP; the default route of every case is pinned to the oracle by
+    test_forward_backward_parity above). Two-pass binning (pair list + bin_scatter_kernel, the default) and the one-pass path with one device atomic per
     coarse item (option "binning" = "direct") build the same frame: duplicate indices come from the same scan and every tile list
     is sorted by (depth, id), so images, radii, counters and every gradient are equal bit for bit."""
     c = CASES.get(case) or BINNING_CASES[case]
@@ -448,7 +449,8 @@ def test_a_skewed_frame_needs_no_per_bin_capacity():
 @pytest.mark.parametrize("case", ["precomp_small", "sh1_ragged", "cfg2_like", "big_splats", "screen_filling", "lists_800",
                                   "lists_2k", "lists_6k", "lists_10k", "cfg2_200k_1080p", "uhd_two_bin_rounds"])
 def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, sfgs_option):
-    """select_sort_kernel (a workgroup hands a coarse bin's items to the LDS lists of a row of tiles, every wave sorts its
+    """ROUTE-EQUALITY test (HIP vs HIP; the default route of every case is pinned to the oracle by
+    test_forward_backward_parity above). select_sort_kernel (a workgroup hands a coarse bin's items to the LDS lists of a row of tiles, every wave sorts its
     tile in registers and writes the final lists; the route the SHORT_LISTS hint selects, forced here) and the two-kernel route with the per-tile items in memory between them
     (option "sort" = "split": fine_bin + sort_tiles_reg) build the same lists -- same members, same (depth, id) order, same
     duplicate indices; only WHERE a tile's list sits inside its bin's slot range may differ -- so images, radii,

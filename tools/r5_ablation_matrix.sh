@@ -1,5 +1,11 @@
 #!/bin/bash
-# round 5, GPU call 1: composite_bwd ablation matrix, the registers-instead-of-DPP variant, LDS-conflict attribution
+# round 5 (gpurun): composite_bwd ablation matrix, the registers-instead-of-DPP variant, LDS-conflict attribution
+# -> profiles/r5_bwd_ablation_matrix_ab.txt. Build the variants first, in the authoring container (they travel with the snapshot):
+#   P=tools/variants/bwd_lab_r5.patch
+#   tools/build_variant.sh base "" ; tools/build_variant.sh noexp "-DSFGS_BWD_ABLATE=32" $P ; tools/build_variant.sh noexprcp "-DSFGS_BWD_ABLATE=96" $P
+#   tools/build_variant.sh nop1 "-DSFGS_BWD_ABLATE=2" $P ; tools/build_variant.sh nop2 "-DSFGS_BWD_ABLATE=4" $P ; tools/build_variant.sh nop1p2 "-DSFGS_BWD_ABLATE=6" $P
+#   tools/build_variant.sh skel "-DSFGS_BWD_ABLATE=30" $P ; tools/build_variant.sh greg2 "-DSFGS_BWD_GREG=2" $P
+#   tools/build_variant.sh greg4o12 "-DSFGS_BWD_GREG=4 -DSFGS_BWD_OCC=12" $P
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 O=gpurun_out/r5c1; mkdir -p $O
 E=skyfall-gs_amd/sfgs/_exp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call 6: the whole -m gpu suite on the final tree, the round's measurement set and the rocprofv3 / PMC passes
+# round 5 (gpurun): the whole -m gpu suite on the final tree, the round's measurement set and the rocprofv3 / PMC passes
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 O=gpurun_out/r5c6; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q > $O/tests.txt 2>&1; tail -6 $O/tests.txt | cut -c1-600
