@@ -173,14 +173,26 @@ def set_option(key, value):
     lib = load()
     old = lib.sfgs_get_option(str(key).encode())
     check(lib.sfgs_set_option(str(key).encode(), str(value).encode()))   # raises for an unknown key or value
+    _opt_cache[key] = str(value)
     return old.decode()
 
 
+_opt_cache = {}   # key -> value as last read / set through THIS module (the wrapper asks once per frame: a dict lookup, not a
+                  # C call; a C caller that changes an option behind Python's back must call refresh_options())
+
+
 def get_option(key):
-    v = load().sfgs_get_option(str(key).encode())
+    v = _opt_cache.get(key)
     if v is None:
-        raise KeyError(f"libsfgs.so has no option {key!r}")
-    return v.decode()
+        raw = load().sfgs_get_option(str(key).encode())
+        if raw is None:
+            raise KeyError(f"libsfgs.so has no option {key!r}")
+        v = _opt_cache[key] = raw.decode()
+    return v
+
+
+def refresh_options():
+    _opt_cache.clear()
 
 
 def profile_enable(on=True):
