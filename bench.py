@@ -292,6 +292,27 @@ def main():
     prof = L.profile_collect()
     L.profile_enable(False)
     L.profile_select(None)
+    # Is the HOST ever the bottleneck? After the timed region (never inside it), SPAN_STEPS more steps with ONE event in front
+    # of and one behind every step on the launch stream and no per-kernel bracket: `gpu_span` = first launch .. last kernel of
+    # a step, `gpu_gap_between_steps` = end of a step .. start of the next. While the host runs ahead the gap is the cost of
+    # the two event records; when the GPU waits for the host it is that wait. (The per-kernel brackets cannot answer this:
+    # each carries a few us of event overhead, and their sum is not the step -- rocprofv3's kernel trace of the headline shows
+    # the kernels back to back: 940.6 us of kernels in a 942.4 us step, profiles/r5_v1_rocprofv3_100steps.txt.)
+    span = None
+    if not args.forward_only:
+        SPAN_STEPS = 20
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SPAN_STEPS)]
+        for a_, b_ in evs:
+            a_.record()
+            step()
+            b_.record()
+        torch.cuda.synchronize(dev)
+        spans = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        gaps = sorted(evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(SPAN_STEPS - 1))
+        span = {"steps": SPAN_STEPS, "gpu_span_ms_per_step": round(spans[len(spans) // 2], 4),
+                "gpu_gap_between_steps_ms": round(gaps[len(gaps) // 2], 4),
+                "what": "median over untimed steps after the timed region: events in front of and behind every step on the launch "
+                        "stream; a gap above the cost of two event records (~0.01 ms) means the GPU waited for the host"}
 
     per_rank_ms = [elapsed / args.steps * 1e3]
     cnt = last_counters()
@@ -376,7 +397,9 @@ def main():
                      "event_pair_us": round(event_pair_ms * 1e3, 2),
                      "gpu_busy_ms_per_step": round(sum(max(v["ms_per_step"] - event_pair_ms * v["launches"] / max(
                          args.steps if k == dom else n_prof, 1), 0.0) for k, v in per_kernel.items()), 4),
-                     "gpu_busy_source": "sum of the brackets minus the measured cost of an empty event pair per launch"}
+                     "gpu_busy_source": "sum of the brackets minus the measured cost of an empty event pair per launch (a LOWER "
+                                        "bound: the subtraction over-corrects; see host_bound for whether the GPU ever waits)",
+                     "host_bound": span}
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only and args.config == "cfg2":

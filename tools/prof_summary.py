@@ -46,6 +46,28 @@ def gap_stats(path):
             by_next.setdefault(short(n1), []).append(g)
     if not gaps:
         return
+    # per STEP (= per launch of the dominant backward kernel): time with at least one kernel running vs idle time, over the
+    # steady part of the trace (between the first and the last composite_bwd launch) -- the answer to "does the GPU ever wait
+    # for the host" (kernels of one stream may overlap at their edges: the union of the intervals is what counts)
+    steps = [(s0, e0) for n0, s0, e0 in rows if "composite_bwd" in n0]
+    if len(steps) > 10:
+        t0, t1 = steps[5][0], steps[-1][0]      # from the 6th step's backward to the last step's backward
+        busy, cur_s, cur_e = 0, None, None
+        for n0, s0, e0 in rows:
+            if e0 <= t0 or s0 >= t1:
+                continue
+            s0, e0 = max(s0, t0), min(e0, t1)
+            if cur_e is None or s0 > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                cur_s, cur_e = s0, e0
+            else:
+                cur_e = max(cur_e, e0)
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        nsteps = len(steps) - 1 - 5
+        print(f"# steady state, {nsteps} steps: {(t1 - t0) / nsteps / 1e3:.1f} us per step, a kernel running {busy / nsteps / 1e3:.1f} us of it "
+              f"-> GPU idle {(t1 - t0 - busy) / nsteps / 1e3:.1f} us per step ({100.0 * (t1 - t0 - busy) / (t1 - t0):.1f} %)")
     gaps.sort()
     print(f"# dispatch gaps between consecutive kernels (us): n={len(gaps)} median={gaps[len(gaps)//2]:.2f} "
           f"mean={sum(gaps)/len(gaps):.2f} p90={gaps[int(0.9*len(gaps))]:.2f}")
