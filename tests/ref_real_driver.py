@@ -444,10 +444,10 @@ def mode_train(ref, iters):
     np.testing.assert_array_equal(got_st["denom"], ref_st["denom"])
     # 2. SHORT horizon (iterations 1 and 5): the fused operators are drop-ins, not approximations -- every checkpointed
     #    tensor agrees to 2e-5 of its range. The per-Gaussian parameters whose gradient can be ARBITRARILY small (`_opacity`,
-    #    `_embeddings` of nearly invisible Gaussians) get a quarter of one Adam step instead: Adam with eps = 1e-15
+    #    `_embeddings` of nearly invisible Gaussians) get half of one Adam step instead: Adam with eps = 1e-15
     #    (scene/gaussian_model.py:382) steps lr g / (|g| + eps'), and at |g| ~ 1e-15 a 1e-7-relative difference between two
     #    correct float32 gradients moves the step by several per cent of lr (measured at iteration 1: 7 % / 5 % of a step)
-    eps_level = {"_opacity": 0.25 * 0.05, "_embeddings": 0.25 * 0.005}          # 0.25 x the group's learning rate
+    eps_level = {"_opacity": 0.5 * 0.05, "_embeddings": 0.5 * 0.005}            # half a step of the group's learning rate
     ranges = {k: max(float(np.abs(ref_st[k]).max()), 1e-30) for k in ("_opacity", "_embeddings")}
     for it in (1, 5):
         for k, v in growth[it].items():

@@ -11,14 +11,14 @@ from sfgs import features, viewdirs as vd
 OPS = {
     "add_scalar": lambda t: t + 1.5,
     "radd": lambda t: 2.0 + t,
-    "mul_tensor": lambda t: t * torch.arange(t.numel(), dtype=t.dtype).reshape(t.shape),
+    "mul_tensor": lambda t: t * torch.arange(t.numel(), dtype=t.dtype, device=t.device).reshape(t.shape),
     "neg": lambda t: -t,
     "pow": lambda t: t ** 2,
-    "matmul": lambda t: t.reshape(t.shape[0], -1) @ torch.ones(t.reshape(t.shape[0], -1).shape[1], 2, dtype=t.dtype),
+    "matmul": lambda t: t.reshape(t.shape[0], -1) @ torch.ones(t.reshape(t.shape[0], -1).shape[1], 2, dtype=t.dtype, device=t.device),
     "gt": lambda t: t > 0.1,
     "index_int": lambda t: t[1],
     "index_slice": lambda t: t[1:4],
-    "index_mask": lambda t: t[torch.arange(t.shape[0]) % 2 == 0],
+    "index_mask": lambda t: t[torch.arange(t.shape[0], device=t.device) % 2 == 0],
     "index_ellipsis": lambda t: t[..., 0],
     "reshape": lambda t: t.reshape(-1),
     "flatten": lambda t: t.flatten(1),
@@ -39,25 +39,25 @@ OPS = {
     "zeros_like": lambda t: torch.zeros_like(t),
     "isnan_any": lambda t: torch.isnan(t).any(),
     "tolist_len": lambda t: torch.tensor(len(t.tolist())),
-    "numpy": lambda t: torch.from_numpy(t.detach().numpy().copy()),
+    "numpy": lambda t: torch.from_numpy(t.detach().cpu().numpy().copy()),
     "expand_as": lambda t: t[:1].expand_as(t),
     "chunk": lambda t: t.chunk(2, dim=0)[0],
 }
 
 
-def _features():
+def _features(device="cpu"):
     gen = torch.Generator().manual_seed(0)
-    dc = torch.randn(6, 1, 3, generator=gen).requires_grad_(True)
-    rest = torch.randn(6, 3, 3, generator=gen).requires_grad_(True)
+    dc = torch.randn(6, 1, 3, generator=gen).to(device).requires_grad_(True)
+    rest = torch.randn(6, 3, 3, generator=gen).to(device).requires_grad_(True)
     return {"features": (lambda: features.DeferredFeatures(dc, rest), lambda: torch.cat((dc, rest), dim=1), (dc, rest)),
             "features_T": (lambda: features.DeferredFeatures(dc, rest).transpose(1, 2),
                            lambda: torch.cat((dc, rest), dim=1).transpose(1, 2), (dc, rest))}
 
 
-def _dirs():
+def _dirs(device="cpu"):
     gen = torch.Generator().manual_seed(1)
-    xyz = torch.nn.Parameter(torch.randn(6, 3, generator=gen))
-    c = torch.randn(3, generator=gen).repeat(6, 1)
+    xyz = torch.nn.Parameter(torch.randn(6, 3, generator=gen).to(device))
+    c = torch.randn(3, generator=gen).to(device).repeat(6, 1)
     h = lambda: vd.LazyDirs(vd.XYZ, xyz, tuple(xyz.shape), xyz)
     return {"xyz": (h, lambda: xyz, (xyz,)),
             "dir_pp": (lambda: h() - c, lambda: xyz - c, (xyz,)),
@@ -67,19 +67,18 @@ def _dirs():
 
 
 HANDLES = {**_features(), **_dirs()}
+KINDS = sorted(HANDLES)
 
 
-@pytest.mark.parametrize("op", sorted(OPS))
-@pytest.mark.parametrize("kind", sorted(HANDLES))
-def test_any_operation_on_a_handle_equals_the_operation_on_the_tensor(kind, op):
-    make_handle, make_real, leaves = HANDLES[kind]
+def check_operation(handles, kind, op):
+    make_handle, make_real, leaves = handles[kind]
     h, r = make_handle(), make_real()
     assert isinstance(h, (features.DeferredFeatures, vd.LazyDirs)) and tuple(h.shape) == tuple(r.shape)
     assert h.dtype == r.dtype and h.device == r.device and h.requires_grad == r.requires_grad and h.dim() == r.dim()
     got, ref = OPS[op](h), OPS[op](r)
     assert type(got) is type(ref) or isinstance(got, torch.Tensor)
     assert not isinstance(got, (features.DeferredFeatures, vd.LazyDirs)), "an arbitrary operation returns a real tensor"
-    assert got.shape == ref.shape and got.dtype == ref.dtype
+    assert got.shape == ref.shape and got.dtype == ref.dtype and got.device == ref.device
     assert torch.equal(got, ref)
     if got.requires_grad and got.is_floating_point():
         for t in leaves:
@@ -91,3 +90,9 @@ def test_any_operation_on_a_handle_equals_the_operation_on_the_tensor(kind, op):
         OPS[op](make_real()).sum().backward()
         for a, t in zip(g1, leaves):
             assert torch.equal(a, t.grad)
+
+
+@pytest.mark.parametrize("op", sorted(OPS))
+@pytest.mark.parametrize("kind", KINDS)
+def test_any_operation_on_a_handle_equals_the_operation_on_the_tensor(kind, op):
+    check_operation(HANDLES, kind, op)
