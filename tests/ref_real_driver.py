@@ -110,7 +110,9 @@ def make_cameras(Camera, n=4):
     return cams
 
 
-def make_model(GaussianModel, appearance, cams, seed, n=N, scale_range=(0.01, 0.15)):
+def make_model(GaussianModel, appearance, cams, seed, n=None, scale_range=None):
+    n = N if n is None else n
+    scale_range = scale_range or ((0.01, 0.15) if W < 1000 else (0.004, 0.05))
     from torch import nn
     from sfgs.synth import scene
     _, g = scene(n, W, H, seed=seed, zrange=(4.0, 8.0), scale_range=scale_range, xy_fill=1.05)
@@ -303,10 +305,22 @@ def one_pass(ref, case, route):
             uninstall_all(GaussianModel, renderer)
 
 
-def compare(name, got, ref):
+def compare(name, got, ref, hooks=False):
     import parity
     rep = {"case": name}
-    np.testing.assert_array_equal(got["out_radii"], ref["out_radii"], err_msg=name + ": radii")
+    if not hooks:
+        np.testing.assert_array_equal(got["out_radii"], ref["out_radii"], err_msg=name + ": radii")
+    else:
+        # With the hooks the rasterizer evaluates exp / sigmoid / normalize of the RAW parameters itself (act_math.h, pinned bit
+        # for bit to the getters' CPU values: tests/test_prepass.py); the oracle pass was fed what torch's GPU kernels made of
+        # the same parameters. Two correct float32 evaluations of one formula may differ in the last ulp (reduction order of
+        # F.normalize's norm, the exponential's last bit), and radius = ceil(3 sigma) then flips by one for a Gaussian that sits
+        # on an integer boundary: observed 2 of 500 000 at 1080p, 0 of 20 000 in the small cases. Allowed: a handful, by exactly 1.
+        d = got["out_radii"].astype(np.int64) - ref["out_radii"].astype(np.int64)
+        nflip = int((d != 0).sum())
+        rep["radii_flips"] = nflip
+        assert nflip <= max(2, int(2e-5 * d.size)) and (np.abs(d).max() if nflip else 0) <= 1, (name, nflip, np.abs(d).max())
+        assert np.array_equal(got["out_radii"] > 0, ref["out_radii"] > 0), name + ": visibility differs"
     for k in ("render", "depth", "alpha"):
         r = parity.assert_image_close(f"{name}:{k}", got["out_" + k], ref["out_" + k], borderline_min=4)
         rep[k] = [r["max_rel"], r["bad"]]
@@ -328,15 +342,23 @@ def compare(name, got, ref):
     return rep
 
 
-def mode_render(ref, only=None):
+LARGE_CASES = [dict(name="A_mlp_1080p_500k", colour="A", jitter=False, cam=0, bg=0.0),
+               dict(name="B_sh_kernel_1080p_500k_jitter", colour="B", jitter=True, cam=1, bg=0.0)]
+
+
+def mode_render(ref, only=None, large=False):
+    global W, H, N
+    if large:       # the training viewport and configs[1]'s starting size: the same comparisons at 1920x1080 / 500 000 Gaussians
+        W, H, N = 1920, 1080, 500_000
+        os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
     n = 0
-    for case in CASES:
+    for case in (LARGE_CASES if large else CASES):
         if only and case["name"] not in only:
             continue
         orc = one_pass(ref, case, "oracle")
         for route in ("hip", "hip+hooks"):
             got = one_pass(ref, case, route)
-            rep = compare(f"{case['name']}[{route}]", got, orc)
+            rep = compare(f"{case['name']}[{route}]", got, orc, hooks=route == "hip+hooks")
             rep["handles"], rep["route"] = got["handles"], got["route"]
             print(json.dumps(rep), flush=True)
             n += 1
@@ -481,6 +503,7 @@ def main():
     ap.add_argument("--mode", choices=["render", "train"], required=True)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--large", action="store_true", help="mode render: two cases at 1920x1080 with 500 000 Gaussians")
     a = ap.parse_args()
     path = locate_reference()
     if path is None:
@@ -491,7 +514,7 @@ def main():
     from sfgs import _lib as L
     L.load()
     print(json.dumps({"reference": path, "libsfgs": L.LIB_PATH}), flush=True)
-    n = mode_render(ref, a.only) if a.mode == "render" else mode_train(ref, a.iters)
+    n = mode_render(ref, a.only, a.large) if a.mode == "render" else mode_train(ref, a.iters)
     print(f"REF-REAL OK {n}")
     return 0
 

@@ -73,3 +73,16 @@ def test_training_loop_of_the_real_classes_hooks_on_equals_hooks_off():
     assert rows[-1]["case"] == "train-ok", rows[-1]
     with open(os.path.join(ROOT, "gpurun_out", "reference_real_train.json"), "w") as f:
         json.dump(rep, f)
+
+
+@needs_ref
+def test_real_render_on_real_model_at_the_training_viewport():
+    """The same three-way comparison at 1920x1080 with 500 000 Gaussians (configs[1]'s starting size): the appearance path
+    and the in-kernel SH path with ray jitter, hooks off and on, against the oracle."""
+    out, rows = _run("--mode", "render", "--large", timeout=1500)
+    assert "REF-REAL OK 4" in out, out[-2000:]
+    cases = rows[1:]
+    assert len(cases) == 4 and all(c["worst_grad_rel_l2"] <= 1e-3 for c in cases), cases
+    with open(os.path.join(ROOT, "gpurun_out", "reference_real_render_1080p.jsonl"), "w") as f:
+        for c in rows:
+            f.write(json.dumps(c) + "\n")
