@@ -46,6 +46,27 @@ def test_fused_ssim_1080p_against_oracle_and_determinism():
     assert abs(float(s) - 1.0) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 1, 1, 7), (1, 2, 5, 3), (2, 1, 4, 43), (1, 1, 21, 31), (1, 3, 22, 32),
+                                   (1, 1, 23, 33), (1, 2, 44, 64), (2, 3, 45, 65), (1, 1, 100, 37), (1, 1, 67, 130),
+                                   (1, 1, 11, 200)])
+def test_fused_ssim_at_tile_boundaries_and_tiny_images_against_oracle(shape):
+    """Image sizes around the kernel's 32 x 22 output tile and its 5-pixel halo (one short of, equal to, one past a tile;
+    images smaller than the window; widths that are not a multiple of 4; batches and channels): value, per-pixel map
+    through the gradient, and the train=False route, against the oracle."""
+    from fused_ssim import fused_ssim
+    g = torch.Generator().manual_seed(shape[2] * 1000 + shape[3])
+    a = torch.rand(*shape, generator=g)
+    b = (a + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    val, _, grad = orc.ssim(a.numpy(), b.numpy(), want_grad=True)
+    x = a.to(DEV).requires_grad_(True)
+    v = fused_ssim(x, b.to(DEV))
+    v.backward()
+    assert abs(float(v.detach()) - val) < 2e-6
+    assert np.abs(x.grad.cpu().numpy() - grad).max() <= 5e-5 * np.abs(grad).max() + 1e-9
+    assert float(fused_ssim(a.to(DEV), b.to(DEV), train=False)) == float(v.detach())
+    assert abs(float(fused_ssim(b.to(DEV), b.to(DEV), train=False)) - 1.0) < 1e-6
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 1000, 20000])
 def test_distcuda2_matches_brute_force_oracle(n):
     from simple_knn._C import distCUDA2

@@ -29,6 +29,24 @@ def kernel_stats(path):
     print()
 
 
+def kernel_stats_by_grid(path, pattern):
+    """average duration per (kernel, launch grid): separates the image sizes of one kernel in a trace of several"""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    grid = [c for c in cols if "grid" in c.lower()]
+    if not grid:
+        print(f"# by grid: no grid column among {cols}")
+        return
+    sel = ", ".join(grid)
+    rows = cur.execute(f"select name, {sel}, count(*), avg(duration), min(duration) from kernels group by name, {sel} "
+                       "order by name, avg(duration)").fetchall()
+    print(f"# per launch grid ({sel}) -- kernels matching '{pattern}'")
+    for r in rows:
+        if pattern in r[0]:
+            print(f"{short(r[0]):32s} grid {tuple(r[1:1 + len(grid)])!s:24s} calls {r[-3]:5d}  avg_us {r[-2] / 1e3:9.2f}  min_us {r[-1] / 1e3:9.2f}")
+    print()
+
+
 def gap_stats(path):
     """Idle time between consecutive kernels on the device (dispatch gaps of dependent launches): end of one kernel to
     the start of the next, over the whole trace; gaps above 50 us (host-side pauses between steps) are left out."""
@@ -168,6 +186,11 @@ if __name__ == "__main__":
         i = args.index("--json")
         json_out = args[i + 1]
         args = args[:i] + args[i + 2:]
+    by_grid = None
+    if "--by-grid" in args:
+        i = args.index("--by-grid")
+        by_grid = args[i + 1]
+        args = args[:i] + args[i + 2:]
     if "--pmc" in args:
         i = args.index("--pmc")
         kts, pmcs = args[:i], args[i + 1:]
@@ -175,6 +198,8 @@ if __name__ == "__main__":
         kts, pmcs = args, []
     for p in kts:
         kernel_stats(p)
+        if by_grid:
+            kernel_stats_by_grid(p, by_grid)
         gap_stats(p)
     for p in pmcs:
         pmc_stats(p)
