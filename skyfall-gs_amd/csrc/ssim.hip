@@ -70,6 +70,23 @@ __device__ __forceinline__ uint32_t halo_row(int row, int y0, int H, int W, bool
   return (uint32_t)min(max(gy, 0), H - 1) * (uint32_t)W * 4u;
 }
 
+// Workgroup -> tile. The hardware deals workgroups to the 8 XCDs round-robin by linear id, and each XCD has its own L2:
+// with tile = workgroup id, the four neighbours whose halos overlap a tile's (10 of its 32 staged rows, 10 of its 42
+// columns) run on OTHER XCDs and every XCD pulls its own copy of the shared lines through the fabric -- 2.7x the
+// algorithmic bytes for the backward kernel. So XCD k takes the k-th CONTIGUOUS eighth of the tiles (row-major within a
+// plane), in order: what it has in flight at any time is a band of a few tile rows, whose halos meet in its L2.
+// Returns the tile's index in plane-major, row-major order (also the index of its partial sum).
+struct SsimTile { int index, plane, x0, y0; };
+__device__ __forceinline__ SsimTile ssim_tile(int tiles_x, int tiles_y) {
+  const int n = gridDim.x, id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int L = xcd * (n >> 3) + min(xcd, n & 7) + slot;   // XCD k owns ceil((n - k) / 8) tiles, starting here
+  const int per_plane = tiles_x * tiles_y;
+  const int plane = L / per_plane, rem = L - plane * per_plane;
+  const int by = rem / tiles_x, bx = rem - by * tiles_x;
+  return {L, plane, bx * ST, by * STY};
+}
+
 // hz row of tap k of the vertical window that starts at row ly0 <= STY - 1: only the taps of the output rows that do not
 // exist (22, 23) can pass the last staged row, and only those pay for the clamp
 __device__ __forceinline__ int vrow(int ly0, int k) {
@@ -79,7 +96,7 @@ __device__ __forceinline__ int vrow(int ly0, int k) {
 // out[q] = sum_k W[k] * v[q + k], k ascending (the order of a direct 11-tap sum)
 // The window's six distinct weights (it is symmetric) in VECTOR registers: v_fmac_f32 with a scalar-register
 // weight measures 9-15 % slower over the whole forward kernel than with a vector-register one
-// (profiles/r5_ssim_ab.txt), and the compiler keeps a __constant__ table in scalar registers unless told otherwise.
+// (profiles/r5_ssim_steps.txt), and the compiler keeps a __constant__ table in scalar registers unless told otherwise.
 struct WindowWeights { float w[6]; };
 __device__ __forceinline__ WindowWeights window_weights() {
   WindowWeights r;
@@ -99,16 +116,16 @@ __device__ __forceinline__ void window(const WindowWeights& ww, const float (&v)
 }
 
 __global__ void __launch_bounds__(256)
-ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
+ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, int tiles_x, int tiles_y,
                 float* __restrict__ ssim_map, float* __restrict__ block_partials, float* __restrict__ dm_dmu1,
                 float* __restrict__ dm_dsig1, float* __restrict__ dm_dsig12) {
   __shared__ float s1[SINY][SPITCH], s2[SINY][SPITCH];   // 11.3 KB of staged inputs
   __shared__ float hz[5][SINY][ST];                       // 20.5 KB of horizontal-pass results
   __shared__ float red[4];
-  const int plane = blockIdx.z;
-  const size_t poff = (size_t)plane * H * W;
+  const SsimTile T = ssim_tile(tiles_x, tiles_y);
+  const size_t poff = (size_t)T.plane * H * W;
   const uint32_t pbytes = (uint32_t)H * (uint32_t)W * 4u;
-  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * STY;
+  const int x0 = T.x0, y0 = T.y0;
   const int tid = threadIdx.x;
   const WindowWeights ww = window_weights();
   // staging: every load is issued before the first LDS write, from an address that is always valid (clamped into the
@@ -206,7 +223,7 @@ ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, 
     }
   }
   const float bs = block_sum_256(vsum, red);
-  if (tid == 0) block_partials[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = bs;
+  if (tid == 0) block_partials[T.index] = bs;
 }
 
 // fixed-order final reduction: mean = sum(partials) / count
@@ -227,16 +244,16 @@ __global__ void __launch_bounds__(1024) ssim_mean_kernel(const float* __restrict
 }
 
 __global__ void __launch_bounds__(256)
-ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
+ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, int tiles_x, int tiles_y,
                 const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsig1,
                 const float* __restrict__ dm_dsig12, const float* __restrict__ dL_dmean, float inv_count,
                 float* __restrict__ dL_dimg1) {
   __shared__ float s[3][SINY][SPITCH];   // 16.9 KB
   __shared__ float hz[3][SINY][ST];      // 12.3 KB
-  const int plane = blockIdx.z;
-  const size_t poff = (size_t)plane * H * W;
+  const SsimTile T = ssim_tile(tiles_x, tiles_y);
+  const size_t poff = (size_t)T.plane * H * W;
   const uint32_t pbytes = (uint32_t)H * (uint32_t)W * 4u;
-  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * STY;
+  const int x0 = T.x0, y0 = T.y0;
   const int tid = threadIdx.x;
   const WindowWeights ww = window_weights();
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -327,7 +344,7 @@ extern "C" int sfgs_ssim_forward(const float* img1, const float* img2, int32_t B
                                  int32_t with_grad, void* stream_) {
   SFGS_REQUIRE(img1 && img2 && ssim_mean && scratch, SFGS_E_ARG, "NULL argument");
   SFGS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SFGS_E_ARG, "bad image shape [%d,%d,%d,%d]", B, C, H, W);
-  SFGS_REQUIRE((int64_t)B * C <= 65535 && (H + STY - 1) / STY <= 65535, SFGS_E_UNSUPPORTED, "B*C or H/22 > 65535");
+  SFGS_REQUIRE(ssim_nblocks(B, C, H, W) <= (size_t)INT32_MAX, SFGS_E_UNSUPPORTED, "more than 2^31 - 1 tiles of 32 x 22");
   SFGS_REQUIRE((int64_t)H * W < ((int64_t)1 << 30), SFGS_E_UNSUPPORTED, "an image plane of 2^30 pixels or more");
   SFGS_REQUIRE(scratch_sz >= sfgs_ssim_scratch_bytes(B, C, H, W, with_grad), SFGS_E_CAPACITY, "ssim scratch too small");
   hipStream_t stream = (hipStream_t)stream_;
@@ -337,9 +354,10 @@ extern "C" int sfgs_ssim_forward(const float* img1, const float* img2, int32_t B
   float* m0 = with_grad ? (float*)maps : nullptr;
   float* m1 = with_grad ? (float*)(maps + plane) : nullptr;
   float* m2 = with_grad ? (float*)(maps + 2 * plane) : nullptr;
-  const dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, B * C), block(256);
+  const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + STY - 1) / STY;
   { ProfScope ps_(KID_SSIM_FWD, stream);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, block, 0, stream, img1, img2, H, W, ssim_map_or_null, partials, m0, m1, m2); }
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, img1, img2, H, W, tiles_x, tiles_y,
+                       ssim_map_or_null, partials, m0, m1, m2); }
   SFGS_POST_LAUNCH("ssim_fwd", stream, 0);
   { ProfScope ps_(KID_SSIM_MEAN, stream);
     hipLaunchKernelGGL(ssim_mean_kernel, dim3(1), dim3(1024), 0, stream, partials, (int)nblk,
@@ -352,14 +370,15 @@ extern "C" int sfgs_ssim_backward(const float* img1, const float* img2, int32_t 
                                   const void* scratch, const float* dL_dmean, float* dL_dimg1, void* stream_) {
   SFGS_REQUIRE(img1 && img2 && scratch && dL_dmean && dL_dimg1, SFGS_E_ARG, "NULL argument");
   SFGS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SFGS_E_ARG, "bad image shape");
-  SFGS_REQUIRE((int64_t)B * C <= 65535 && (H + STY - 1) / STY <= 65535 && (int64_t)H * W < ((int64_t)1 << 30),
+  SFGS_REQUIRE(ssim_nblocks(B, C, H, W) <= (size_t)INT32_MAX && (int64_t)H * W < ((int64_t)1 << 30),
                SFGS_E_UNSUPPORTED, "image too large");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t nblk = ssim_nblocks(B, C, H, W), plane = align_up((size_t)B * C * H * W * 4, 256);
   const char* maps = (const char*)scratch + align_up(nblk * 4, 256);
-  const dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, B * C), block(256);
+  const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + STY - 1) / STY;
   { ProfScope ps_(KID_SSIM_BWD, stream);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, block, 0, stream, img1, img2, H, W, (const float*)maps,
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, img1, img2, H, W, tiles_x, tiles_y,
+                       (const float*)maps,
                        (const float*)(maps + plane), (const float*)(maps + 2 * plane), dL_dmean,
                        1.0f / (float)((double)B * C * H * W), dL_dimg1); }
   SFGS_POST_LAUNCH("ssim_bwd", stream, 0);
