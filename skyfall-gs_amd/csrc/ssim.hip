@@ -78,9 +78,7 @@ __device__ __forceinline__ uint32_t halo_row(int row, int y0, int H, int W, bool
 // Returns the tile's index in plane-major, row-major order (also the index of its partial sum).
 struct SsimTile { int index, plane, x0, y0; };
 __device__ __forceinline__ SsimTile ssim_tile(int tiles_x, int tiles_y) {
-  const int n = gridDim.x, id = blockIdx.x;
-  const int xcd = id & 7, slot = id >> 3;
-  const int L = xcd * (n >> 3) + min(xcd, n & 7) + slot;   // XCD k owns ceil((n - k) / 8) tiles, starting here
+  const int L = (int)xcd_remap(blockIdx.x, gridDim.x);
   const int per_plane = tiles_x * tiles_y;
   const int plane = L / per_plane, rem = L - plane * per_plane;
   const int by = rem / tiles_x, bx = rem - by * tiles_x;
