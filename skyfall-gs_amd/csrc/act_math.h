@@ -104,4 +104,15 @@ __device__ __forceinline__ float4 act_rotation_backward(float4 q, float4 gr) {
     }                                                                            \
   } while (0)
 
+// element g of a float or double array as raw bits / back: lets a kernel issue the load where its other loads are and
+// interpret the word inside the dtype switch later
+template <typename T> __device__ __forceinline__ unsigned long long raw_bits(const void* p, size_t g) {
+  if constexpr (sizeof(T) == 4) return static_cast<const unsigned*>(p)[g];
+  else return static_cast<const unsigned long long*>(p)[g];
+}
+template <typename T> __device__ __forceinline__ T from_bits(unsigned long long b) {
+  if constexpr (sizeof(T) == 4) return __uint_as_float((unsigned)b);
+  else return __longlong_as_double((long long)b);
+}
+
 }  // namespace sfgs

@@ -736,11 +736,14 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     float4 qv = qraw;
     float opacity;
     const float sraw[3] = {s[0], s[1], s[2]};
-    if constexpr (!RAW) {
+    unsigned long long o_bits = 0ull, f_bits = 0ull;   // RAW: the raw opacity / filter_3D words, loaded ONCE (as bits:
+    if constexpr (!RAW) {                               // their types are a launch-uniform switch), used twice below
       opacity = static_cast<const float*>(opac_)[g];
     } else {
-#define SFGS_ACT_FWD(FT, OT) \
-  act_outputs(act_terms<FT, OT>(sraw, static_cast<const OT*>(opac_)[g], static_cast<const FT*>(filt)[g]), s, &opacity)
+#define SFGS_ACT_LOAD(FT, OT) do { o_bits = raw_bits<OT>(opac_, g); f_bits = raw_bits<FT>(filt, g); } while (0)
+      SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_LOAD);
+#undef SFGS_ACT_LOAD
+#define SFGS_ACT_FWD(FT, OT) act_outputs(act_terms<FT, OT>(sraw, from_bits<OT>(o_bits), from_bits<FT>(f_bits)), s, &opacity)
       SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_FWD);
 #undef SFGS_ACT_FWD
       qv = act_rotation(qraw);
@@ -768,8 +771,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
 #define SFGS_ACT_BWD(FT, OT)                                                                                         \
   do {                                                                                                              \
     OT gro;                                                                                                         \
-    act_backward(act_terms<FT, OT>(sraw, static_cast<const OT*>(opac_)[g], static_cast<const FT*>(filt)[g]), gs,    \
-                 out.opacity, out.scales, &gro);                                                                    \
+    act_backward(act_terms<FT, OT>(sraw, from_bits<OT>(o_bits), from_bits<FT>(f_bits)), gs, out.opacity, out.scales, \
+                 &gro);                                                                                             \
     static_cast<OT*>(g_opac_)[g] = gro;                                                                             \
   } while (0)
       SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_BWD);

@@ -172,14 +172,18 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
     if constexpr (!RAW) opacity_in = static_cast<const float*>(opac_)[g];
     float rgb_in[3] = {0.f, 0.f, 0.f};
     if constexpr (K == 0) load3(colors + 3 * (size_t)g, rgb_in);
-    asm volatile("" :: "v"(p[2]), "v"(s[0]), "v"(qv.x), "v"(opacity_in), "v"(rgb_in[0]));   // all five in registers here
+    // RAW: the raw opacity and filter_3D words belong to the same round trip (as bits: their types are a launch-uniform
+    // switch, and a load inside the switch BELOW the asm would be a second, dependent trip to memory)
+    unsigned long long o_bits = 0ull, f_bits = 0ull;
+    if constexpr (RAW) {
+#define SFGS_ACT_LOAD(FT, OT) do { o_bits = raw_bits<OT>(opac_, g); f_bits = raw_bits<FT>(filt, g); } while (0)
+      SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_LOAD);
+#undef SFGS_ACT_LOAD
+    }
+    asm volatile("" :: "v"(p[2]), "v"(s[0]), "v"(qv.x), "v"(opacity_in), "v"(rgb_in[0]), "v"((unsigned)o_bits),
+                 "v"((unsigned)f_bits));   // all of them in registers here
     if constexpr (RAW) {   // raw parameters -> what render() would have passed (the mask is uniform over the launch)
-#define SFGS_ACT_FWD(FT, OT)                                                                                        \
-  do {                                                                                                              \
-    const OT o_raw = static_cast<const OT*>(opac_)[g];                                                              \
-    const FT f_raw = static_cast<const FT*>(filt)[g];                                                               \
-    act_outputs(act_terms<FT, OT>(s, o_raw, f_raw), s, &opacity_in);                                                \
-  } while (0)
+#define SFGS_ACT_FWD(FT, OT) act_outputs(act_terms<FT, OT>(s, from_bits<OT>(o_bits), from_bits<FT>(f_bits)), s, &opacity_in)
       SFGS_ACT_DISPATCH(raw_mask, SFGS_ACT_FWD);
 #undef SFGS_ACT_FWD
       qv = act_rotation(qv);
