@@ -18,7 +18,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 SRCS="api.cpp raster_fwd.hip raster_bwd.hip ssim.hip knn.hip prepass.hip filter3d.hip densify_stats.hip adam.hip sh_eval.hip compact.hip densify.hip"
 mkdir -p o
 for f in $SRCS; do
-  extra=""; [ $f = raster_bwd.hip -o $f = ssim.hip ] && extra="-fno-slp-vectorize"
+  extra=""; [ $f = raster_bwd.hip -o $f = raster_fwd.hip -o $f = ssim.hip ] && extra="-fno-slp-vectorize"
   # only what the patches / flags can touch is recompiled; the other objects come from the main build (make first)
   if cmp -s $f "$SRC/$f" && [ -z "$defs" -o \( $f != raster_fwd.hip -a $f != raster_bwd.hip -a $f != api.cpp \) ] && \
      cmp -s raster_math.h "$SRC/raster_math.h" && cmp -s sfgs_internal.h "$SRC/sfgs_internal.h" && [ -f "$SRC/_obj/$f.o" ]; then
