@@ -472,7 +472,8 @@ def load_traffic(N, W, H, forward_only):
         try:
             if meta.get("commit"):
                 r = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", meta["commit"], "--",
-                                    "skyfall-gs_amd/csrc/raster_fwd.hip", "skyfall-gs_amd/csrc/raster_bwd.hip"],
+                                    "skyfall-gs_amd/csrc/raster_fwd.hip", "skyfall-gs_amd/csrc/raster_bwd.hip",
+                                    "skyfall-gs_amd/csrc/composite_bwd.hip"],
                                    capture_output=True, timeout=10)
                 src["kernels_changed_since"] = {0: False, 1: True}.get(r.returncode)   # None: no git here (GPU box)
         except Exception:

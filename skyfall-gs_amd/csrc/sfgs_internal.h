@@ -519,4 +519,11 @@ __device__ __forceinline__ unsigned block_excl_scan_u32(unsigned v, unsigned* to
   return res;
 }
 
+// composite_bwd.hip (a translation unit of its own: compiled with another scheduling strategy, see the Makefile)
+void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8, int TY8, int SX, int nblk,
+                          const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
+                          const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
+                          const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,
+                          float4* dupgrad, const unsigned long long* hdr, int not_prefilled);
+
 }  // namespace sfgs

@@ -210,5 +210,5 @@ def test_route_options_are_set_through_the_abi_not_the_environment():
         assert r.stdout.split() == ["split", "never"], r.stdout + r.stderr
     finally:
         del os.environ["SFGS_SORT"]
-    src = "".join(open(os.path.join(ROOT, "skyfall-gs_amd", "csrc", f)).read() for f in ("raster_fwd.hip", "raster_bwd.hip", "knn.hip"))
+    src = "".join(open(os.path.join(ROOT, "skyfall-gs_amd", "csrc", f)).read() for f in ("raster_fwd.hip", "raster_bwd.hip", "composite_bwd.hip", "knn.hip"))
     assert "getenv" not in src

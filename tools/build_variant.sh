@@ -15,12 +15,13 @@ cp "$SRC"/*.hip "$SRC"/*.cpp "$SRC"/*.h "$W/skyfall-gs_amd/csrc/"; cp "$ROOT"/in
 for p in "$@"; do ( cd "$W" && patch -s -p1 < "$ROOT/$p" ); done
 cd "$W/skyfall-gs_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
-SRCS="api.cpp raster_fwd.hip raster_bwd.hip ssim.hip knn.hip prepass.hip filter3d.hip densify_stats.hip adam.hip sh_eval.hip compact.hip densify.hip"
+SRCS="api.cpp raster_fwd.hip raster_bwd.hip composite_bwd.hip ssim.hip knn.hip prepass.hip filter3d.hip densify_stats.hip adam.hip sh_eval.hip compact.hip densify.hip"
 mkdir -p o
 for f in $SRCS; do
   extra=""; [ $f = raster_bwd.hip -o $f = raster_fwd.hip -o $f = ssim.hip ] && extra="-fno-slp-vectorize"
+  [ $f = composite_bwd.hip ] && extra="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp"
   # only what the patches / flags can touch is recompiled; the other objects come from the main build (make first)
-  if cmp -s $f "$SRC/$f" && [ -z "$defs" -o \( $f != raster_fwd.hip -a $f != raster_bwd.hip -a $f != api.cpp \) ] && \
+  if cmp -s $f "$SRC/$f" && [ -z "$defs" -o \( $f != raster_fwd.hip -a $f != raster_bwd.hip -a $f != composite_bwd.hip -a $f != api.cpp \) ] && \
      cmp -s raster_math.h "$SRC/raster_math.h" && cmp -s sfgs_internal.h "$SRC/sfgs_internal.h" && [ -f "$SRC/_obj/$f.o" ]; then
     cp "$SRC/_obj/$f.o" o/$f.o
   else
