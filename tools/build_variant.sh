@@ -5,6 +5,8 @@
 # usage: tools/build_variant.sh <name> "<-D flags>" [patch ...]        (patches: tools/variants/*.patch, applied with -p1
 #        from the repo root, in order; "" for no flags)
 #   tools/build_variant.sh nop1 "-DSFGS_BWD_ABLATE=2" tools/variants/bwd_lab_r5.patch
+#   FLAG_FILES=ssim.hip tools/build_variant.sh ssim_ilp "-mllvm -amdgpu-sched-strategy=max-ilp"
+# The objects of files that are not recompiled are COPIED from the main build: run make on the same sources first.
 set -e
 name=$1; defs=${2:-}; shift; [ $# -gt 0 ] && shift
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -21,11 +23,14 @@ for f in $SRCS; do
   extra=""; [ $f = raster_bwd.hip -o $f = raster_fwd.hip -o $f = ssim.hip ] && extra="-fno-slp-vectorize"
   [ $f = composite_bwd.hip ] && extra="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp"
   # only what the patches / flags can touch is recompiled; the other objects come from the main build (make first)
-  if cmp -s $f "$SRC/$f" && [ -z "$defs" -o \( $f != raster_fwd.hip -a $f != raster_bwd.hip -a $f != composite_bwd.hip -a $f != api.cpp \) ] && \
+  # FLAG_FILES="a.hip b.hip" (environment): the -D / -mllvm flags go to these files only (default: the rasterizer's three + api.cpp)
+  flagged=0; for ff in ${FLAG_FILES:-raster_fwd.hip raster_bwd.hip composite_bwd.hip api.cpp}; do [ $f = $ff ] && flagged=1; done
+  fdefs=""; [ $flagged = 1 ] && fdefs="$defs"
+  if cmp -s $f "$SRC/$f" && [ -z "$fdefs" ] && \
      cmp -s raster_math.h "$SRC/raster_math.h" && cmp -s sfgs_internal.h "$SRC/sfgs_internal.h" && [ -f "$SRC/_obj/$f.o" ]; then
     cp "$SRC/_obj/$f.o" o/$f.o
   else
-    ( /opt/rocm/bin/hipcc $FLAGS $extra $defs -x hip -c $f -o o/$f.o 2>&1 | grep -v "hip-link" || true ) &
+    ( /opt/rocm/bin/hipcc $FLAGS $extra $fdefs -x hip -c $f -o o/$f.o 2>&1 | grep -v "hip-link" || true ) &
   fi
 done
 wait
