@@ -355,7 +355,8 @@ int sfgs_raster_backward_scratch(const SfgsFrame* frame, const SfgsGaussians* g,
  * non-NULL and, when with_grad != 0, the three partial-derivative maps the backward consumes into
  * `scratch` (sfgs_ssim_scratch_bytes). The mean is reduced in a fixed order (bit-reproducible).
  * backward: dL_dimg1 = *dL_dmean (device float) * d(mean ssim)/d(img1); img2 gets no gradient
- * (it is the ground truth, train.py:222). */
+ * (it is the ground truth, train.py:222).
+ * Limits (SFGS_E_UNSUPPORTED): H * W < 2^30 pixels per plane, at most 2^31 - 1 tiles of 32 x 22 pixels in all. */
 size_t sfgs_ssim_scratch_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t with_grad);
 int sfgs_ssim_forward(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H,
                       int32_t W, float* ssim_map_or_null, float* ssim_mean, void* scratch,

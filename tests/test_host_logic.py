@@ -111,6 +111,15 @@ def test_gpu_free_entry_points_and_error_convention():
     # a NULL frame is rejected before any HIP call
     assert lib.sfgs_raster_forward_plan(None, None, None, None, 0, None, 0, None, 0, 0, 0, None, None) == -1
     assert lib.sfgs_ssim_scratch_bytes(1, 3, 1080, 1920, 1) > 3 * 3 * 1080 * 1920 * 4
+    # one partial sum per 32 x 22 output tile (60 x 50 x 3 at 1080p) in front of the three derivative maps
+    assert lib.sfgs_ssim_scratch_bytes(1, 3, 1080, 1920, 0) == 60 * 50 * 3 * 4 + (-(60 * 50 * 3 * 4)) % 256
+    # a plane of 2^30 pixels or more is refused before any HIP call (the kernels address a plane through a 32-bit buffer
+    # descriptor); the pointers are never dereferenced
+    dummy = C.c_float(0.0)
+    fp = C.cast(C.byref(dummy), C.c_void_p)
+    assert lib.sfgs_ssim_forward(fp, fp, 1, 1, 32768, 32768, None, fp, fp, C.c_size_t(1 << 62), 0, None) == -4
+    assert b"2^30" in lib.sfgs_last_error()
+    assert lib.sfgs_ssim_backward(fp, fp, 1, 1, 32768, 32768, fp, fp, fp, None) == -4
     assert lib.sfgs_knn_scratch_bytes(1000) == 0
     assert lib.sfgs_profile_kernel_count() >= 10 and lib.sfgs_profile_kernel_name(1) == b"preprocess"
 
