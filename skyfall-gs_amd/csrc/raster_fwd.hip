@@ -235,16 +235,23 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
           // ONE flat loop over the tiles of the walk range (a 4-deep coarse-bin x tile loop nest with per-lane
           // bounds costs as much in divergent loop control as the tile tests themselves); hits are ORed into the
           // 16-bit mask of their coarse bin, BIG_WALK (= 6) masks = 96 bits in two registers
-          const int w_t = br.x1 - br.x0, ncx = cx1 - cx0;
-          int tx = br.x0, ty = br.y0;
-          for (int q = (br.y1 - br.y0) * w_t; q > 0; --q) {
-            if (bin_test(r, thr, tx, ty, f.W, f.H, bound)) {
-              const int slot = (ty / COARSE - cy0) * ncx + (tx / COARSE - cx0);
-              const int pos = slot * 16 + (ty % COARSE) * COARSE + (tx % COARSE);
-              if (pos < 64) mask_lo |= 1ull << pos; else mask_hi |= 1ull << (pos - 64);
+          // The kernel is bound by VALU issue and this loop is half of its instructions: the tile's pixel origin is
+          // carried as two floats stepped by 8 (bin_test_at: the bounds bin_test derives from the tile indices, bit for
+          // bit) and the mask position is shifts and ands of unsigned indices (the tile range is never negative).
+          static_assert(COARSE == 4, "mask position: 2-bit tile coordinates inside a coarse bin");
+          const unsigned w_t = (unsigned)(br.x1 - br.x0), ncx = (unsigned)(cx1 - cx0);
+          const float fx_first = (float)(br.x0 * TILE_BIN), wm1 = (float)(f.W - 1), hm1 = (float)(f.H - 1);
+          unsigned tx = (unsigned)br.x0, ty = (unsigned)br.y0;
+          float fx = fx_first, fy = (float)(br.y0 * TILE_BIN);
+          for (unsigned q = (unsigned)(br.y1 - br.y0) * w_t; q > 0; --q) {
+            if (bin_test_at(r, thr, fx, fy, wm1, hm1, bound)) {
+              const unsigned slot = ((ty >> 2) - (unsigned)cy0) * ncx + ((tx >> 2) - (unsigned)cx0);
+              const unsigned pos = slot * 16u + (ty & 3u) * 4u + (tx & 3u);
+              if (pos < 64u) mask_lo |= 1ull << pos; else mask_hi |= 1ull << (pos - 64u);
               ++n_dup;
             }
-            if (++tx == br.x1) { tx = br.x0; ++ty; }
+            fx += (float)TILE_BIN;
+            if (++tx == (unsigned)br.x1) { tx = (unsigned)br.x0; fx = fx_first; ++ty; fy += (float)TILE_BIN; }
           }
         }
       }

@@ -404,6 +404,17 @@ SFGS_HD BinRange bin_range(const SplatRec& r, int W, int H, int rminx, int rminy
   return br;
 }
 
+// the tile whose first pixel is (fx, fy) -- tile index x 8 as a float, exact below 2^24 -- on an image whose last pixel is
+// (wm1, hm1): the same four bounds as bin_test below, bit for bit (integer-valued floats: the float min and the float
+// + 7 are the integer ones), for a walk that steps fx / fy by 8.0f instead of converting tile indices in every iteration
+SFGS_HD bool bin_test_at(const SplatRec& r, float thr, float fx, float fy, float wm1, float hm1, float bound) {
+  const float x0 = fx - bound;
+  const float x1 = fminf(fx + (float)(TILE_BIN - 1), wm1) + bound;
+  const float y0 = fy - bound;
+  const float y1 = fminf(fy + (float)(TILE_BIN - 1), hm1) + bound;
+  return tile_can_contribute(r, thr, x0, x1, y0, y1);
+}
+
 SFGS_HD bool bin_test(const SplatRec& r, float thr, int tx, int ty, int W, int H, float bound) {
   const float x0 = (float)(tx * TILE_BIN) - bound;
   const float x1 = (float)imin(tx * TILE_BIN + TILE_BIN - 1, W - 1) + bound;
