@@ -46,6 +46,10 @@ def main():
     res["top_kernels_of_torch_group"] = [
         {"ms_per_iteration": round(a, 4), "launches_per_iteration": round(b, 2), "kernel": n}
         for a, b, n in sorted(detail.get(GROUPS[-1][0], []), reverse=True)[:8]]
+    res["library_kernels"] = [
+        {"ms_per_iteration": round(a, 4), "launches_per_iteration": round(b, 2), "kernel": re.sub(r"^void ", "", n)[:70]}
+        for g in out if g != GROUPS[-1][0] for a, b, n in sorted(detail.get(g, []), reverse=True)]
+    res["library_kernels"].sort(key=lambda r: -r["ms_per_iteration"])
     print(json.dumps(res, indent=1))
 
 
