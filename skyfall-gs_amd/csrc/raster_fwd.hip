@@ -72,6 +72,14 @@ __device__ __forceinline__ unsigned coarse_hits(const SplatRec& r, float thr, co
   return m;
 }
 
+// small walks handed to the wave (preprocess_kernel): at most this many tiles per Gaussian (so a wave has at most 2 048
+// tasks), the owner's test inputs, its mask words and the task -> owner map, 7 KB of LDS per wave
+constexpr int WALK_COOP_MAX = 32;
+struct WalkLds {
+  float4 rec[64][4];
+  uint4 mask[64];
+  unsigned char owner[64 * WALK_COOP_MAX];
+};
 constexpr int BIG_WALK = 6;  // coarse bins above which a splat's walk is done by a whole wave (big_walk_kernel)
 constexpr int BIG_WALK_BLOCKS = 1024;   // persistent grid of big_walk_kernel: 4 096 waves = 4 per SIMD, what its 120 VGPRs allow (round 4:
                                         // with 1 per SIMD nothing hid the tile tests' dependent chains -- near-camera regime); the
@@ -152,6 +160,7 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   const int CX = (((f.W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
   unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
   unsigned long long mask_lo = 0ull, mask_hi = 0ull;  // 16-bit tile masks of the (<= BIG_WALK) coarse bins of the walk
+  unsigned walk_tiles = 0;           // tiles of a walk of at most BIG_WALK coarse bins (<= 96): walked after the per-thread part
   bool big = false;                  // walk handled cooperatively by the wave (BIG_WALK < coarse bins < 64)
   bool huge = false;                 // >= 64 coarse bins: walked by big_walk_kernel
   const int lane = threadIdx.x & 63;
@@ -232,29 +241,97 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
         huge = ncb_ >= 64;
         big = ncb_ > BIG_WALK && !huge;
         if (ncb_ <= BIG_WALK) {
-          // ONE flat loop over the tiles of the walk range (a 4-deep coarse-bin x tile loop nest with per-lane
-          // bounds costs as much in divergent loop control as the tile tests themselves); hits are ORed into the
-          // 16-bit mask of their coarse bin, BIG_WALK (= 6) masks = 96 bits in two registers
-          // The kernel is bound by VALU issue and this loop is half of its instructions: the tile's pixel origin is
-          // carried as two floats stepped by 8 (bin_test_at: the bounds bin_test derives from the tile indices, bit for
-          // bit) and the mask position is shifts and ands of unsigned indices (the tile range is never negative).
-          static_assert(COARSE == 4, "mask position: 2-bit tile coordinates inside a coarse bin");
-          const unsigned w_t = (unsigned)(br.x1 - br.x0), ncx = (unsigned)(cx1 - cx0);
-          const float fx_first = (float)(br.x0 * TILE_BIN), wm1 = (float)(f.W - 1), hm1 = (float)(f.H - 1);
-          unsigned tx = (unsigned)br.x0, ty = (unsigned)br.y0;
-          float fx = fx_first, fy = (float)(br.y0 * TILE_BIN);
-          for (unsigned q = (unsigned)(br.y1 - br.y0) * w_t; q > 0; --q) {
-            if (bin_test_at(r, thr, fx, fy, wm1, hm1, bound)) {
-              const unsigned slot = ((ty >> 2) - (unsigned)cy0) * ncx + ((tx >> 2) - (unsigned)cx0);
-              const unsigned pos = slot * 16u + (ty & 3u) * 4u + (tx & 3u);
-              if (pos < 64u) mask_lo |= 1ull << pos; else mask_hi |= 1ull << (pos - 64u);
-              ++n_dup;
-            }
-            fx += (float)TILE_BIN;
-            if (++tx == (unsigned)br.x1) { tx = (unsigned)br.x0; fx = fx_first; ++ty; fy += (float)TILE_BIN; }
+          walk_tiles = (unsigned)(br.y1 - br.y0) * (unsigned)(br.x1 - br.x0);   // walked below, by the wave or by this thread
+        }
+      }
+    }
+  }
+  // Small walks, balanced over the wave. One thread walking ITS Gaussian's tiles makes the wave run max over its 64
+  // lanes of the tile counts -- 11.4 steps on the headline scene for 4.4 tiles per Gaussian (tools/workmodel) -- in a kernel
+  // that is bound by VALU issue with this loop as half of its instructions. Here lane = one (Gaussian, tile) task: the
+  // owners publish what the test needs (48 bytes) and their lane number in the task slots they own, every lane takes task
+  // 64 p + lane in pass p (4.9 passes), hits are ORed into the owner's mask words with LDS atomics. Same tests on the
+  // same tiles: masks and duplicate counts are bit-identical.
+  // A wave that holds a walk of more than WALK_COOP_MAX tiles (its task map would not fit the LDS block) keeps the
+  // thread-per-Gaussian loop for all its lanes: UHD frames and low elevations, where most waves hold one, would
+  // otherwise pay for that lane's long loop AND for the passes (measured: +12 ... +17 %).
+  const bool coop_walk = __ballot(walk_tiles > (unsigned)WALK_COOP_MAX) == 0ull;
+  if (!coop_walk && walk_tiles) {
+    // ONE flat loop over the tiles of the walk range (a 4-deep coarse-bin x tile loop nest with per-lane bounds costs as
+    // much in divergent loop control as the tile tests themselves); hits are ORed into the 16-bit mask of their coarse
+    // bin, BIG_WALK (= 6) masks = 96 bits in two registers. The tile's pixel origin is carried as two floats stepped by
+    // 8 (bin_test_at: the bounds bin_test derives from the tile indices, bit for bit) and the mask position is shifts
+    // and ands of unsigned indices (the tile range is never negative).
+    static_assert(COARSE == 4, "mask position: 2-bit tile coordinates inside a coarse bin");
+    const unsigned ncx = (unsigned)(cx1 - cx0);
+    const float fx_first = (float)(br.x0 * TILE_BIN), wm1 = (float)(f.W - 1), hm1 = (float)(f.H - 1);
+    unsigned tx = (unsigned)br.x0, ty = (unsigned)br.y0;
+    float fx = fx_first, fy = (float)(br.y0 * TILE_BIN);
+    for (unsigned q = walk_tiles; q > 0; --q) {
+      if (bin_test_at(r, thr, fx, fy, wm1, hm1, bound)) {
+        const unsigned slot = ((ty >> 2) - (unsigned)cy0) * ncx + ((tx >> 2) - (unsigned)cx0);
+        const unsigned pos = slot * 16u + (ty & 3u) * 4u + (tx & 3u);
+        if (pos < 64u) mask_lo |= 1ull << pos; else mask_hi |= 1ull << (pos - 64u);
+        ++n_dup;
+      }
+      fx += (float)TILE_BIN;
+      if (++tx == (unsigned)br.x1) { tx = (unsigned)br.x0; fx = fx_first; ++ty; fy += (float)TILE_BIN; }
+    }
+  }
+  if (coop_walk) {
+    __shared__ WalkLds s_walk[PRE_BLOCK / 64];
+    const unsigned incl = wave_incl_scan_u32(walk_tiles);
+    const unsigned total_t = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total_t) {   // wave-uniform
+      WalkLds& wl = s_walk[threadIdx.x >> 6];
+      const unsigned excl = incl - walk_tiles;
+      wl.mask[lane] = make_uint4(0u, 0u, 0u, 0u);
+      if (walk_tiles) {
+        const unsigned w_t = (unsigned)(br.x1 - br.x0);
+        wl.rec[lane][0] = make_float4(r.mx, r.my, r.qa, r.qb);
+        wl.rec[lane][1] = make_float4(r.qc, thr, (float)(br.x0 * TILE_BIN), (float)(br.y0 * TILE_BIN));
+        // k / w_t for k < 32 as (k * M) >> 16 with M = ceil(2^16 / w_t): exact while k (M - 2^16 / w_t) < 2^16 / w_t
+        const unsigned M = (65536u + w_t - 1u) / w_t;
+        wl.rec[lane][2] = make_float4(__uint_as_float(w_t | (M << 8)), __uint_as_float((unsigned)br.x0 | ((unsigned)br.y0 << 16)),
+                                      __uint_as_float((unsigned)cx0 | ((unsigned)cy0 << 16)),
+                                      __uint_as_float((unsigned)(cx1 - cx0) | (excl << 8)));
+        wl.rec[lane][3] = make_float4(-0.5f / r.qc, -0.5f / r.qa, 0.f, 0.f);   // the test's two divisions, once per Gaussian
+        for (unsigned k = 0; k < walk_tiles; ++k) wl.owner[excl + k] = (unsigned char)lane;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float wm1 = (float)(f.W - 1), hm1 = (float)(f.H - 1);
+      for (unsigned t0 = 0; t0 < total_t; t0 += 64) {
+        const unsigned t = t0 + (unsigned)lane;
+        if (t < total_t) {
+          const unsigned o = wl.owner[t];
+          const float4 a0 = wl.rec[o][0], a1 = wl.rec[o][1], a2 = wl.rec[o][2];
+          const float2 a3 = *reinterpret_cast<const float2*>(&wl.rec[o][3]);
+          const unsigned wM = __float_as_uint(a2.x), xy = __float_as_uint(a2.y), cxy = __float_as_uint(a2.z),
+                         ne = __float_as_uint(a2.w);
+          const unsigned w_t = wM & 0xffu, k = t - (ne >> 8);
+          const unsigned row = __umul24(k, wM >> 8) >> 16, col = k - __umul24(row, w_t);   // k < 32, M <= 2^16
+          SplatRec q;
+          q.mx = a0.x; q.my = a0.y; q.qa = a0.z; q.qb = a0.w; q.qc = a1.x;
+          if (bin_test_at_h(q, a1.y, a1.z + (float)(col * TILE_BIN), a1.w + (float)(row * TILE_BIN), wm1, hm1, bound, a3.x, a3.y)) {
+            const unsigned tx = (xy & 0xffffu) + col, ty = (xy >> 16) + row;
+            const unsigned slot = ((ty >> 2) - (cxy >> 16)) * (ne & 0xffu) + ((tx >> 2) - (cxy & 0xffffu));
+            const unsigned pos = slot * 16u + (ty & 3u) * 4u + (tx & 3u);
+            atomicOr(&wl.mask[o].x + (pos >> 5), 1u << (pos & 31u));
           }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (walk_tiles) {
+        const uint4 m = wl.mask[lane];
+        mask_lo = (unsigned long long)m.x | ((unsigned long long)m.y << 32);
+        mask_hi = (unsigned long long)m.z;
+        n_dup = (unsigned)__popcll(mask_lo) + (unsigned)__popc(m.z);
+      }
+      __builtin_amdgcn_wave_barrier();   // the next user of this wave's LDS block is the next launch
     }
   }
   // Mid-size splats (more than BIG_WALK, fewer than 64 coarse bins) are walked by the whole wave, lane = tile, instead

@@ -349,35 +349,38 @@ SFGS_HD float p2_at(const SplatRec& r, float dx, float dy) {
 // point clamped to the edge. The nearer vertical and the nearer horizontal edge are therefore all that has to be
 // evaluated (an edge that does not face the centre only adds a smaller candidate): 2 clamped stationary points
 // instead of 4 corners + 4 edges -- the tile tests are a fifth of preprocess_kernel's instructions.
-SFGS_HD bool tile_can_contribute(const SplatRec& r, float thr, float x0, float x1, float y0, float y1) {
+// hc = -0.5f / r.qc and ha = -0.5f / r.qa are passed in, so that a caller testing many tiles of one splat divides once
+// (tile_can_contribute below computes them itself: the same two divisions, the same result bit for bit)
+SFGS_HD bool tile_can_contribute_h(const SplatRec& r, float thr, float x0, float x1, float y0, float y1, float hc, float ha) {
   const float dxl = r.mx - x1, dxh = r.mx - x0, dyl = r.my - y1, dyh = r.my - y0;
   if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;  // centre inside: p2 = 0
   float best;
   if (r.qa < 0.f && r.qc < 0.f) {
     const float dxv = fabsf(dxl) < fabsf(dxh) ? dxl : dxh;   // nearer vertical edge
     const float dyv = fabsf(dyl) < fabsf(dyh) ? dyl : dyh;   // nearer horizontal edge
-    const float dy = fminf(dyh, fmaxf(dyl, r.qb * dxv * (-0.5f / r.qc)));
-    const float dx = fminf(dxh, fmaxf(dxl, r.qb * dyv * (-0.5f / r.qa)));
+    const float dy = fminf(dyh, fmaxf(dyl, r.qb * dxv * hc));
+    const float dx = fminf(dxh, fmaxf(dxl, r.qb * dyv * ha));
     best = fmaxf(p2_at(r, dxv, dy), p2_at(r, dx, dyv));
   } else {
     // degenerate or NaN conic: all four corners and whatever edge maxima exist (NaN keeps the pair below)
     best = fmaxf(fmaxf(p2_at(r, dxl, dyl), p2_at(r, dxl, dyh)), fmaxf(p2_at(r, dxh, dyl), p2_at(r, dxh, dyh)));
     if (r.qc < 0.f) {
-      const float inv = -0.5f / r.qc;
-      float dy = fminf(dyh, fmaxf(dyl, r.qb * dxl * inv));
+      float dy = fminf(dyh, fmaxf(dyl, r.qb * dxl * hc));
       best = fmaxf(best, p2_at(r, dxl, dy));
-      dy = fminf(dyh, fmaxf(dyl, r.qb * dxh * inv));
+      dy = fminf(dyh, fmaxf(dyl, r.qb * dxh * hc));
       best = fmaxf(best, p2_at(r, dxh, dy));
     }
     if (r.qa < 0.f) {
-      const float inv = -0.5f / r.qa;
-      float dx = fminf(dxh, fmaxf(dxl, r.qb * dyl * inv));
+      float dx = fminf(dxh, fmaxf(dxl, r.qb * dyl * ha));
       best = fmaxf(best, p2_at(r, dx, dyl));
-      dx = fminf(dxh, fmaxf(dxl, r.qb * dyh * inv));
+      dx = fminf(dxh, fmaxf(dxl, r.qb * dyh * ha));
       best = fmaxf(best, p2_at(r, dx, dyh));
     }
   }
   return !(best < thr);  // NaN keeps the pair
+}
+SFGS_HD bool tile_can_contribute(const SplatRec& r, float thr, float x0, float x1, float y0, float y1) {
+  return tile_can_contribute_h(r, thr, x0, x1, y0, y1, -0.5f / r.qc, -0.5f / r.qa);
 }
 
 struct BinRange { int x0, x1, y0, y1; };  // 8x8-tile index ranges [x0,x1) x [y0,y1)
@@ -407,12 +410,16 @@ SFGS_HD BinRange bin_range(const SplatRec& r, int W, int H, int rminx, int rminy
 // the tile whose first pixel is (fx, fy) -- tile index x 8 as a float, exact below 2^24 -- on an image whose last pixel is
 // (wm1, hm1): the same four bounds as bin_test below, bit for bit (integer-valued floats: the float min and the float
 // + 7 are the integer ones), for a walk that steps fx / fy by 8.0f instead of converting tile indices in every iteration
-SFGS_HD bool bin_test_at(const SplatRec& r, float thr, float fx, float fy, float wm1, float hm1, float bound) {
+SFGS_HD bool bin_test_at_h(const SplatRec& r, float thr, float fx, float fy, float wm1, float hm1, float bound, float hc,
+                           float ha) {
   const float x0 = fx - bound;
   const float x1 = fminf(fx + (float)(TILE_BIN - 1), wm1) + bound;
   const float y0 = fy - bound;
   const float y1 = fminf(fy + (float)(TILE_BIN - 1), hm1) + bound;
-  return tile_can_contribute(r, thr, x0, x1, y0, y1);
+  return tile_can_contribute_h(r, thr, x0, x1, y0, y1, hc, ha);
+}
+SFGS_HD bool bin_test_at(const SplatRec& r, float thr, float fx, float fy, float wm1, float hm1, float bound) {
+  return bin_test_at_h(r, thr, fx, fy, wm1, hm1, bound, -0.5f / r.qc, -0.5f / r.qa);
 }
 
 SFGS_HD bool bin_test(const SplatRec& r, float thr, int tx, int ty, int W, int H, float bound) {

@@ -34,13 +34,29 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
   std::vector<SplatRec> recs;
   std::vector<int> dup_per_gauss;
   long long D_all = 0;
+  // preprocess's inline tile walk (one thread per Gaussian, the wave runs max over its 64 lanes of the walked tiles):
+  // wave steps now, and what a walk balanced over the wave (lane = one (Gaussian, tile) task) would take
+  double walk_waves = 0, walk_steps_max = 0, walk_steps_balanced = 0, walk_tiles = 0, walk_hits = 0, walk_rows_max = 0;
+  int wave_max = 0, wave_sum = 0, wave_rows_max = 0;
   for (int g = 0; g < N; ++g) {
+    if (g % 64 == 0 && g) {
+      walk_waves += 1; walk_steps_max += wave_max; walk_steps_balanced += (wave_sum + 63) / 64; walk_rows_max += wave_rows_max;
+      wave_max = wave_sum = wave_rows_max = 0;
+    }
     const Projected pr = project_gaussian(f, means + 3 * (size_t)g, scales + 3 * (size_t)g, rots + 4 * (size_t)g);
     if (!pr.visible) continue;
     const float rgb[3] = {0.5f, 0.5f, 0.5f};
     SplatRec r = make_record(pr, opac[g], rgb);
     const BinRange br = bin_range(r, W, H, pr.rminx, pr.rminy, pr.rmaxx, pr.rmaxy, 0.f);
     const float thr = alpha_threshold_log2(r.op);
+    {
+      const int wt = (br.x1 - br.x0) * (br.y1 - br.y0);
+      const int ncb = wt > 0 ? ((br.x1 - 1) / 4 - br.x0 / 4 + 1) * ((br.y1 - 1) / 4 - br.y0 / 4 + 1) : 0;
+      if (wt > 0 && ncb <= 6) {   // BIG_WALK: larger walks are cooperative already
+        wave_max = wt > wave_max ? wt : wave_max; wave_sum += wt; walk_tiles += wt;
+        wave_rows_max = (br.y1 - br.y0) > wave_rows_max ? (br.y1 - br.y0) : wave_rows_max;
+      }
+    }
     uint32_t depth_bits; memcpy(&depth_bits, &r.depth, 4);
     int idx = -1;
     for (int ty = br.y0; ty < br.y1; ++ty)
@@ -53,7 +69,7 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
           }
         }
   }
-  (void)TX8;
+  (void)TX8; (void)walk_hits;
   // statistics
   double n_tiles = 0, sumL = 0, sumK = 0, hits = 0, dense16 = 0;
   double sp16 = 0, sp32 = 0, sp64 = 0, spInf = 0;        // per-lane sparse phase-1 steps with batch B
@@ -226,7 +242,8 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
   double vals[] = {n_tiles, sumL, sumK, hits, dense16, sp16, sp32, sp64, spInf, q16, q64, strip16, dead_entries,
                    live_entries, behind, task_nonzero, task_total, (double)D_all, all16_batches, live16_batches,
                    fstrip64[0], fstrip64[1], fstrip64[2], fstrip64[3], fstrip32[0], fstrip32[1], fstrip32[2], fstrip32[3],
-                   fwd_steps, fwd_steps_no_accept, row_task_nonzero, row_task_total, p2_groups_zero, p2_groups, sp16_ahead};
+                   fwd_steps, fwd_steps_no_accept, row_task_nonzero, row_task_total, p2_groups_zero, p2_groups, sp16_ahead,
+                   walk_waves, walk_steps_max, walk_steps_balanced, walk_tiles, walk_rows_max};
   int nv = (int)(sizeof(vals) / sizeof(vals[0]));
   for (int i = 0; i < nv && i < n_out; ++i) out[i] = vals[i];
   for (int i = 0; i < 65 && nv + i < n_out; ++i) out[nv + i] = hist_hits[i];
