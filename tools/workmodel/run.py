@@ -45,7 +45,7 @@ def main():
              "dead_entries", "live_entries", "behind", "task_nonzero", "task_total", "D_all", "all16_batches",
              "live16_batches", "f64_bbox", "f64_xy", "f64_exact", "f64_ideal", "f32_bbox", "f32_xy", "f32_exact", "f32_ideal",
              "fwd_steps", "fwd_steps_no_accept", "row_task_nonzero", "row_task_total", "p2_groups_zero", "p2_groups", "sp16_ahead",
-             "walk_waves", "walk_steps_max", "walk_steps_balanced", "walk_tiles", "walk_rows_max"]
+             "walk_waves", "walk_steps_max", "walk_steps_balanced", "walk_tiles", "walk_rows_max", "walk_waves_over32", "walk_steps_hybrid"]
     v = dict(zip(names, out[:nv]))
     T = v["n_tiles"]
     print(f"tiles {T:.0f}  mean list {v['sumL']/T:.1f}  mean kmax {v['sumK']/T:.1f}  D_all {v['D_all']:.0f}")
@@ -68,7 +68,8 @@ def main():
     print(f"phase 1, batches of 16, an idle lane may take ONE hit of the next batch early: {v['sp16_ahead']/K:.3f} of kmax (now {v['sp16']/K:.3f})")
     print(f"preprocess tile walk: {v['walk_tiles'] / (64 * v['walk_waves']):.2f} tiles walked per Gaussian; wave steps now (max over the 64 lanes) "
           f"{v['walk_steps_max'] / v['walk_waves']:.2f}, balanced over the wave (lane = (Gaussian, tile) task) {v['walk_steps_balanced'] / v['walk_waves']:.2f}; "
-          f"rows: max over lanes {v['walk_rows_max'] / v['walk_waves']:.2f}")
+          f"rows: max over lanes {v['walk_rows_max'] / v['walk_waves']:.2f}; waves holding a walk of more than 32 tiles "
+          f"{v['walk_waves_over32'] / v['walk_waves']:.4f} (steps with the shipped per-wave choice {v['walk_steps_hybrid'] / v['walk_waves']:.2f})")
     h = out[nv:nv + 65]
     cum = np.cumsum(h) / h.sum()
     print("hits/entry quantiles:", {q: int(np.searchsorted(cum, q)) for q in (0.1, 0.25, 0.5, 0.75, 0.9, 0.99)})

@@ -36,11 +36,12 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
   long long D_all = 0;
   // preprocess's inline tile walk (one thread per Gaussian, the wave runs max over its 64 lanes of the walked tiles):
   // wave steps now, and what a walk balanced over the wave (lane = one (Gaussian, tile) task) would take
-  double walk_waves = 0, walk_steps_max = 0, walk_steps_balanced = 0, walk_tiles = 0, walk_hits = 0, walk_rows_max = 0;
+  double walk_waves = 0, walk_steps_max = 0, walk_steps_balanced = 0, walk_tiles = 0, walk_hits = 0, walk_rows_max = 0, walk_waves_over32 = 0, walk_steps_hybrid = 0;
   int wave_max = 0, wave_sum = 0, wave_rows_max = 0;
   for (int g = 0; g < N; ++g) {
     if (g % 64 == 0 && g) {
       walk_waves += 1; walk_steps_max += wave_max; walk_steps_balanced += (wave_sum + 63) / 64; walk_rows_max += wave_rows_max;
+      if (wave_max > 32) { walk_waves_over32 += 1; walk_steps_hybrid += wave_max; } else walk_steps_hybrid += (wave_sum + 63) / 64;
       wave_max = wave_sum = wave_rows_max = 0;
     }
     const Projected pr = project_gaussian(f, means + 3 * (size_t)g, scales + 3 * (size_t)g, rots + 4 * (size_t)g);
@@ -243,7 +244,7 @@ int wm_run(const WmFrame* hf, int32_t N, const float* means, const float* scales
                    live_entries, behind, task_nonzero, task_total, (double)D_all, all16_batches, live16_batches,
                    fstrip64[0], fstrip64[1], fstrip64[2], fstrip64[3], fstrip32[0], fstrip32[1], fstrip32[2], fstrip32[3],
                    fwd_steps, fwd_steps_no_accept, row_task_nonzero, row_task_total, p2_groups_zero, p2_groups, sp16_ahead,
-                   walk_waves, walk_steps_max, walk_steps_balanced, walk_tiles, walk_rows_max};
+                   walk_waves, walk_steps_max, walk_steps_balanced, walk_tiles, walk_rows_max, walk_waves_over32, walk_steps_hybrid};
   int nv = (int)(sizeof(vals) / sizeof(vals[0]));
   for (int i = 0; i < nv && i < n_out; ++i) out[i] = vals[i];
   for (int i = 0; i < 65 && nv + i < n_out; ++i) out[nv + i] = hist_hits[i];
