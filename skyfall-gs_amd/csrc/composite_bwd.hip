@@ -258,96 +258,107 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int tx = (int)(sb % SX) * BE + (wave % BE), ty = (int)(sb / SX) * BE + (wave / BE);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[lw];
-  if (lane < 3) lds.recs[B * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy entry (see phase 1)
   const int W = kf.W, H = kf.H;
   const size_t P = (size_t)W * H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const size_t pix = (size_t)py * W + px;
   const int t = ty * TX8 + tx;
-  const uint2 tr = tile_range[t];
-  const unsigned s = tr.x, e = tr.x + tr.y;
-  const unsigned L = e - s;
-  if (L == 0) return;
-
-  float sx = (float)px, sy = (float)py;
-  unsigned last = 0;
-  PixelBwd ps;
-  {
-    float T_final = 1.f, dac = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gdep = 0.f, galp = 0.f;
-    if (inside) {
-      if (kf.subpix) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
-      last = n_contrib[pix];
-      T_final = final_T[pix];
-      dac = dacc[pix];
-      if (dL_dcolor) { gr = dL_dcolor[pix]; gg = dL_dcolor[P + pix]; gb = dL_dcolor[2 * P + pix]; }
-      if (dL_ddepth) gdep = dL_ddepth[pix];
-      if (dL_dalpha) galp = dL_dalpha[pix];
-    }
-    const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
-    pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
-  }
   static_assert(B == 16, "phase 2 maps pixel groups onto DPP rows: 16 entries x 4 row pairs");
-  // wave-uniform (same for the whole frame): with a black background the bg term of dL/dalpha vanishes identically
-  const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
+  static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
+  static_assert(3 * B <= 64 && REC_F4 == 3, "one gather instruction per batch: 48-byte records, at most 21 entries");
 
+  // ---- prologue: THREE dependent memory round trips per tile, every load of a round in flight together (round 6: the
+  // wave timeline, tools/timeline.py, showed 16 % of all wave time in a prologue of seven serial round trips) -----------
+  // round A (needs the tile's coordinates only): the tile's list range / last contributor / frame words (scalar loads) and
+  // the per-pixel forward state and upstream gradients
+  const uint2 tr = tile_range[t];
   const unsigned kmax = tile_kmax[t];   // max of `last` over the tile's pixels (written by the forward; scalar load)
+  const unsigned prefilled = (unsigned)hdr[HDR_PREFILLED], subpix_bound = (unsigned)hdr[HDR_SUBPIX_BOUND];
+  unsigned last = 0;
+  float T_final = 1.f, dac = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gdep = 0.f, galp = 0.f;
+  if (inside) {
+    last = n_contrib[pix];
+    T_final = final_T[pix];
+    dac = dacc[pix];
+    if (dL_dcolor) { gr = dL_dcolor[pix]; gg = dL_dcolor[P + pix]; gb = dL_dcolor[2 * P + pix]; }
+    if (dL_ddepth) gdep = dL_ddepth[pix];
+    if (dL_dalpha) galp = dL_dalpha[pix];
+  }
+  const unsigned s = tr.x, L = tr.y;
+  if (L == 0) return;
+  // wave-uniform: sample points on the pixel grid (max |subpixel_offset| of the plan == 0)? Then the (all-zero) offsets are
+  // not even loaded: px + 0 = px
+  const bool on_grid = !(kf.subpix && subpix_bound != 0u);
+  float sx = (float)px, sy = (float)py;
+  if (!on_grid && inside) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
 
+  // round B (needs the list range and kmax): ids / duplicate indices of the last batch, ids of the one before, the hit-mask
+  // words of the last two 64-entry groups, and the duplicate indices of the first 64 DEAD entries (behind every pixel's last
+  // contributor: they receive zero gradient records)
+  const int ej = lane & (B - 1), grp = lane / B;  // phase-2 role of this lane
+  const int orow = lane >> 4;   // which float of each record quarter this lane stores (its DPP row; = grp for B = 16)
+  const int nbatch = (int)((kmax + B - 1) / B);
+  // one gather INSTRUCTION per batch: lane = (entry g_rec = lane / 3, 16-byte piece g_piece = lane % 3) for lanes < 3 B, so
+  // adjacent lanes fetch adjacent pieces of a record (one 48-byte request per record instead of three 16-byte ones from
+  // three instructions) and the LDS stage is written with one contiguous ds_write_b128 (float4 index = lane)
+  const int g_rec = lane / 3, g_piece = lane - 3 * g_rec;
+  constexpr int BPG = 64 / B;   // batches per 64-entry hit-mask group
   // list entries behind every pixel's last contributor receive zero gradient -- unless dupgrad_prefill_kernel found so
   // many of them in this frame that it zeroed the whole record array with streaming stores instead
   // (not_prefilled: the caller did not launch the prefill kernel for THIS backward -- the header word may still hold the
   // decision of an earlier backward over the same forward state, e.g. retain_graph)
-  if (not_prefilled || (unsigned)hdr[HDR_PREFILLED] == 0u) {
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (unsigned k = kmax + lane; k < L; k += 64) {
-      float4* dst = dupgrad + (size_t)sorted_dup[s + k] * DG_F4;
+  const bool zero_dead = not_prefilled || prefilled == 0u;
+  if (kmax == 0u) {   // nothing blended in this tile: every entry is dead
+    if (zero_dead) {
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (unsigned k = lane; k < L; k += 64) {
+        float4* dst = dupgrad + (size_t)sorted_dup[s + k] * DG_F4;
 #pragma unroll
-      for (int q = 0; q < DG_F4; ++q) dst[q] = zero4;
+        for (int q = 0; q < DG_F4; ++q) dst[q] = zero4;
+      }
     }
+    return;
   }
-  if (kmax == 0) return;
-
-  const int ej = lane & (B - 1), grp = lane / B;  // phase-2 role of this lane
-  const int orow = lane >> 4;   // which float of each record quarter this lane stores (its DPP row; = grp for B = 16)
-  // wave-uniform: sample points on the pixel grid (max |subpixel_offset| of the plan == 0)?
-  const bool on_grid = !(kf.subpix && (unsigned)hdr[HDR_SUBPIX_BOUND] != 0u);
-  const float ocx = (float)(tx * 8) + 3.5f, ocy = (float)(ty * 8) + 3.5f;  // tile centre
-  const int nbatch = (int)((kmax + B - 1) / B);
-  // Software pipeline over the batches (back to front): the dependent id -> record gathers of the NEXT batch are in
-  // flight while this one is processed, the ids of the one after are fetched alongside (as in the forward).
-  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  [[maybe_unused]] float4 n1 = n0, n2 = n0;
-  unsigned dup_cur = 0, id_next = 0;
-  // one gather INSTRUCTION per batch: lane = (entry g_rec = lane / 3, 16-byte piece g_piece = lane % 3) for lanes < 3 B, so
-  // adjacent lanes fetch adjacent pieces of a record (one 48-byte request per record instead of three 16-byte ones from
-  // three instructions) and the LDS stage is written with one contiguous ds_write_b128 (float4 index = lane)
-  static_assert(3 * B <= 64 && REC_F4 == 3, "one gather instruction per batch: 48-byte records, at most 21 entries");
-  const int g_rec = lane / 3, g_piece = lane - 3 * g_rec;
-  {
-    const unsigned b0 = (unsigned)(nbatch - 1) * B;
-    // the duplicate index of entry ej is needed by all four lanes (ej, row) of the entry: each stores a quarter of
-    // the entry's gradient record (see the combine step)
-    if ((unsigned)ej < kmax - b0) dup_cur = sorted_dup[s + b0 + ej];
-    if (lane < 3 * B && (unsigned)g_rec < kmax - b0) {
-      const unsigned id = sorted_id[s + b0 + g_rec];
-      n0 = rec[REC_F4 * (size_t)id + g_piece];
-    }
-    if (nbatch >= 2) {
-      if (lane < 3 * B) id_next = sorted_id[s + b0 - B + g_rec];
-    }
-  }
+  // Straight-line and UNCONDITIONAL (lanes without an entry re-load a valid neighbour's word: a load under a lane mask
+  // whose result merges with a default value makes the compiler wait for it on the spot)
+  const unsigned bl = (unsigned)(nbatch - 1) * B;   // first entry of the last batch
+  const unsigned nl = kmax - bl;                     // its entry count (1 .. B)
+  // the duplicate index of entry ej is needed by all four lanes (ej, row) of the entry: each stores a quarter of
+  // the entry's gradient record (see the combine step)
+  const unsigned id0 = sorted_id[s + bl + min((unsigned)g_rec, nl - 1u)];
+  unsigned dup_cur = sorted_dup[s + bl + min((unsigned)ej, nl - 1u)];
+  // (a one-batch tile has no batch before the last: the word is re-loaded, never used)
+  unsigned id_next = sorted_id[s + (nbatch >= 2 ? bl - B + min((unsigned)g_rec, (unsigned)(B - 1)) : bl)];
   // hit-mask words of the tile's 64-entry groups (one uint2 per pixel and group), fetched one group ahead
-  static_assert(LIST_ALIGN == 64 && 64 % B == 0, "hit-mask words cover 64 list entries");
-  constexpr int BPG = 64 / B;   // batches per 64-entry hit-mask group
   int g_cur = (nbatch - 1) / BPG;
   uint2 mw = hitmask[(size_t)s + 64u * (unsigned)g_cur + lane];
-  uint2 mw_next = make_uint2(0u, 0u);
-  if (g_cur > 0) mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur - 1) + lane];
+  uint2 mw_next = hitmask[(size_t)s + 64u * (unsigned)(g_cur > 0 ? g_cur - 1 : 0) + lane];
+  const unsigned dead_dup = sorted_dup[s + min(kmax + lane, L - 1u)];
+
+  // LDS set-up while the loads fly: the dummy entry (see phase 1) and the zero (u, w) matrix
+  if (lane < 3) lds.recs[B * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = lane; i < B * ROW; i += 64) lds.UW[i] = make_float2(0.f, 0.f);
+
+  PixelBwd ps;
+  {
+    const float bg[3] = {kf.bg[0], kf.bg[1], kf.bg[2]};
+    pixel_bwd_init(ps, last, T_final, dac, gr, gg, gb, gdep, galp, kf.depth_mode, bg);
+  }
+  // wave-uniform (same for the whole frame): with a black background the bg term of dL/dalpha vanishes identically
+  const bool has_bg = kf.bg[0] != 0.f || kf.bg[1] != 0.f || kf.bg[2] != 0.f;
+
+  // round C (needs the ids): the last batch's records. Software pipeline over the batches (back to front): the dependent
+  // id -> record gathers of the NEXT batch are in flight while this one is processed, the ids of the one after are fetched
+  // alongside (as in the forward).
+  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < 3 * B && (unsigned)g_rec < nl) n0 = rec[REC_F4 * (size_t)id0 + g_piece];
+
+  const float ocx = (float)(tx * 8) + 3.5f, ocy = (float)(ty * 8) + 3.5f;  // tile centre
   // A batch's three 16-byte record stores are issued at the START of the next iteration, right after that iteration's
   // prefetch loads: the s_waitcnt vmcnt(0) the compiler places at the loop's back edge (for the prefetched registers)
   // then only sees memory operations that had a whole batch of arithmetic to complete. Issued at the end of their own
   // iteration, the stores were waited for every batch (measured: the kernel had a 0.08 ms floor of pure store latency).
-  for (int i = lane; i < B * ROW; i += 64) lds.UW[i] = make_float2(0.f, 0.f);
   float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;   // this lane's three floats of the record: floats 3 row .. 3 row + 2 (row = lane >> 4)
   unsigned p_dup = 0;
   bool p_valid = false;
@@ -494,6 +505,20 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
       typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
       v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
       *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
+    }
+  }
+  // the dead entries' zero records, last: nothing waits for these stores (their duplicate indices arrived with round B)
+  if (zero_dead) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kmax + lane < L) {
+      float4* dst = dupgrad + (size_t)dead_dup * DG_F4;
+#pragma unroll
+      for (int q = 0; q < DG_F4; ++q) dst[q] = zero4;
+    }
+    for (unsigned k = kmax + 64 + lane; k < L; k += 64) {
+      float4* dst = dupgrad + (size_t)sorted_dup[s + k] * DG_F4;
+#pragma unroll
+      for (int q = 0; q < DG_F4; ++q) dst[q] = zero4;
     }
   }
 }

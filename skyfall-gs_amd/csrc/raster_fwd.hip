@@ -1708,13 +1708,13 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const size_t pix = (size_t)py * W + px;
-  float sx = (float)px, sy = (float)py;
-  if (kf.subpix && inside) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
-
   const int t = ty * TX8 + tx;
   const uint2 tr = tile_range[t];
   const unsigned s = tr.x, e = tr.x + tr.y;
   const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
+  float sx = (float)px, sy = (float)py;
+  // (an all-zero offset tensor -- what the reference's render() passes without --ray_jitter -- is not even loaded: px + 0 = px)
+  if (kf.subpix && bound != 0.f && inside) { sx += kf.subpix[pix * 2]; sy += kf.subpix[pix * 2 + 1]; }
   PixelFwd ps;
   pixel_fwd_init(ps, inside);
   float4* st = stage[lw];
