@@ -33,6 +33,48 @@ FP32_PEAK_TFLOPS = 157.3
 APPEARANCE_MLP_FLOATS = 24966  # shared parameters all-reduced per step (scene/gaussian_model.py:52-58)
 
 
+def pick_backend(world, device_count, env):
+    """Collective backend of a multi-rank run. "nccl" (= RCCL on ROCm) always, unless SFGS_BENCH_BACKEND=gloo is set -- a TEST
+    hook for boxes with fewer GPUs than ranks (ranks then share GPUs, collectives run on host tensors). It never happens silently
+    and never where RCCL could have run: with a GPU per rank the hook is refused, so a driver-run
+    `bench.py --gpus 8` on an 8-GPU node can only ever report rccl.backend == "nccl"."""
+    backend = env.get("SFGS_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"bench.py: SFGS_BENCH_BACKEND={backend!r}: only 'nccl' (RCCL) or the test hook 'gloo'")
+    if backend == "gloo" and world > 1 and device_count >= world:
+        raise SystemExit(f"bench.py: SFGS_BENCH_BACKEND=gloo refused: {device_count} GPUs are visible for {world} ranks, so the "
+                         "collectives must run over RCCL (backend 'nccl'); the gloo hook is for boxes with fewer GPUs than ranks")
+    if backend == "gloo":
+        print(f"bench.py: TEST HOOK: collectives over gloo on host tensors ({device_count} GPU(s) for {world} rank(s)); "
+              "the JSON line says collective_backend=gloo", file=sys.stderr, flush=True)
+    return backend
+
+
+def box_probe(dev, L):
+    """What THIS box sustains, measured in ~0.1 s before the timed region (boxes of the pool run the same
+    binary 3-8 % apart, so a line from one round cannot be compared with another round's without it): a 256 MB + 256 MB ->
+    256 MB torch add (HBM) and the library's fixed FP32 multiply-add loop (sfgs_box_probe: VALU rate and the shader clock it
+    implies at one wave64 FMA per two cycles per SIMD)."""
+    x = torch.rand(64 * 1024 * 1024, device=dev)
+    y = torch.rand_like(x)
+    z = torch.empty_like(x)
+    for _ in range(3):
+        torch.add(x, y, out=z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        torch.add(x, y, out=z)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    dt = e0.elapsed_time(e1) * 1e-3 / 20
+    del x, y, z
+    torch.cuda.empty_cache()
+    tf, mhz = L.box_probe(None)
+    return {"hbm_tbs": round(3 * 64 * 1024 * 1024 * 4 / dt / 1e12, 3), "valu_tflops": round(tf, 2), "sclk_mhz": round(mhz),
+            "what": "torch add of 2 x 256 MB -> 256 MB (bytes moved / time); sfgs_box_probe: v_fma_f32 loop at 8 waves per SIMD, "
+                    "sclk = the clock that rate implies at 2 cycles per wave64 FMA per SIMD; both before the timed region"}
+
+
 def kernel_bytes(N, Nvis, D, P):
     """SURVEY 8(d) algorithmic bytes split per kernel (sums to 128 N + 184 Nvis + 124 D + 64 P)."""
     return {
@@ -122,7 +164,7 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     # SFGS_BENCH_BACKEND=gloo: test hook that exercises the multi-rank control flow (spawn, barriers, per-rank gather,
     # JSON) on a box with fewer GPUs than ranks -- ranks then share GPUs and the collectives run on host tensors.
-    backend = os.environ.get("SFGS_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    backend = pick_backend(world, torch.cuda.device_count(), os.environ)   # "nccl" is RCCL on ROCm
     local_dev = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -216,6 +258,7 @@ def main():
     step()
     max_tile_list = last_counters()["max_tile_list"]
     collect_full_counters(False)
+    box = box_probe(dev, L) if rank == 0 else None
     # device clock ramp (power management, not this code: the same ramp follows every idle period): a training loop runs
     # at the sustained state, so bring the device there before the W warm-up and K timed steps
     for _ in range(max(args.prewarm_steps, 0)):   # a fixed count: with N > 1 every step holds a collective
@@ -400,6 +443,18 @@ def main():
                      "gpu_busy_source": "sum of the brackets minus the measured cost of an empty event pair per launch (a LOWER "
                                         "bound: the subtraction over-corrects; see host_bound for whether the GPU ever waits)",
                      "host_bound": span}
+    if traffic:
+        # the waste next to the contract's `frac`: real HBM traffic of the whole step from the committed PMC
+        # passes (same file and provenance as roofline.traffic) against the algorithmic bytes
+        # the kernels of a steady-state step (the split route's fine_bin / sort_tiles_reg run in the first, un-hinted frame only)
+        names = ("preprocess", "bin_count", "bin_rank", "bin_scatter", "select_sort", "composite_fwd", "composite_bwd",
+                 "preprocess_bwd", "subpix_bound", "zero_head")
+        tot = sum(v for k, v in traffic.items() if k in names)
+        if tot > 0 and not args.forward_only:
+            roofline_step["traffic"] = int(tot)
+            roofline_step["traffic_over_algorithmic"] = round(tot / B_step, 3)
+            roofline_step["traffic_gbs"] = round(tot / (ms_step * 1e-3) / 1e9, 1)
+            roofline_step["traffic_source"] = traffic_source
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only and args.config == "cfg2":
@@ -420,6 +475,8 @@ def main():
                        "max_tile_list": max_tile_list, "parallelism": f"scene-per-gpu x{world}",
                        "collective_backend": backend if dist is not None else None,
                        "prewarm_steps": args.prewarm_steps, "settle_steps": args.settle_steps, "order": args.order},
+            "subpixel_offset": args.subpixel_offset, "kernel_ms_brackets": "raw",   # not comparable with r1-r4 lines otherwise
+            "box": box,
             "roofline": roofline, "roofline_composite_pair": roofline_pair, "roofline_step": roofline_step,
             "cpu_baseline": cpu_baseline,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
@@ -463,7 +520,7 @@ def load_traffic(N, W, H, forward_only):
         data = json.load(open(path))
         meta = data.pop("_meta", {}) if isinstance(data.get("_meta"), dict) else {}
         for k, v in data.items():
-            key = k.replace("_kernel", "").split("<")[0]
+            key = k.replace("void sfgs::", "").replace("_kernel", "").split("<")[0].split("(")[0]
             key = "sort_tiles" if key.startswith("sort_tiles") else key
             out[key] = out.get(key, 0) + int(v["hbm_bytes_per_launch"])
         src = {"kind": "file, not measured in this run", "file": os.path.relpath(path, ROOT),

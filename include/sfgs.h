@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 16
+#define SFGS_ABI_VERSION 17
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -250,6 +250,12 @@ int sfgs_profile_kernel_count(void);
 const char* sfgs_profile_kernel_name(int32_t id);
 int sfgs_profile_collect(double* ms_sum, int64_t* launches, int32_t n);
 
+/* Box probe (ABI 17; bench.py, before its timed region -- not on the rendering path): a fixed FP32 multiply-add loop at 8 waves
+ * per SIMD on every CU, timed with HIP events on `stream` (synchronous: returns when it has run, ~0.1 s). *valu_tflops = what
+ * the box sustains on plain v_fma_f32; *sclk_mhz_effective = the shader clock that rate implies at one wave64 FMA per two cycles
+ * per SIMD. Boxes of one pool run the same binary 3-8 % apart: a bench line carries these so that rounds can be compared. */
+int sfgs_box_probe(double* valu_tflops, double* sclk_mhz_effective, void* stream);
+
 /* Blob sizes for N Gaussians, a W x H image, a list-slot capacity D (bins, image, dupgrad) and a per-coarse-bin
  * item capacity (bins). Every 8x8 tile's list starts on a multiple of 64 slots and every 32x32-pixel coarse bin's lists
  * are placed from the bin's tile-hit total (an upper bound, scanned by the plan: no allocator), so a frame with
@@ -353,7 +359,11 @@ int sfgs_raster_backward_scratch(const SfgsFrame* frame, const SfgsGaussians* g,
  * C2=0.03^2 == utils/loss_utils.py:23-63) of img1,img2 [B,C,H,W] float32.
  * forward: writes the mean into *ssim_mean (device float), the per-element map into ssim_map when
  * non-NULL and, when with_grad != 0, the three partial-derivative maps the backward consumes into
- * `scratch` (sfgs_ssim_scratch_bytes). The mean is reduced in a fixed order (bit-reproducible).
+ * `scratch` (sfgs_ssim_scratch_bytes). The mean is reduced in a fixed order (bit-reproducible run to run).
+ * Numerics: value and gradient are TOLERANCE-equal to the reference formula (utils/loss_utils.py:33-63; tests: 2e-6 on the
+ * mean, 5e-5 relative on the gradient), not bit-equal to it nor across ABI 15 -> 16: since ABI 16 the derivative maps use
+ * 1/B1 = B2 * inv and 1/B2 = B1 * inv with one reciprocal of B1 * B2 where the reference divides twice, and the 32 x 22
+ * tiling sums the mean's partials in a different (fixed) order.
  * backward: dL_dimg1 = *dL_dmean (device float) * d(mean ssim)/d(img1); img2 gets no gradient
  * (it is the ground truth, train.py:222).
  * Limits (SFGS_E_UNSUPPORTED): H * W < 2^30 pixels per plane, at most 2^31 - 1 tiles of 32 x 22 pixels in all. */

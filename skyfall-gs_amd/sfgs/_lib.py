@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGS_LIB") or os.path.join(_HERE, "libsfgs.so")   # SFGS_LIB: experiment builds (tools/)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 SFGS_OK = 0
 DEPTH_NORMALISED, DEPTH_RAW = 0, 1
@@ -89,6 +89,7 @@ SYMBOLS = {
     "sfgs_profile_kernel_count": (C.c_int, []),
     "sfgs_profile_kernel_name": (C.c_char_p, [_I32]),
     "sfgs_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
+    "sfgs_box_probe": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), _V]),
     "sfgs_raster_sizes": (C.c_int, [_I32, _I32, _I32, _I64, _I64, C.POINTER(SfgsRasterSizes)]),
     "sfgs_raster_slot_capacity": (C.c_int64, [_I32, _I32, _I64]),
     "sfgs_raster_forward_plan": (C.c_int, [C.POINTER(SfgsFrame), C.POINTER(SfgsGaussians), _V, _V, _SZ, _V, _SZ, _V, _SZ,
@@ -173,26 +174,27 @@ def set_option(key, value):
     lib = load()
     old = lib.sfgs_get_option(str(key).encode())
     check(lib.sfgs_set_option(str(key).encode(), str(value).encode()))   # raises for an unknown key or value
-    _opt_cache[key] = str(value)
     return old.decode()
 
 
-_opt_cache = {}   # key -> value as last read / set through THIS module (the wrapper asks once per frame: a dict lookup, not a
-                  # C call; a C caller that changes an option behind Python's back must call refresh_options())
-
-
 def get_option(key):
-    v = _opt_cache.get(key)
-    if v is None:
-        raw = load().sfgs_get_option(str(key).encode())
-        if raw is None:
-            raise KeyError(f"libsfgs.so has no option {key!r}")
-        v = _opt_cache[key] = raw.decode()
-    return v
+    """The library's CURRENT value (one ctypes call: no Python-side mirror that a C caller or a second binding could leave
+    stale -- ADVICE r5)."""
+    raw = load().sfgs_get_option(str(key).encode())
+    if raw is None:
+        raise KeyError(f"libsfgs.so has no option {key!r}")
+    return raw.decode()
 
 
-def refresh_options():
-    _opt_cache.clear()
+def refresh_options():   # kept for callers of the ABI-16 binding: there is no cache any more
+    pass
+
+
+def box_probe(stream=None):
+    """-> (valu_tflops, sclk_mhz_effective) of this box (include/sfgs.h: sfgs_box_probe)."""
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    check(load().sfgs_box_probe(C.byref(a), C.byref(b), stream))
+    return a.value, b.value
 
 
 def profile_enable(on=True):

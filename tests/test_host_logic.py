@@ -221,3 +221,38 @@ def test_route_options_are_set_through_the_abi_not_the_environment():
         del os.environ["SFGS_SORT"]
     src = "".join(open(os.path.join(ROOT, "skyfall-gs_amd", "csrc", f)).read() for f in ("raster_fwd.hip", "raster_bwd.hip", "composite_bwd.hip", "knn.hip"))
     assert "getenv" not in src
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sfgs_bench_for_tests", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_never_falls_back_to_gloo_where_rccl_can_run(capsys):
+    """`bench.py --gpus N` on a node with a GPU per rank can only ever run its collectives over RCCL
+    (backend "nccl"); the gloo hook is a TEST hook for boxes with fewer GPUs than ranks, refused otherwise, never silent."""
+    b = _bench_module()
+    assert b.pick_backend(8, 8, {}) == "nccl"
+    assert b.pick_backend(2, 1, {}) == "nccl"                  # no silent fallback either: nccl is asked for and fails loudly
+    for world, gpus in ((2, 2), (8, 8), (2, 8)):
+        with pytest.raises(SystemExit, match="refused"):
+            b.pick_backend(world, gpus, {"SFGS_BENCH_BACKEND": "gloo"})
+    assert b.pick_backend(2, 1, {"SFGS_BENCH_BACKEND": "gloo"}) == "gloo"      # the hook: fewer GPUs than ranks
+    assert "TEST HOOK" in capsys.readouterr().err                             # ... and it says so
+    assert b.pick_backend(1, 1, {"SFGS_BENCH_BACKEND": "gloo"}) == "gloo"      # world 1 (--force-dist tests)
+    with pytest.raises(SystemExit):
+        b.pick_backend(2, 2, {"SFGS_BENCH_BACKEND": "mpi"})
+
+
+def test_bench_step_traffic_sums_the_steady_state_kernels():
+    """roofline_step.traffic = the committed PMC bytes of the kernels a steady-state step launches."""
+    b = _bench_module()
+    t, src = b.load_traffic(2_000_000, 1920, 1080, False)
+    assert src and src["file"].startswith("profiles/")
+    for k in ("composite_bwd", "composite_fwd", "preprocess", "preprocess_bwd", "bin_scatter", "select_sort"):
+        assert t.get(k, 0) > 0, k
+    assert b.load_traffic(1000, 64, 64, False) == ({}, None)

@@ -17,7 +17,7 @@ cp "$SRC"/*.hip "$SRC"/*.cpp "$SRC"/*.h "$W/skyfall-gs_amd/csrc/"; cp "$ROOT"/in
 for p in "$@"; do ( cd "$W" && patch -s -p1 < "$ROOT/$p" ); done
 cd "$W/skyfall-gs_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
-SRCS="api.cpp raster_fwd.hip raster_bwd.hip composite_bwd.hip ssim.hip knn.hip prepass.hip filter3d.hip densify_stats.hip adam.hip sh_eval.hip compact.hip densify.hip"
+SRCS="api.cpp raster_fwd.hip raster_bwd.hip composite_bwd.hip ssim.hip knn.hip prepass.hip filter3d.hip densify_stats.hip adam.hip sh_eval.hip compact.hip densify.hip probe.hip"
 mkdir -p o
 for f in $SRCS; do
   extra=""; [ $f = raster_bwd.hip -o $f = raster_fwd.hip -o $f = ssim.hip ] && extra="-fno-slp-vectorize"
