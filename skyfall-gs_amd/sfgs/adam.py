@@ -18,6 +18,18 @@ from . import _lib as L
 __all__ = ["FusedAdam", "install", "uninstall"]
 
 
+def _dense(t):
+    """True when t's elements occupy exactly numel() consecutive storage slots (any permutation of a contiguous layout)."""
+    if t.is_contiguous():
+        return True
+    expect = 1
+    for size, stride in sorted(((sz, sd) for sz, sd in zip(t.shape, t.stride()) if sz != 1), key=lambda x: x[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 class FusedAdam(torch.optim.Adam):
     """Drop-in for `torch.optim.Adam(params, lr, betas, eps, weight_decay)` on float32 / float64 GPU parameters."""
 
@@ -43,7 +55,7 @@ class FusedAdam(torch.optim.Adam):
         return new
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None):  # noqa: C901
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -63,9 +75,13 @@ class FusedAdam(torch.optim.Adam):
                 if g.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
                 # float64: the reference's `_opacity` group from its first reset_opacity on (scene/gaussian_model.py:483-501)
-                if not p.is_cuda or p.dtype not in (torch.float32, torch.float64) or not p.is_contiguous():
-                    raise ValueError("FusedAdam: parameters must be contiguous float32 / float64 GPU tensors "
-                                     f"(got {p.dtype}, {p.device}, contiguous={p.is_contiguous()})")
+                # Layout: any DENSE, non-overlapping layout (the update is elementwise, so parameter, gradient and moments
+                # only have to share ONE index -> offset map): the reference's `_xyz` is column-major from create_from_pcd
+                # (fetchPly's `np.vstack([x, y, z]).T`, scene/dataset_readers.py:126-132 -> torch.tensor keeps the strides)
+                # until the first densification re-allocates it -- found by running the real train.training() (round 6).
+                if not p.is_cuda or p.dtype not in (torch.float32, torch.float64) or not _dense(p):
+                    raise ValueError("FusedAdam: parameters must be dense (non-overlapping) float32 / float64 GPU tensors "
+                                     f"(got {p.dtype}, {p.device}, shape {tuple(p.shape)}, strides {p.stride()})")
                 if g.dtype != p.dtype or g.device != p.device or g.shape != p.shape:
                     raise ValueError("FusedAdam: gradient dtype/device/shape must match its parameter")
                 st = self.state[p]
@@ -78,14 +94,14 @@ class FusedAdam(torch.optim.Adam):
                     if t.dtype != p.dtype or t.device != p.device or t.shape != p.shape:
                         raise ValueError(f"FusedAdam: state '{name}' does not match its parameter "
                                          f"({tuple(t.shape)} {t.dtype} {t.device} vs {tuple(p.shape)})")
-                    if not t.is_contiguous():
-                        st[name] = t = t.contiguous()
+                    if t.stride() != p.stride():     # e.g. a state dict loaded into a differently laid out parameter
+                        st[name] = t = torch.empty_like(p, memory_format=torch.preserve_format).copy_(t)
                         if name == "exp_avg":
                             m = t
                         else:
                             v = t
-                if not g.is_contiguous():
-                    g = g.contiguous()
+                if g.stride() != p.stride():
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                 st["step"] += 1
                 t_step = float(st["step"])
                 # host scalars in double, exactly as torch/optim/adam.py::_multi_tensor_adam forms them

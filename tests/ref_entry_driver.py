@@ -1,0 +1,425 @@
+#!/usr/bin/env python
+"""ref_entry_driver.py -- the reference's ENTRY FUNCTIONS themselves on this repo's drop-ins (VERDICT r5 "missing" item 3).
+
+north_star: "drops in behind gaussian_renderer.render() and GaussianModel so train.py / render_video.py run unchanged".
+tests/ref_real_driver.py executes render() + GaussianModel + a loop re-spelled from train.py; THIS driver executes
+
+    train.training(dataset, opt, pipe, testing_iterations, saving_iterations, checkpoint_iterations, checkpoint, debug_from)
+                                                                                          /root/reference/train.py:79-348
+    render_video.render_sets(dataset, iteration, pipeline, camera_path, load_from_checkpoints, ...)
+                                                                                   /root/reference/render_video.py:172-272
+
+-- the functions, not restatements: with their Scene (scene/__init__.py:21-98 -> the "Satellite" loader
+scene/dataset_readers.py:360-570 on a scene this driver writes to disk: transforms_train/test.json, points3D.txt,
+images/*.png, depths_moge/*.exr), network_gui (init + the per-iteration try_connect), tqdm, the torch.cuda.Event iter_time
+pair (train.py:120-121,167,281,305), training_report's evaluation pass at a test iteration, add_densification_stats /
+densify_and_prune / compute_3D_filter on the reference's schedule, the checkpoint capture() -> torch.save (train.py:342-344)
+and, in a second call, torch.load -> restore() (train.py:97-110), scene.save() -> save_ply; then render_sets loads the
+checkpoint AND the saved PLY and renders a camera path into the video writer. The module objects are imported from
+/root/reference when it exists (authoring container) or from the staged archive (tools/stage_reference.py).
+
+`diff_gauss`, `fused_ssim`, `simple_knn` resolve to this repo's packages (libsfgs.so). What is NOT this repo's and absent
+from the image is stood in for, as SURVEY App. C lists: plyfile (sfgs.ply's two classes), OpenEXR (a reader of the float32
+payload this driver writes), mediapy (a VideoWriter that keeps the frames), torchmetrics' pearson_corrcoef (six lines of
+torch), torchvision's to_pil_image, lpips, the MoGe / FlowEdit IDU classes train.py instantiates at import (inert: the
+out-of-scope diffusion side, SURVEY 8 "out"), tensorboardX (absent; train.py tolerates that itself).
+
+Modes:  --backend hip (default; needs a GPU: the real thing) | --backend oracle (GPU-less dry run of THIS harness: "cuda"
+allocations redirected to the CPU as tests/golden/make_golden_r3.py does, the rasterizer's backend seam swapped for the C
+oracle double, fused_ssim / distCUDA2 doubles from the reference's own ssim and scipy -- test infrastructure only).
+--hooks: install every fused sfgs hook on the reference's GaussianModel first (tools/launch_scenes.py: install_hooks).
+
+Prints one JSON line per stage and `REF-ENTRY OK`; exits non-zero on the first failure. Only tests/ runs it.
+"""
+import argparse
+import json
+import math
+import os
+import socket
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "skyfall-gs_amd")
+STAGE = os.path.join(HERE, "_refstage", "skyfall_ref.zip")
+for p in (HERE, ROOT, PKG, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H = 256, 160
+N_POINTS = 20000
+CAM_HEIGHT = 300.0
+FRAMES = []          # what render_video's VideoWriter received
+
+
+def locate_reference():
+    env = os.environ.get("SFGS_REFERENCE")
+    if env == "stage":                                  # force the staged archive where the tree exists too (harness check)
+        return STAGE if os.path.isfile(STAGE) else None
+    for p in ([env] if env else []) + ["/root/reference"]:
+        if p and os.path.isfile(os.path.join(p, "train.py")):
+            return p
+    return STAGE if os.path.isfile(STAGE) else None
+
+
+# ---- the scene on disk (Satellite format: what scripts/run_jax.py trains on) -------------------------------------------
+def _c2w_looking_down(cx, cy, tilt):
+    """COLMAP-convention camera (x right, y down, z forward) at (cx, cy, CAM_HEIGHT) looking at the ground, tilted by `tilt`
+    radians about its x axis."""
+    Rx = np.array([[1, 0, 0], [0, math.cos(tilt), -math.sin(tilt)], [0, math.sin(tilt), math.cos(tilt)]])
+    R = np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]]) @ Rx     # camera axes in world coordinates (columns)
+    m = np.eye(4)
+    m[:3, :3] = R
+    m[:3, 3] = [cx, cy, CAM_HEIGHT]
+    return m
+
+
+def write_scene(path, seed=5):
+    """20 000 coloured points on a bumpy ground patch seen by three cameras from 300 units up (the geometry of the urban
+    tiles: scene radius ~ 128, view depth 250-350); images / depth maps = the points splatted as 3x3 squares."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    os.makedirs(os.path.join(path, "depths_moge"), exist_ok=True)
+    xy = rng.uniform(-95.0, 95.0, size=(N_POINTS, 2))
+    z = 8.0 + 6.0 * np.sin(xy[:, 0] / 25.0) * np.cos(xy[:, 1] / 30.0) + rng.uniform(0, 1.0, N_POINTS)
+    xyz = np.concatenate([xy, z[:, None]], axis=1)
+    rgb = np.stack([0.5 + 0.45 * np.sin(xy[:, 0] / 18.0), 0.5 + 0.45 * np.cos(xy[:, 1] / 22.0),
+                    0.5 + 0.45 * np.sin((xy[:, 0] + xy[:, 1]) / 35.0)], axis=1)
+    rgb8 = np.clip(rgb * 255.0, 1, 255).astype(np.uint8)          # never (0, 0, 0): the loader masks black pixels out
+    with open(os.path.join(path, "points3D.txt"), "w") as f:
+        f.write("# 3D point list with one line of data per point:\n#   POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[]\n")
+        for i in range(N_POINTS):
+            f.write(f"{i + 1} {xyz[i, 0]:.5f} {xyz[i, 1]:.5f} {xyz[i, 2]:.5f} {rgb8[i, 0]} {rgb8[i, 1]} {rgb8[i, 2]} 0.5\n")
+    fl = (W / 2) / math.tan(math.radians(40.0) / 2)
+    cams = [("train_0", 0.0, 0.0, 0.0), ("train_1", 12.0, -8.0, 0.05), ("train_2", -10.0, 6.0, -0.04), ("test_0", 4.0, 3.0, 0.02)]
+    frames = {"train": [], "test": []}
+    for name, cx, cy, tilt in cams:
+        c2w = _c2w_looking_down(cx, cy, tilt)
+        w2c = np.linalg.inv(c2w)
+        pc = xyz @ w2c[:3, :3].T + w2c[:3, 3]
+        u = fl * pc[:, 0] / pc[:, 2] + W / 2
+        v = fl * pc[:, 1] / pc[:, 2] + H / 2
+        img = np.full((H, W, 3), 40, np.uint8)
+        dep = np.full((H, W), CAM_HEIGHT, np.float32)
+        order = np.argsort(-pc[:, 2])                                # far first: near points overwrite
+        for i in order:
+            x0, y0 = int(round(u[i])), int(round(v[i]))
+            if 1 <= x0 < W - 1 and 1 <= y0 < H - 1 and pc[i, 2] > 0:
+                img[y0 - 1:y0 + 2, x0 - 1:x0 + 2] = rgb8[i]
+                dep[y0 - 1:y0 + 2, x0 - 1:x0 + 2] = pc[i, 2]
+        Image.fromarray(img, "RGB").save(os.path.join(path, "images", name + ".png"))
+        with open(os.path.join(path, "depths_moge", name + ".exr"), "wb") as f:      # see the OpenEXR stand-in below
+            f.write(b"SFGSEXR1" + np.array([H, W], np.int32).tobytes() + dep.tobytes())
+        frames[name.split("_")[0]].append({"file_path": f"images/{name}.png", "transform_matrix": c2w.tolist(),
+                                           "fl_x": fl, "fl_y": fl, "cx": W / 2, "cy": H / 2, "w": W, "h": H})
+    for split in ("train", "test"):
+        with open(os.path.join(path, f"transforms_{split}.json"), "w") as f:
+            json.dump({"frames": frames[split]}, f)
+    return path
+
+
+def write_camera_path(path, n=6):
+    """A nerfstudio-style camera path (render_video.py:64-127): OpenGL camera-to-world matrices, fov in degrees."""
+    cams = []
+    for i in range(n):
+        a = 0.05 * (i - n / 2)
+        R = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1.0]])   # OpenGL: looks along -z = down
+        m = np.eye(4)
+        m[:3, :3] = R
+        m[:3, 3] = [3.0 * i - 8.0, 2.0 * i - 5.0, CAM_HEIGHT - 5.0 * i]
+        cams.append({"camera_to_world": m.reshape(-1).tolist(), "fov": 28.0, "aspect": W / H})
+    with open(path, "w") as f:
+        json.dump({"render_height": H, "render_width": W, "_radius": 128.0, "fps": 8, "seconds": n / 8, "camera_path": cams}, f)
+    return path
+
+
+# ---- stand-ins for third-party packages the image lacks ------------------------------------------------
+def install_stand_ins():
+    from sfgs import ply as sply
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+            if "." in name:
+                parent, child = name.rsplit(".", 1)
+                setattr(mod(parent), child, m)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+    try:
+        import plyfile  # noqa: F401
+    except ImportError:
+        mod("plyfile", PlyData=sply.PlyData, PlyElement=sply.PlyElement)
+
+    class _ExrInput:                       # OpenEXR.InputFile as scene/dataset_readers.py:572-597 uses it, on write_scene's payload
+        def __init__(self, filename):
+            raw = open(filename, "rb").read()
+            assert raw[:8] == b"SFGSEXR1", "not a depth map written by this driver"
+            self.h, self.w = (int(x) for x in np.frombuffer(raw[8:16], np.int32))
+            self.data = raw[16:]
+
+        def header(self):
+            box = types.SimpleNamespace(min=types.SimpleNamespace(x=0, y=0), max=types.SimpleNamespace(x=self.w - 1, y=self.h - 1))
+            return {"dataWindow": box, "channels": {"Y": types.SimpleNamespace(type="FLOAT")}}
+
+        def channel(self, name, pixel_type):
+            return self.data
+    mod("OpenEXR", InputFile=_ExrInput)
+    mod("Imath")
+
+    class _VideoWriter:                    # mediapy.VideoWriter as render_video.py:244-250 uses it
+        def __init__(self, path, shape, fps):
+            self.path, self.shape, self.fps = path, tuple(shape), fps
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            with open(self.path, "wb") as f:
+                f.write(b"frames: %d\n" % len(FRAMES))
+            return False
+
+        def add_image(self, img):
+            assert img.shape[:2] == self.shape, (img.shape, self.shape)
+            FRAMES.append(np.asarray(img).copy())
+    mod("mediapy", VideoWriter=_VideoWriter)
+
+    def pearson_corrcoef(preds, target):   # torchmetrics.functional.regression.pearson_corrcoef for [P, 1] inputs
+        x, y = preds.squeeze(-1).double(), target.squeeze(-1).double()
+        xm, ym = x - x.mean(), y - y.mean()
+        return ((xm * ym).sum() / (xm.square().sum().sqrt() * ym.square().sum().sqrt())).to(preds.dtype)
+    mod("torchmetrics.functional.regression", pearson_corrcoef=pearson_corrcoef)
+
+    def to_pil_image(t):
+        from PIL import Image
+        return Image.fromarray((t.detach().clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8))
+    mod("torchvision.transforms.functional", to_pil_image=to_pil_image)
+
+    class _Unused:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            raise RuntimeError(f"{type(self).__name__}.{name}: out of scope here (SURVEY 8 'out': the diffusion / depth-prior side)")
+    mod("lpips", LPIPS=type("LPIPS", (_Unused,), {}))
+    mod("submodules.MoGe.idu_depth", MoGeIDU=type("MoGeIDU", (_Unused,), {}))
+    mod("submodules.FlowEdit.idu_refine", FlowEditRefineIDU=type("FlowEditRefineIDU", (_Unused,), {}))
+
+
+# ---- GPU-less dry run of this harness (--backend oracle): doubles, never the product -----------------------------------
+def install_cpu_doubles():
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden_r3 as mg3
+    mg3._redirect_cuda()
+    import diff_gauss
+    import oracle_backend
+    diff_gauss._backend = oracle_backend.OracleBackend()
+
+    class _Event:                          # torch.cuda.Event(enable_timing=True) on a host without a GPU
+        def __init__(self, *a, **k):
+            self.t = None
+
+        def record(self, *a):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+        def synchronize(self):
+            pass
+    torch.cuda.Event = _Event
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.empty_cache = lambda *a, **k: None
+    orig_load = torch.load
+    torch.load = lambda f, *a, **k: orig_load(f, *a, **{**k, "map_location": "cpu"})
+    # fused_ssim / simple_knn doubles: the reference's own ssim (what fused_ssim replaces) and scipy's exact k-NN
+    fs = types.ModuleType("fused_ssim")
+
+    def fused_ssim(img1, img2, *a, **k):
+        from utils.loss_utils import ssim
+        return ssim(img1, img2)
+    fs.fused_ssim = fused_ssim
+    sys.modules["fused_ssim"] = fs
+    sk, skc = types.ModuleType("simple_knn"), types.ModuleType("simple_knn._C")
+
+    def distCUDA2(points):
+        from scipy.spatial import cKDTree
+        p = points.detach().cpu().double().numpy()
+        d, _ = cKDTree(p).query(p, k=4)
+        return torch.from_numpy((d[:, 1:] ** 2).mean(axis=1)).float()
+    skc.distCUDA2 = distCUDA2
+    sk._C = skc
+    sys.modules["simple_knn"], sys.modules["simple_knn._C"] = sk, skc
+
+
+def tensors_equal(a, b):
+    return a.shape == b.shape and bool(torch.equal(a.detach().cpu(), b.detach().cpu()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=["hip", "oracle"], default="hip")
+    ap.add_argument("--hooks", action="store_true")
+    ap.add_argument("--work", required=True, help="scratch directory (scene, model output, ./depth_tmp)")
+    ap.add_argument("--iters", type=int, default=300)
+    a = ap.parse_args()
+    ref = locate_reference()
+    if ref is None:
+        print("REF-ENTRY SKIP: no reference tree and no staged archive")
+        return 0
+    # train.py:99 / render_video.py:186 call torch.load(path) on their OWN checkpoints, which hold a numpy scalar
+    # (spatial_lr_scale): written for torch < 2.6, whose default was weights_only=False. The documented switch, not an edit:
+    os.environ["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = "1"
+    os.makedirs(a.work, exist_ok=True)
+    os.chdir(a.work)                                   # train.py creates ./depth_tmp in the CWD at import
+    install_stand_ins()
+    sys.path.insert(0, ref)
+    if a.backend == "oracle":
+        install_cpu_doubles()
+    else:
+        assert torch.cuda.is_available(), "--backend hip needs a GPU"
+        from sfgs import _lib
+        _lib.load()                                    # fails loudly if libsfgs.so is missing: there is no fallback
+    import train                                       # the reference's module: its import-time code runs (MoGeIDU(...), ./depth_tmp)
+    import render_video
+    import diff_gauss
+    import gaussian_renderer
+    from arguments import ModelParams, OptimizationParams, PipelineParams
+    from gaussian_renderer import network_gui
+    from scene.gaussian_model import GaussianModel
+    from utils.general_utils import safe_state
+    src = lambda m: os.path.abspath(m.__file__)
+    assert src(train).startswith(ref) and src(render_video).startswith(ref) and src(gaussian_renderer).startswith(ref)
+    assert src(diff_gauss).startswith(PKG) and gaussian_renderer.GaussianRasterizer is diff_gauss.GaussianRasterizer
+    if a.backend == "hip":
+        import fused_ssim
+        import simple_knn._C
+        assert src(fused_ssim).startswith(PKG) and src(simple_knn._C).startswith(PKG) and train.fused_ssim is fused_ssim.fused_ssim
+    if a.hooks:
+        import launch_scenes
+        launch_scenes.install_hooks(GaussianModel, fused=True)
+    print(json.dumps({"stage": "import", "reference": ref, "backend": a.backend, "hooks": a.hooks,
+                      "libsfgs": None if a.backend == "oracle" else sys.modules["sfgs._lib"].LIB_PATH}), flush=True)
+
+    scene_dir = write_scene(os.path.join(a.work, "scene"))
+    model_dir = os.path.join(a.work, "model")
+    K, K_ckpt = a.iters, a.iters // 2
+    d_from, d_int = a.iters // 3, a.iters // 3                    # ONE densify_and_prune, at iteration 2 * iters / 3
+    argv = ["-s", scene_dir, "-m", model_dir, "--eval", "--resolution", "1", "--sh_degree", "1", "--kernel_size", "0.1",
+            "--iterations", str(K), "--densify_from_iter", str(d_from), "--densification_interval", str(d_int),
+            "--densify_until_iter", str(K - 10), "--densify_grad_threshold", "0.00005", "--position_lr_max_steps", str(K)]
+
+    def parse(extra):
+        from argparse import ArgumentParser                      # train.py:1104-1121, statement for statement
+        parser = ArgumentParser(description="Training script parameters")
+        lp, op, pp = ModelParams(parser), OptimizationParams(parser), PipelineParams(parser)
+        args = parser.parse_args(argv + extra)
+        return lp.extract(args), op.extract(args), pp.extract(args)
+
+    # what the iterations saw: training_report is called once per iteration with the loss tensor and iter_time (train.py:305)
+    log = []
+    orig_report = train.training_report
+
+    def report(tb_writer, iteration, Ll1, loss, l1_loss, elapsed, testing_iterations, scene, *rest, **kw):
+        log.append({"it": iteration, "loss": float(loss.item()), "l1": float(Ll1.item()), "iter_ms": float(elapsed),
+                    "n": int(scene.gaussians.get_xyz.shape[0])})
+        if iteration == report.grab_at:
+            g = scene.gaussians
+            report.grabbed = [t.detach().clone() for t in (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)]
+            report.grabbed_opt = {k: {f: (t.detach().clone() if torch.is_tensor(t) else t) for f, t in v.items()}
+                                  for k, v in g.optimizer.state_dict()["state"].items()}   # clones: the steps update in place
+        return orig_report(tb_writer, iteration, Ll1, loss, l1_loss, elapsed, testing_iterations, scene, *rest, **kw)
+    report.grab_at, report.grabbed = -1, None
+    train.training_report = report
+
+    if a.backend == "hip":
+        safe_state(True)                                          # train.py:1126: seeds + torch.cuda.set_device(cuda:0) + quiet stdout
+    else:
+        import random
+        random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    network_gui.init("127.0.0.1", port)                           # train.py:1129 (the loop polls try_connect every iteration)
+
+    # ---- 1. training(): from scratch, K iterations ---------------------------------------------------------------------
+    lp, op, pp = parse([])
+    t0 = time.perf_counter()
+    train.training(lp, op, pp, [K], [K], [K_ckpt, K], None, -1)
+    dt = time.perf_counter() - t0
+    sys.stdout = sys.__stdout__
+    run1 = list(log)
+    assert [r["it"] for r in run1] == list(range(1, K + 1)), "training_report was not called once per iteration"
+    first, last = np.mean([r["loss"] for r in run1[:20]]), np.mean([r["loss"] for r in run1[-20:]])
+    assert all(math.isfinite(r["loss"]) for r in run1), "non-finite loss"
+    assert last < 0.8 * first, f"the loss did not fall: {first:.4f} -> {last:.4f}"
+    assert all(math.isfinite(r["iter_ms"]) and r["iter_ms"] > 0 for r in run1), "iter_time events (train.py:120-121,305) returned no time"
+    n_series = [r["n"] for r in run1]
+    d_iter = 2 * d_int
+    assert n_series[d_iter - 1] == n_series[0] and n_series[d_iter] != n_series[0], \
+        f"densify_and_prune at iteration {d_iter} did not change the model: {n_series[d_iter - 2:d_iter + 2]}"
+    for f in (f"chkpnt{K_ckpt}.pth", f"chkpnt{K}.pth", f"point_cloud/iteration_{K}/point_cloud.ply", "cfg_args", "cameras.json", "input.ply"):
+        assert os.path.isfile(os.path.join(model_dir, f)), f"training() did not write {f}"
+    print(json.dumps({"stage": "training", "iterations": K, "seconds": round(dt, 1), "loss_first20": round(float(first), 5),
+                      "loss_last20": round(float(last), 5), "gaussians": [n_series[0], n_series[-1]], "densified_at": d_iter,
+                      "iter_ms_median": round(float(np.median([r["iter_ms"] for r in run1[20:]])), 3)}), flush=True)
+
+    # ---- 2. training() again from the mid-run checkpoint: torch.load -> restore() (train.py:97-110) ---------------------
+    ck = os.path.join(model_dir, f"chkpnt{K_ckpt}.pth")
+    saved, saved_iter = torch.load(ck, **({} if a.backend == "hip" else {"map_location": "cpu"}))
+    assert saved_iter == K_ckpt
+    del log[:]
+    report.grab_at = K_ckpt + 1                                   # the first report after restore(): before any optimizer.step
+    if a.backend == "hip":
+        safe_state(True)
+    lp, op, pp = parse(["--iterations", str(K_ckpt + 20)])
+    train.training(lp, op, pp, [], [], [], ck, -1)
+    sys.stdout = sys.__stdout__
+    run2 = list(log)
+    assert [r["it"] for r in run2] == list(range(K_ckpt + 1, K_ckpt + 21)), [r["it"] for r in run2][:3]
+    names = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+    for nm, got, want in zip(names, report.grabbed, saved[1:7]):
+        assert tensors_equal(got, want), f"restore(): {nm} differs from the checkpoint"
+    want_state = saved[13]["state"]
+    assert set(report.grabbed_opt) == set(want_state), "restore(): optimizer state keys differ"
+    for k, st in want_state.items():
+        for field in ("exp_avg", "exp_avg_sq"):
+            assert tensors_equal(report.grabbed_opt[k][field], st[field]), f"restore(): Adam {field} of group {k} differs"
+    # the resumed run continues where the first one was (same model, same cameras, different RNG draws): same loss level
+    l1_resume = np.mean([r["loss"] for r in run2])
+    l1_there = np.mean([r["loss"] for r in run1[K_ckpt:K_ckpt + 20]])
+    assert abs(l1_resume - l1_there) < 0.25 * l1_there, (l1_resume, l1_there)
+    print(json.dumps({"stage": "restore", "from": K_ckpt, "iterations": 20, "loss_resumed": round(float(l1_resume), 5),
+                      "loss_first_run_same_span": round(float(l1_there), 5), "gaussians": run2[0]["n"]}), flush=True)
+
+    # ---- 3. render_video.render_sets() on the saved model --------------------------------------------------------------
+    cam_path = write_camera_path(os.path.join(a.work, "path.json"))
+    from argparse import ArgumentParser
+    parser = ArgumentParser()
+    lp_, pp_ = ModelParams(parser, sentinel=True), PipelineParams(parser)   # render_video.py:254-256
+    args = parser.parse_args(["-s", scene_dir, "-m", model_dir, "--eval", "--resolution", "1", "--sh_degree", "1", "--kernel_size", "0.1"])
+    del FRAMES[:]
+    t0 = time.perf_counter()
+    render_video.render_sets(lp_.extract(args), K, pp_.extract(args), cam_path, True, False, True, 0)
+    dt = time.perf_counter() - t0
+    assert len(FRAMES) == 6, len(FRAMES)
+    fr = np.stack(FRAMES)
+    assert fr.shape == (6, H, W, 3) and np.isfinite(fr).all(), (fr.shape, "non-finite frame")
+    assert fr.std() > 0.02 and fr.max() <= 1.5, ("flat or exploding frames", float(fr.std()), float(fr.max()))
+    assert np.abs(fr[0] - fr[-1]).mean() > 1e-3, "the camera path did not move"
+    vid = os.path.join(model_dir, "video", f"ours_{K}", "path.mp4")
+    assert os.path.isfile(vid) and len(os.listdir(os.path.join(model_dir, "video", f"ours_{K}", "path_frames"))) == 6
+    print(json.dumps({"stage": "render_sets", "frames": 6, "seconds": round(dt, 1), "mean": round(float(fr.mean()), 4),
+                      "std": round(float(fr.std()), 4)}), flush=True)
+    print("REF-ENTRY OK", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -193,6 +193,41 @@ def test_fused_adam_matches_torch_adam_on_gpu(n):
             assert float(fus.state[y]["step"]) == float(ref.state[x]["step"]) == 4.0
 
 
+def test_dense_layout_rule():
+    from sfgs.adam import _dense
+    x = torch.zeros(7, 3)
+    assert _dense(x) and _dense(x.t()) and _dense(torch.zeros(3, 7).t()) and _dense(torch.zeros(5, 1, 3).transpose(1, 2))
+    assert not _dense(x[:, :2]) and not _dense(x[::2]) and not _dense(torch.zeros(4).expand(3, 4))
+
+
+@pytest.mark.gpu
+def test_fused_adam_steps_a_column_major_parameter_like_the_references_initial_xyz():
+    """create_from_pcd builds `_xyz` from fetchPly's `np.vstack([x, y, z]).T` (scene/gaussian_model.py:316, dataset_readers.py:
+    126-132): torch.tensor keeps the transposed strides, so until the first densification the reference's position parameter
+    is COLUMN-major. torch.optim.Adam does not care; the fused step must not either (found by the real train.training())."""
+    from sfgs.adam import FusedAdam
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    base = torch.randn(3, 5001, generator=gen)
+
+    def make(cls):
+        a = torch.nn.Parameter(base.to(dev).t())            # [5001, 3], strides (1, 5001)
+        assert not a.is_contiguous()
+        return cls([{"params": [a], "lr": 1e-2}], lr=0.0, eps=1e-15), a
+    ref, x = make(torch.optim.Adam)
+    fus, y = make(FusedAdam)
+    for s in range(3):
+        g = torch.randn(5001, 3, generator=gen).to(dev)
+        # autograd hands a leaf a gradient in the leaf's own layout; a contiguous one must work too (step 2)
+        x.grad = torch.empty_like(x).copy_(g) if s != 2 else g.clone()
+        y.grad = torch.empty_like(y).copy_(g) if s != 2 else g.clone()
+        ref.step(); fus.step()
+    assert y.stride() == x.stride() == (1, 5001)
+    torch.testing.assert_close(y, x, rtol=RTOL, atol=ATOL)
+    for k in ("exp_avg", "exp_avg_sq"):
+        torch.testing.assert_close(fus.state[y][k], ref.state[x][k], rtol=RTOL, atol=1e-6 * float(ref.state[x][k].abs().max()))
+
+
 @pytest.mark.gpu
 def test_install_rehomes_the_optimizer_training_setup_builds():
     from sfgs import adam
