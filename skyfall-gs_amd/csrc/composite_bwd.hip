@@ -458,17 +458,31 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
 #undef SFGS_P2
         pa = phase2_grid_finish(pg, mxl, dy0, dy1);
       } else {
+        // jittered sample points (--ray_jitter): the generic form, software-pipelined like the grid form (round 6: rolled over
+        // four 4-pixel groups with each (u, w) pair consumed right behind its LDS round trip, it cost +30 % of the kernel)
         pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define SFGS_P2(I) { const float2 t_ = uw_take(UWrow + I); phase2_step<I>(pa, t_.x, t_.y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3); }
-#pragma nounroll
-        for (int c = 0; c < 4; ++c) {
-          switch (c) {
-            case 0: SFGS_P2(0); SFGS_P2(1); SFGS_P2(2); SFGS_P2(3); break;
-            case 1: SFGS_P2(4); SFGS_P2(5); SFGS_P2(6); SFGS_P2(7); break;
-            case 2: SFGS_P2(8); SFGS_P2(9); SFGS_P2(10); SFGS_P2(11); break;
-            default: SFGS_P2(12); SFGS_P2(13); SFGS_P2(14); SFGS_P2(15); break;
-          }
+#define SFGS_P2(I) phase2_step<I>(pa, uw##I.x, uw##I.y, mx, my, cA, cB, cC, sx, sy, g0, g1, g2, g3)
+#define SFGS_P2_LOAD(A, Bq, C, D) const float2 uw##A = uw_take(UWrow + A), uw##Bq = uw_take(UWrow + Bq), uw##C = uw_take(UWrow + C), uw##D = uw_take(UWrow + D);
+#define SFGS_P2_DO(A, Bq, C, D) SFGS_P2(A); SFGS_P2(Bq); SFGS_P2(C); SFGS_P2(D);
+#define SFGS_P2_FENCE asm volatile("" ::: "memory");
+        {
+          SFGS_P2_LOAD(0, 1, 2, 3)
+          SFGS_P2_LOAD(4, 5, 6, 7)
+          SFGS_P2_FENCE
+          SFGS_P2_DO(0, 1, 2, 3)
+          SFGS_P2_FENCE
+          SFGS_P2_LOAD(8, 9, 10, 11)
+          SFGS_P2_FENCE
+          SFGS_P2_DO(4, 5, 6, 7)
+          SFGS_P2_FENCE
+          SFGS_P2_LOAD(12, 13, 14, 15)
+          SFGS_P2_FENCE
+          SFGS_P2_DO(8, 9, 10, 11)
+          SFGS_P2_DO(12, 13, 14, 15)
         }
+#undef SFGS_P2_LOAD
+#undef SFGS_P2_DO
+#undef SFGS_P2_FENCE
 #undef SFGS_P2
       }
     }

@@ -252,33 +252,23 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
   // owners publish what the test needs (48 bytes) and their lane number in the task slots they own, every lane takes task
   // 64 p + lane in pass p (4.9 passes), hits are ORed into the owner's mask words with LDS atomics. Same tests on the
   // same tiles: masks and duplicate counts are bit-identical.
-  // A wave that holds a walk of more than WALK_COOP_MAX tiles (its task map would not fit the LDS block) keeps the
-  // thread-per-Gaussian loop for all its lanes: UHD frames and low elevations, where most waves hold one, would
-  // otherwise pay for that lane's long loop AND for the passes (measured: +12 ... +17 %).
-  const bool coop_walk = __ballot(walk_tiles > (unsigned)WALK_COOP_MAX) == 0ull;
-  if (!coop_walk && walk_tiles) {
-    // ONE flat loop over the tiles of the walk range (a 4-deep coarse-bin x tile loop nest with per-lane bounds costs as
-    // much in divergent loop control as the tile tests themselves); hits are ORed into the 16-bit mask of their coarse
-    // bin, BIG_WALK (= 6) masks = 96 bits in two registers. The tile's pixel origin is carried as two floats stepped by
-    // 8 (bin_test_at: the bounds bin_test derives from the tile indices, bit for bit) and the mask position is shifts
-    // and ands of unsigned indices (the tile range is never negative).
-    static_assert(COARSE == 4, "mask position: 2-bit tile coordinates inside a coarse bin");
-    const unsigned ncx = (unsigned)(cx1 - cx0);
-    const float fx_first = (float)(br.x0 * TILE_BIN), wm1 = (float)(f.W - 1), hm1 = (float)(f.H - 1);
-    unsigned tx = (unsigned)br.x0, ty = (unsigned)br.y0;
-    float fx = fx_first, fy = (float)(br.y0 * TILE_BIN);
-    for (unsigned q = walk_tiles; q > 0; --q) {
-      if (bin_test_at(r, thr, fx, fy, wm1, hm1, bound)) {
-        const unsigned slot = ((ty >> 2) - (unsigned)cy0) * ncx + ((tx >> 2) - (unsigned)cx0);
-        const unsigned pos = slot * 16u + (ty & 3u) * 4u + (tx & 3u);
-        if (pos < 64u) mask_lo |= 1ull << pos; else mask_hi |= 1ull << (pos - 64u);
-        ++n_dup;
-      }
-      fx += (float)TILE_BIN;
-      if (++tx == (unsigned)br.x1) { tx = (unsigned)br.x0; fx = fx_first; ++ty; fy += (float)TILE_BIN; }
-    }
+  // A walk of more than WALK_COOP_MAX tiles (33 .. 96: its tasks would not fit the wave's task map) is not left to its
+  // owner thread -- until round 6 such a lane sent its WHOLE wave back to the thread-per-Gaussian loop, up to 96 serial tile
+  // tests with 63 lanes waiting: most waves of a low-elevation or UHD frame (preprocess 0.078 -> 0.276 ms on the pitched
+  // camera) -- but walked by the whole wave, lane = tile, as the mid-size splats below are: its at most 6 coarse bins are
+  // two ballots, whose 16-bit slices ARE the owner's mask words (walk_ballot4: same tests, same bit positions).
+  const bool wide = walk_tiles > (unsigned)WALK_COOP_MAX;
+  const unsigned long long wide_lanes = __ballot(wide);
+  if (wide) walk_tiles = 0;   // not a task of the cooperative map
+  for (unsigned long long wl_ = wide_lanes; wl_; wl_ &= wl_ - 1) {
+    const int L = __builtin_ctzll(wl_);
+    const WalkArgs a = broadcast_walk(r, br, thr, cx0, cx1, cy0, cy1, L);
+    int cb_;
+    const unsigned long long m0 = walk_ballot4(a, 0, lane, f.W, f.H, bound, &cb_, CX);
+    const unsigned long long m1 = (a.cx1 - a.cx0) * (a.cy1 - a.cy0) > 4 ? walk_ballot4(a, 1, lane, f.W, f.H, bound, &cb_, CX) : 0ull;
+    if (lane == L) { mask_lo = m0; mask_hi = m1; n_dup = (unsigned)__popcll(m0) + (unsigned)__popcll(m1); }
   }
-  if (coop_walk) {
+  {
     __shared__ WalkLds s_walk[PRE_BLOCK / 64];
     const unsigned incl = wave_incl_scan_u32(walk_tiles);
     const unsigned total_t = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
