@@ -363,7 +363,7 @@ def main():
                         "stream; a gap above the cost of two event records (~0.01 ms) means the GPU waited for the host"}
 
     train_shaped = None
-    if args.cameras > 0 and not args.forward_only and rank == 0:
+    if args.cameras > 0 and not args.forward_only and dist is None:   # single-process runs only: its steps hold no collective
         train_shaped = run_train_shaped(args, dev, frame, t, means2D, gc, gd, W, H, max(sh, 0), GaussianRasterizationSettings,
                                         GaussianRasterizer, last_counters, step)
     per_rank_ms = [elapsed / args.steps * 1e3]

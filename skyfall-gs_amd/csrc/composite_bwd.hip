@@ -239,7 +239,7 @@ __device__ __forceinline__ void phase1_walk(BwdLds<B>& lds, PixelBwd& ps, unsign
 
 template <int B>
 __global__ void __launch_bounds__(64 * BWG_WAVES, 16 / BWG_WAVES)   // 16 waves per CU (the LDS allows no more)
-composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2* __restrict__ tile_range,
+composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* __restrict__ tile_range,
                      const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ sorted_dup,
                      const float4* __restrict__ rec, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
@@ -250,12 +250,11 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[BWG_WAVES];
   // wave-uniform: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
-  unsigned sb;
-  int wave, lw;
-  composite_wave_role<BWG_WAVES>((unsigned)nblk, sb, wave, lw);
+  int sbx, sby, wave, lw;
+  if (!composite_wave_role<BWG_WAVES>(SX, SY, sbx, sby, wave, lw)) return;   // a surplus workgroup of the padded grid
   const int lane = threadIdx.x & 63;
   constexpr int BE = composite_block_edge<BWG_WAVES>();
-  const int tx = (int)(sb % SX) * BE + (wave % BE), ty = (int)(sb / SX) * BE + (wave / BE);
+  const int tx = sbx * BE + (wave % BE), ty = sby * BE + (wave / BE);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[lw];
   const int W = kf.W, H = kf.H;
@@ -537,12 +536,12 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int nblk, const uint2*
   }
 }
 
-void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8, int TY8, int SX, int nblk,
+void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8, int TY8, int SX, int SY,
                           const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
                           const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
                           const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,
                           float4* dupgrad, const unsigned long long* hdr, int not_prefilled) {
-  hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(grid), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX, nblk, tile_range,
+  hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(grid), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX, SY, tile_range,
                      sorted_id, sorted_dup, rec, n_contrib, final_T, dacc, dL_dcolor, dL_ddepth, dL_dalpha, hitmask, tile_kmax,
                      dupgrad, hdr, not_prefilled);
 }

@@ -365,7 +365,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const KFrame kf = make_kframe(frame);
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   constexpr int BE = composite_block_edge<BWG_WAVES>();
-  const int SX = (TX8 + BE - 1) / BE, SY = (TY8 + BE - 1) / BE, nblk = SX * SY;
+  const int SX = (TX8 + BE - 1) / BE, SY = (TY8 + BE - 1) / BE;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
     // (without the prefill kernel its decision word keeps the plan's zero: composite_bwd writes the zero records itself)
     if (!(frame->launch_hints & SFGS_HINT_NO_PREFILL))
@@ -373,7 +373,7 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                        (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
                        (unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
-    launch_composite_bwd((unsigned)(nblk * (BE * BE / BWG_WAVES)), stream, kf, TX8, TY8, SX, nblk, tv.tile_range, bv.sorted_id,
+    launch_composite_bwd(composite_grid(SX, SY, BE * BE / BWG_WAVES), stream, kf, TX8, TY8, SX, SY, tv.tile_range, bv.sorted_id,
                          bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth, dL_dalpha, iv.hitmask,
                          iv.tile_kmax, (float4*)dupgrad, tv.hdr, (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0);
   }

@@ -197,11 +197,14 @@ struct TilesView {
   uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
+  float* subpix_part;       // [SUBPIX_PARTS] per-workgroup maxima of |subpixel_offset| (plan_head_kernel; fully rewritten per frame)
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
   // two-pass binning without device atomics: per (scatter workgroup, coarse bin) the workgroup's items, their tile hits
   // and -- after the column scan -- the first slab rank of its run ([scatter_groups(N)][N_cb] each, fully rewritten per frame)
   uint32_t *sc_cnt, *sc_hits, *sc_base;
 };
+constexpr int SUBPIX_PARTS = 64;     // workgroups (at most) that reduce the sub-pixel offset tensor in the plan's head launch: one
+                                     // partial maximum per lane of the waves that pick them up (preprocess_kernel)
 constexpr int SCATTER_BLOCKS = 32;   // preprocess workgroups per scatter workgroup
 static inline int tiles8_x(int W) { return (W + TILE_BIN - 1) / TILE_BIN; }
 static inline int tiles8_y(int H) { return (H + TILE_BIN - 1) / TILE_BIN; }
@@ -224,6 +227,7 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   t.long_tiles = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
+  t.subpix_part = (float*)(p + off); off += align_up((size_t)SUBPIX_PARTS * 4, 256);
   const size_t msz = align_up((size_t)scatter_groups(N) * NCB * 4, 256);
   t.sc_cnt = (uint32_t*)(p + off); off += msz;
   t.sc_hits = (uint32_t*)(p + off); off += msz;
@@ -388,17 +392,46 @@ static_assert(BWG_WAVES == 16 || BWG_WAVES == 8 || BWG_WAVES == 4 || BWG_WAVES =
 // A workgroup's tiles come from a BLOCK of CBLK x CBLK tiles (2 x 2 = the 16x16-pixel super-tile; 4 x 4 for workgroups of
 // 8 / 16 waves); a block is split over CBLK^2 / WAVES workgroups.
 template <int WAVES> constexpr int composite_block_edge() { return WAVES > 4 ? 4 : 2; }
-// block `sb`, wave-in-block `wave` and wave-in-workgroup `lw` (its slice of the workgroup's LDS) of the calling
-// wave; all wave-uniform: the tile, its list range and every loop bound derived from them become SGPRs
+// Which block of tiles a compositing workgroup takes. Hardware places workgroup b on XCD b % 8. Until round 6 every XCD owned
+// ONE contiguous eighth of the image (xcd_remap): perfect for the L2, and a load-balance disaster on any frame that is not
+// uniform -- the wave timeline of an orbit view of a city at 25 degrees elevation (tools/timeline.py, profiles/r6_*) has one XCD
+// finish composite_fwd after 13 us and another after 299 us. Now the image is cut into CHUNKS of 8 x 4 blocks (128 x 64 pixels
+// with 2 x 2-tile blocks; 32 workgroups that run back to back on ONE XCD and share its L2 like before) and the chunks are
+// dealt to the XCDs round-robin in row-major order: every XCD gets every eighth chunk, spread over the whole frame.
+constexpr int CHUNK_BX = 8, CHUNK_BY = 4;
+static inline unsigned composite_grid(int SX, int SY, int per_block) {   // workgroups to launch (padded: surplus ones return at once)
+  const unsigned nch = (unsigned)((SX + CHUNK_BX - 1) / CHUNK_BX) * (unsigned)((SY + CHUNK_BY - 1) / CHUNK_BY);
+  return (nch + 7u) / 8u * 8u * (unsigned)(CHUNK_BX * CHUNK_BY * per_block);
+}
+#ifdef __HIPCC__
+// block (sbx, sby), wave-in-block `wave` and wave-in-workgroup `lw` (its slice of the workgroup's LDS) of the calling
+// wave; all wave-uniform: the tile, its list range and every loop bound derived from them become SGPRs. false: a surplus
+// workgroup of the padded grid (nothing to do).
 template <int WAVES = CWG_WAVES>
-__device__ __forceinline__ void composite_wave_role(unsigned nblk, unsigned& sb, int& wave, int& lw) {
+__device__ __forceinline__ bool composite_wave_role(int SX, int SY, int& sbx, int& sby, int& wave, int& lw) {
   constexpr int E = composite_block_edge<WAVES>();
   constexpr unsigned PER = E * E / WAVES;   // workgroups per block
-  const unsigned l = xcd_remap(blockIdx.x, nblk * PER);
+  constexpr unsigned CS = CHUNK_BX * CHUNK_BY * PER;
+  const unsigned b = blockIdx.x, idx = b >> 3;
+  const unsigned c = (idx / CS) * 8u + (b & 7u), within = idx % CS;   // chunk, position inside it
+  const unsigned SXc = (unsigned)(SX + CHUNK_BX - 1) / CHUNK_BX;
+  const unsigned st = within / PER;
+  sbx = (int)((c % SXc) * CHUNK_BX + st % CHUNK_BX);
+  sby = (int)((c / SXc) * CHUNK_BY + st / CHUNK_BX);
   lw = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  sb = l / PER;
-  wave = (int)(l % PER) * WAVES + lw;
+  wave = (int)(within % PER) * WAVES + lw;
+  return sbx < SX && sby < SY;
 }
+
+// the same idea in one dimension (select_sort_kernel: workgroups = rows of four tiles of the coarse bins, 4 per bin): chunks of
+// CS consecutive workgroups, dealt to the XCDs round-robin; the last < 8 CS workgroups keep their own index. Bijective.
+__device__ __forceinline__ unsigned xcd_chunked(unsigned b, unsigned n, unsigned CS) {
+  const unsigned nfull = n / (8u * CS) * (8u * CS);
+  if (b >= nfull) return b;
+  const unsigned idx = b >> 3;
+  return ((idx / CS) * 8u + (b & 7u)) * CS + idx % CS;
+}
+#endif
 
 // ---- [N,3] rows (means, scales, colours and their gradients): ONE 12-byte access per thread instead of three dword accesses
 // 12 bytes apart (round 4; cf. profiles/r4_bwd_store3_ab.txt: partial scattered accesses cost per instruction, not per byte)
@@ -520,7 +553,7 @@ __device__ __forceinline__ unsigned block_excl_scan_u32(unsigned v, unsigned* to
 }
 
 // composite_bwd.hip (a translation unit of its own: compiled with another scheduling strategy, see the Makefile)
-void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8, int TY8, int SX, int nblk,
+void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8, int TY8, int SX, int SY,
                           const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
                           const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
                           const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,

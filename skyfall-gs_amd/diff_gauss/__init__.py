@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from sfgs import _lib as L
-from sfgs import features as _features, prepass, sh as _sh, viewdirs as _viewdirs   # the hooks' handle types (recognised below)
+from sfgs import features as _features, max_radii as _max_radii, prepass, sh as _sh, viewdirs as _viewdirs   # the hooks' handle types
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_counters",
            "last_backward_hints", "collect_full_counters"]
@@ -676,4 +676,6 @@ class GaussianRasterizer(nn.Module):
         else:
             color, depth, norm, alpha, radii = _backend.rasterize(means3D, means2D, shs, colors_precomp, opacities,
                                                                   scales, rotations, self.raster_settings, **kw)
-        return color, depth, norm, alpha, radii, None
+        # sfgs.max_radii (opt-in hook): `radii` as a tensor subclass over the same storage, so that train.py:314's masked max
+        # runs without its three nonzero synchronisations; a plain tensor otherwise
+        return color, depth, norm, alpha, _max_radii.wrap_radii(radii), None

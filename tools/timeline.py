@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Wave timeline of a compositing kernel on the headline scene (design tool; runs on the GPU box).
-Needs a library built with tools/variants/bwd_timeline.patch (or fwd_timeline.patch), which makes every wave store
+Needs a library built with tools/variants/timeline.patch, which makes every wave store
 (entry time, first-batch time, exit time, [nbatch | XCC | HW_ID]) per tile, 100 MHz wall clock:
-    tools/build_variant.sh timeline "" tools/variants/bwd_timeline.patch
+    tools/build_variant.sh timeline "" tools/variants/timeline.patch
     SFGS_LIB=$PWD/skyfall-gs_amd/sfgs/_exp/lib_timeline.so python tools/timeline.py [--n N] [--steps K]
 Prints: kernel span, wave-time integral -> mean resident waves per SIMD, share of wave time spent in the per-tile
 prologue, how the kernel's last stretch drains (resident waves over time), per-XCD finish times."""
@@ -24,16 +24,26 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--kernel", default="bwd", choices=["bwd", "fwd"], help="composite_bwd or composite_fwd<TRAIN> (batches of 64 entries)")
+    ap.add_argument("--regime", default="headline", choices=["headline", "city_e25", "city_e45", "orbit_e25", "low_elevation"],
+                    help="scene / camera (tools/bench_regimes.py's geometry)")
     a = ap.parse_args()
     import numpy as np
     import torch
     from sfgs import _lib as L
-    from sfgs.synth import scene, upstream_grads
+    from sfgs.synth import city_scene, orbit_scene, scene, upstream_grads
     from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
     L.load()
     dev = torch.device("cuda:0")
     W, H, N = a.width, a.height, a.n
-    frame, g = scene(N, W, H, seed=0)
+    if a.regime == "headline":
+        frame, g = scene(N, W, H, seed=0)
+    elif a.regime.startswith("city"):
+        frame, g = city_scene(N, W, H, float(a.regime[-2:]), seed=0)
+    elif a.regime.startswith("orbit"):
+        frame, g = orbit_scene(N, W, H, float(a.regime[-2:]), seed=0)
+    else:
+        frame, g = scene(N, W, H, seed=0, pitch_deg=45.0, zrange=(40.0, 400.0))
     gc, gd = upstream_grads(W, H, 0)
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=frame["tanfovx"], tanfovy=frame["tanfovy"], kernel_size=frame["kernel_size"],
@@ -50,13 +60,13 @@ def main():
                 v.grad = None
         color, depth, *_ = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=t["colors_precomp"],
                                 opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
-        torch.autograd.backward([color, depth], [gc, gd])
+        torch.autograd.backward([color, torch.nan_to_num(depth)], [gc, gd])
     torch.cuda.synchronize()
     lib = C.CDLL(L.LIB_PATH)
     T8 = ((W + 7) // 8) * ((H + 7) // 8)
     n = min(T8, 65536)
     buf = (C.c_uint64 * (4 * n))()
-    rc = lib.sfgs_dbg_timeline(buf, 4 * n)
+    rc = (lib.sfgs_dbg_timeline if a.kernel == "bwd" else lib.sfgs_dbg_timeline_fwd)(buf, 4 * n)
     assert rc == 0, rc
     tl = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4).astype(np.int64)
     ok = tl[:, 2] > 0
@@ -69,7 +79,8 @@ def main():
     span = t2.max()
     life = t2 - t0
     pro = t1 - t0
-    res = {"tiles_with_work": int(len(tl)), "kernel_span_us": round(float(span), 1),
+    res = {"kernel": a.kernel, "regime": a.regime, "nbatch_mean": round(float(nbatch.mean()), 2), "nbatch_p99": int(np.percentile(nbatch, 99)),
+           "nbatch_max": int(nbatch.max()), "tiles_with_work": int(len(tl)), "kernel_span_us": round(float(span), 1),
            "wave_time_integral_us": round(float(life.sum()), 0),
            "mean_resident_waves_per_simd": round(float(life.sum() / span / 1024.0), 3),
            "prologue_share_of_wave_time": round(float(pro.sum() / life.sum()), 4),
