@@ -151,23 +151,11 @@ preprocess_kernel(KFrame kf, int N, const float* __restrict__ means3D, const flo
                   uint32_t* __restrict__ block_nvis, unsigned long long* __restrict__ block_dref,
                   uint4* __restrict__ big_list, unsigned long long* __restrict__ hdr,
                   unsigned long long* __restrict__ dup_pool, uint4* __restrict__ pairs,
-                  uint32_t* __restrict__ block_items, const float* __restrict__ subpix_part, int subpix_parts) {
+                  uint32_t* __restrict__ block_items) {
   __shared__ unsigned s_red[PRE_BLOCK / 64 + 1];
   __shared__ unsigned long long s_base;
   const FrameParams f = load_frame(kf);
-  // max |subpixel_offset| of the frame: the plan's head launch left one partial maximum per workgroup (plan_head_kernel);
-  // every wave reduces the <= 64 floats itself -- no atomic, no barrier, no launch of its own (round 6; with 512 partials and a
-  // workgroup reduction this cost preprocess 10 us) -- and the first one publishes the result for the kernels behind this one (big_walk, the compositing kernels). subpix_parts == 0: no
-  // offset tensor, or a caller that filled the header word itself (sfgs_raster_plan_merge).
-  float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
-  if (subpix_parts > 0) {   // kernel argument: uniform. <= 64 partials: one per lane, every wave reduces them by itself
-    static_assert(SUBPIX_PARTS <= 64, "one partial maximum per lane");
-    float m = subpix_part[min((int)lane_id(), subpix_parts - 1)];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    bound = m;
-    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HDR_SUBPIX_BOUND] = (unsigned long long)__float_as_uint(bound);
-  }
+  const float bound = __uint_as_float((unsigned)hdr[HDR_SUBPIX_BOUND]);
   const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int CX = (((f.W + TILE_BIN - 1) / TILE_BIN) + COARSE - 1) / COARSE;
   unsigned n_dup = 0, vis = 0, dref = 0, depth_bits = 0;
@@ -1927,33 +1915,6 @@ __global__ void __launch_bounds__(256) zero_head_kernel(uint4* __restrict__ p, u
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
-// The plan's head launch when the frame carries a sub-pixel offset tensor (every frame of the reference's render(): zeros when
-// ray jitter is off): workgroups [0, nz) clear the head, workgroups [nz, nz + parts) each reduce a slice of the tensor to
-// max |offset| -> part[b]. Two roles, ONE launch (round 6: subpix_bound_kernel was a launch of its own with an atomic per
-// workgroup on a header word the clearing had to precede); preprocess_kernel reduces the partial maxima.
-__global__ void __launch_bounds__(256) plan_head_kernel(uint4* __restrict__ p, unsigned n16, unsigned nz,
-                                                        const float* __restrict__ subpix, int64_t n, float* __restrict__ part) {
-  if (blockIdx.x < nz) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
-    return;
-  }
-  __shared__ float s_m[4];
-  const int64_t b = blockIdx.x - nz, nb = gridDim.x - nz;
-  float m = 0.f;
-  const int64_t n4 = (reinterpret_cast<uintptr_t>(subpix) & 15) ? 0 : (n >> 2);  // unaligned view: scalar tail only
-  const float4* __restrict__ v4 = reinterpret_cast<const float4*>(subpix);
-  for (int64_t i = b * 256 + threadIdx.x; i < n4; i += nb * 256) {
-    const float4 v = v4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
-  for (int64_t i = (n4 << 2) + b * 256 + threadIdx.x; i < n; i += nb * 256) m = fmaxf(m, fabsf(subpix[i]));
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-  if (lane_id() == 0) s_m[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) part[b] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-}
 static hipError_t zero_head(void* p, size_t bytes, hipStream_t stream) {
   const unsigned n16 = (unsigned)(bytes / 16);   // zero_bytes is a multiple of 256
   hipLaunchKernelGGL(zero_head_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (uint4*)p, n16);
@@ -2008,18 +1969,16 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
   const BinsView bv = bins_view_csr(bins, dup_capacity, NCB, coarse_capacity, N);
   const KFrame kf = make_kframe(frame);
   const int NB = (int)pre_blocks(N);
-  int subpix_parts = 0;
-  if (frame->subpixel_offset) {   // clear + partial maxima of |subpixel_offset| in one launch (plan_head_kernel)
+  SFGS_CHECK_HIP(zero_head(tiles, tv.zero_bytes, stream));
+  if (frame->subpixel_offset) {
+    // (round 6 tried ONE launch for the clear and the reduction -- per-workgroup partial maxima that every preprocess wave
+    // reduces: the launch saved is worth less than what the 31 250 waves pay for it, 88 -> 92 us for the three kernels;
+    // profiles/r6_plan_head_merge_ab_not_kept.txt)
     const int64_t n = (int64_t)W * H * 2;
-    subpix_parts = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, SUBPIX_PARTS));
-    const unsigned n16 = (unsigned)(tv.zero_bytes / 16), nz = (n16 + 255) / 256;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 512));
     { ProfScope ps_(KID_SUBPIX, stream);
-      hipLaunchKernelGGL(plan_head_kernel, dim3(nz + (unsigned)subpix_parts), dim3(256), 0, stream, (uint4*)tiles, n16, nz,
-                         frame->subpixel_offset, n, tv.subpix_part); }
-    SFGS_CHECK_HIP(hipGetLastError());
-    SFGS_POST_LAUNCH("plan_head", stream, frame->debug);
-  } else {
-    SFGS_CHECK_HIP(zero_head(tiles, tv.zero_bytes, stream));
+      hipLaunchKernelGGL(subpix_bound_kernel, dim3(blocks), dim3(256), 0, stream, frame->subpixel_offset, n, tv.hdr); }
+    SFGS_POST_LAUNCH("subpix_bound", stream, frame->debug);
   }
   // two-pass binning (pair list + bin_scatter_kernel) unless the coarse-bin index does not fit the pair's 16 bits (images
   // beyond 65 536 coarse bins = 8 192 x 8 192 pixels) or SFGS_BINNING=direct asks for the one-pass path (A/B, tests)
@@ -2034,8 +1993,7 @@ extern "C" int sfgs_raster_forward_plan(const SfgsFrame* frame, const SfgsGaussi
                      g->sh_centers ? 1 : 0, radii, gv.rec, gv.dup, tv.coarse_count,                                    \
                      bv.slabs,                                                                                         \
                      (unsigned)coarse_capacity, (unsigned long long)dup_capacity, tv.block_nvis, tv.block_dref,        \
-                     gv.big_list, tv.hdr, tv.dup_pool, two_pass ? bv.pairs : nullptr, gv.block_items, tv.subpix_part,       \
-                     subpix_parts)
+                     gv.big_list, tv.hdr, tv.dup_pool, two_pass ? bv.pairs : nullptr, gv.block_items)
 #define SFGS_LAUNCH_PRE(K, D)                                                                                          \
   do {                                                                                                                 \
     if constexpr ((K) > 0) {                                                                                           \

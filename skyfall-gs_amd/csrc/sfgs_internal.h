@@ -197,14 +197,11 @@ struct TilesView {
   uint32_t* long_tiles;     // [T8] ids of the tiles with more than 512 entries (HDR_LONG_COUNT of them)
   uint32_t* block_nvis;     // [NB]
   unsigned long long* block_dref;  // [NB]
-  float* subpix_part;       // [SUBPIX_PARTS] per-workgroup maxima of |subpixel_offset| (plan_head_kernel; fully rewritten per frame)
   size_t zero_bytes;        // bytes from the start of the blob that plan() must clear
   // two-pass binning without device atomics: per (scatter workgroup, coarse bin) the workgroup's items, their tile hits
   // and -- after the column scan -- the first slab rank of its run ([scatter_groups(N)][N_cb] each, fully rewritten per frame)
   uint32_t *sc_cnt, *sc_hits, *sc_base;
 };
-constexpr int SUBPIX_PARTS = 64;     // workgroups (at most) that reduce the sub-pixel offset tensor in the plan's head launch: one
-                                     // partial maximum per lane of the waves that pick them up (preprocess_kernel)
 constexpr int SCATTER_BLOCKS = 32;   // preprocess workgroups per scatter workgroup
 static inline int tiles8_x(int W) { return (W + TILE_BIN - 1) / TILE_BIN; }
 static inline int tiles8_y(int H) { return (H + TILE_BIN - 1) / TILE_BIN; }
@@ -227,7 +224,6 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   t.long_tiles = (uint32_t*)(p + off); off += align_up((size_t)T8 * 4, 256);
   t.block_nvis = (uint32_t*)(p + off); off += align_up((size_t)NB * 4, 256);
   t.block_dref = (unsigned long long*)(p + off); off += align_up((size_t)NB * 8, 256);
-  t.subpix_part = (float*)(p + off); off += align_up((size_t)SUBPIX_PARTS * 4, 256);
   const size_t msz = align_up((size_t)scatter_groups(N) * NCB * 4, 256);
   t.sc_cnt = (uint32_t*)(p + off); off += msz;
   t.sc_hits = (uint32_t*)(p + off); off += msz;
@@ -383,10 +379,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
 // super-tile per workgroup). With 1 every 8x8 tile is a workgroup of its own: the four waves of a super-tile never
 // synchronise anyway, and a one-wave workgroup gives its LDS and wave slot back the moment ITS list is done instead of
 // when the longest of four lists is (2: half a super-tile). Workgroups stay XCD-contiguous in super-tile order.
-constexpr int CWG_WAVES = 4;
+constexpr int CWG_WAVES = 1;   // composite_fwd (round 6, with the chunked XCD mapping: -2 ... -3.5 % against 4 on the headline and on
+                               // every regime, profiles/r6_wg_waves_chunks_ab.txt); composite_bwd keeps four, see BWG_WAVES
 // composite_bwd's own value (round 4 experiment: 8 = 4x2 tiles, 16 = 4x4 tiles = a coarse bin per workgroup, so that the
 // tiles that gather the same records share a CU's L1; one-wave workgroups measured +3.8 %: profiles/r4_bwd_lds18_ab_not_kept.txt)
-constexpr int BWG_WAVES = CWG_WAVES;
+constexpr int BWG_WAVES = 4;   // (1 and 2 measured again in round 6: +6 ... +7 % on the headline, nothing gained on the skewed regimes)
 static_assert(CWG_WAVES == 4 || CWG_WAVES == 2 || CWG_WAVES == 1, "compositing workgroups: 4, 2 or 1 of a super-tile's tiles");
 static_assert(BWG_WAVES == 16 || BWG_WAVES == 8 || BWG_WAVES == 4 || BWG_WAVES == 2 || BWG_WAVES == 1, "composite_bwd workgroups");
 // A workgroup's tiles come from a BLOCK of CBLK x CBLK tiles (2 x 2 = the 16x16-pixel super-tile; 4 x 4 for workgroups of
