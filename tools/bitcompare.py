@@ -20,6 +20,8 @@ SCENES = {
     "lists_3k": dict(n=3000, W=24, H=24, kw=dict(zrange=(3., 6.), scale_range=(0.8, 1.5), opacity_range=(0.006, 0.012))),
     "big_splats": dict(n=400, W=256, H=192, kw=dict(zrange=(3., 6.), scale_range=(0.3, 2.0))),
     "headline_2M_1080p": dict(n=2000000, W=1920, H=1080, kw=dict()),
+    # (round 6) a pitched camera: splats of 33..96 tiles (the wave-wide walk of preprocess), lists of 513..1 024 entries
+    "low_elevation_300k_720p": dict(n=300000, W=1280, H=720, kw=dict(pitch_deg=45.0, zrange=(40.0, 400.0))),
 }
 
 

@@ -22,6 +22,9 @@ $B --forward-only --config cfg3 > "$R/fps_cfg3_1024sq.json" 2>/dev/null
 $B --forward-only --n 16000000 > "$R/fps_16M.json" 2>/dev/null
 timeout 600 python tools/bench_regimes.py > "$R/regimes.jsonl" 2>/dev/null
 timeout 300 python tools/bench_train_iter.py > "$R/train_iteration.json" 2>/dev/null
+REAL=1 APPEARANCE=0 timeout 400 python tools/bench_train_iter.py 2>/dev/null | tail -1 > "$R/train_iteration_real_classes.json"     # the reference's own GaussianModel / render()
+REAL=1 timeout 400 python tools/bench_train_iter.py 2>/dev/null | tail -1 > "$R/train_iteration_real_classes_appearance.json"   # + --appearance_enabled (its MLP GEMMs: not this path's)
+timeout 400 python tools/prof_host.py 1000 100000 500000 2000000 2>/dev/null | grep "^N=" > "$R/host_floor.txt"
 timeout 300 python tools/bench_next_rows.py > "$R/next_rows.json" 2> "$R/next_rows.err"
 for f in "$R"/*.json "$R"/*.jsonl; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
