@@ -11,6 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "skyfall-gs_amd"), os.path.join(ROOT, "tests"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    # No test of this suite takes more than a few minutes. A hang (round 6: a rank-0-only block of bench.py that issued
+    # collectives the other ranks never matched) must cost ONE test its verdict, not the whole GPU session its budget:
+    # with pytest-timeout installed (this image), every test gets a ceiling unless the command line sets its own.
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 1500
 
 
 def pytest_collection_modifyitems(config, items):
