@@ -8,6 +8,8 @@ tests/ref_real_driver.py executes render() + GaussianModel + a loop re-spelled f
                                                                                           /root/reference/train.py:79-348
     render_video.render_sets(dataset, iteration, pipeline, camera_path, load_from_checkpoints, ...)
                                                                                    /root/reference/render_video.py:172-272
+    create_fused_ply.py (as a script) -> render_video_from_ply.render_video_from_ply(ply_path, camera_path, ...)
+                                                      /root/reference/create_fused_ply.py, render_video_from_ply.py:318-393
 
 -- the functions, not restatements: with their Scene (scene/__init__.py:21-98 -> the "Satellite" loader
 scene/dataset_readers.py:360-570 on a scene this driver writes to disk: transforms_train/test.json, points3D.txt,
@@ -417,6 +419,40 @@ def main():
     assert os.path.isfile(vid) and len(os.listdir(os.path.join(model_dir, "video", f"ours_{K}", "path_frames"))) == 6
     print(json.dumps({"stage": "render_sets", "frames": 6, "seconds": round(dt, 1), "mean": round(float(fr.mean()), 4),
                       "std": round(float(fr.std()), 4)}), flush=True)
+    # ---- 4. create_fused_ply.py (a script: run as __main__) + render_video_from_ply.render_video_from_ply() -----------------
+    # the reference's inference chain: bake the 3D filter into a standard 3DGS PLY (scene/gaussian_model.py:438-481), detect its SH
+    # degree, load it (render_video_from_ply.py:169-280), compute_3D_filter over the path's cameras, render with IN-KERNEL SH
+    # (colour path B: shs = pc.get_features, gaussian_renderer/__init__.py:126-127)
+    import runpy
+    fused = os.path.join(a.work, "fused.ply")
+    argv_saved = sys.argv
+    sys.argv = ["create_fused_ply.py", "-m", model_dir, "--iteration", str(K), "--load_from_checkpoints", "--output_ply", fused, "--quiet"]
+    try:
+        script = os.path.join(ref, "create_fused_ply.py")
+        if os.path.isfile(script):
+            runpy.run_path(script, run_name="__main__")
+        else:                                          # staged archive: the script is a member of the zip
+            import zipfile
+            code = zipfile.ZipFile(ref).read("create_fused_ply.py").decode()
+            exec(compile(code, os.path.join(ref, "create_fused_ply.py"), "exec"), {"__name__": "__main__"})
+    finally:
+        sys.argv = argv_saved
+        sys.stdout = sys.__stdout__
+    assert os.path.isfile(fused) and os.path.getsize(fused) > 100 * run1[-1]["n"], "create_fused_ply.py wrote no PLY"
+    import render_video_from_ply as rvp
+    assert src(rvp).startswith(ref)
+    assert rvp.detect_sh_degree_from_ply(fused) == 1
+    del FRAMES[:]
+    t0 = time.perf_counter()
+    rvp.render_video_from_ply(fused, cam_path, output_path=os.path.join(a.work, "from_ply"), save_images=True, kernel_size=0.1)
+    dt = time.perf_counter() - t0
+    fr2 = np.stack(FRAMES)
+    assert fr2.shape == (6, H, W, 3) and np.isfinite(fr2).all() and fr2.std() > 0.02
+    # the same model through the other colour path and a re-derived 3D filter: the same picture up to the filter's change
+    diff = float(np.abs(fr2 - fr).mean())
+    assert diff < 0.05, f"frames from the fused PLY differ from the checkpoint's by {diff:.3f} on average"
+    print(json.dumps({"stage": "fused_ply_video", "frames": 6, "seconds": round(dt, 1), "ply_bytes": os.path.getsize(fused),
+                      "mean_abs_diff_to_checkpoint_frames": round(diff, 4)}), flush=True)
     print("REF-ENTRY OK", flush=True)
     return 0
 
