@@ -10,6 +10,7 @@ tests/ref_real_driver.py executes render() + GaussianModel + a loop re-spelled f
                                                                                    /root/reference/render_video.py:172-272
     create_fused_ply.py (as a script) -> render_video_from_ply.render_video_from_ply(ply_path, camera_path, ...)
                                                       /root/reference/create_fused_ply.py, render_video_from_ply.py:318-393
+    train.generate_pseudo_cams(...) + train.render_idu_set(...)   the IDU stage's orbit cameras   /root/reference/train.py:350-357,528-577
 
 -- the functions, not restatements: with their Scene (scene/__init__.py:21-98 -> the "Satellite" loader
 scene/dataset_readers.py:360-570 on a scene this driver writes to disk: transforms_train/test.json, points3D.txt,
@@ -453,6 +454,27 @@ def main():
     assert diff < 0.05, f"frames from the fused PLY differ from the checkpoint's by {diff:.3f} on average"
     print(json.dumps({"stage": "fused_ply_video", "frames": 6, "seconds": round(dt, 1), "ply_bytes": os.path.getsize(fused),
                       "mean_abs_diff_to_checkpoint_frames": round(diff, 4)}), flush=True)
+    # ---- 5. the IDU stage's pseudo cameras through the reference's own functions --------------------------------------------
+    # train.generate_pseudo_cams() (train.py:528-577 -> utils.camera_utils.gen_idu_orbit_camera: orbit cameras at a given
+    # elevation, radius 300, 1024 x 1024, fov 60) and train.render_idu_set() (train.py:350-357) on the trained model: the views
+    # the IDU episodes render (elevations 85 ... 45, 25 in one schedule: arguments/__init__.py:238-249)
+    import random
+    random.seed(3); torch.manual_seed(3)
+    g = GaussianModel(1, False, 4, 32)
+    ckpt, _ = torch.load(os.path.join(model_dir, f"chkpnt{K}.pth"), **({} if a.backend == "hip" else {"map_location": "cpu"}))
+    g.load_from_checkpoints(ckpt)
+    g.load_ply(os.path.join(model_dir, "point_cloud", f"iteration_{K}", "point_cloud.ply"))
+    lp, op, pp = parse([])
+    bg = torch.tensor([0, 0, 0], dtype=torch.float32, device="cuda")
+    stats = {}
+    for elev in (80.0, 45.0, 25.0):
+        views = train.generate_pseudo_cams(lp, 4, 3, elevation=elev, radius=300.0, target_std=16.0)
+        sys.stdout = sys.__stdout__
+        t0 = time.perf_counter()
+        imgs = np.stack(train.render_idu_set(views, g, pp, bg, lp.kernel_size))
+        stats[str(int(elev))] = {"ms_per_view": round((time.perf_counter() - t0) / len(views) * 1e3, 2), "mean": round(float(imgs.mean()), 4)}
+        assert imgs.shape == (4, 1024, 1024, 3) and np.isfinite(imgs).all() and imgs.std() > 0.01, (elev, imgs.shape, float(imgs.std()))
+    print(json.dumps({"stage": "idu_pseudo_cameras", "views_per_elevation": 4, "size": [1024, 1024], "by_elevation": stats}), flush=True)
     print("REF-ENTRY OK", flush=True)
     return 0
 

@@ -13,6 +13,8 @@ Satellite-format scene (3 + 1 cameras, 20 000 points, depth maps) to tmp_path an
   render_video_from_ply.render_video_from_ply(...)  detects the PLY's SH degree, loads it, compute_3D_filter over the path's
                                  cameras, renders the same path with IN-KERNEL SH (colour path B) -- the same frames as the
                                  checkpoint's to < 0.05 mean absolute difference
+  train.generate_pseudo_cams(...) + train.render_idu_set(...)   the IDU stage's orbit cameras (elevation 80 / 45 / 25 degrees,
+                                 radius 300, 1024 x 1024, fov 60) rendered by the reference's own loop
 
 and asserts: one training_report per iteration, finite loss that falls by > 20 %, every iter_time > 0, the model size changes
 exactly at the densification, all files written, finite non-flat frames that move with the camera path. Once with the plain
@@ -55,6 +57,7 @@ def test_train_training_and_render_video_render_sets_run_unchanged(tmp_path, hoo
     assert tr["loss_last20"] < 0.8 * tr["loss_first20"]
     assert rows["restore"]["from"] == 150 and rows["render_sets"]["frames"] == 6
     assert rows["fused_ply_video"]["frames"] == 6 and rows["fused_ply_video"]["mean_abs_diff_to_checkpoint_frames"] < 0.05
+    assert set(rows["idu_pseudo_cameras"]["by_elevation"]) == {"80", "45", "25"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"reference_entry_{'hooks' if hooks else 'plain'}.json"), "w") as f:
         json.dump(rows, f)

@@ -18,5 +18,5 @@ def test_real_training_and_render_sets_run_on_the_oracle_double(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_entry_driver.py"), "--backend", "oracle", "--work",
                         str(tmp_path / "work"), "--iters", "60"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0 and "REF-ENTRY OK" in r.stdout, r.stdout[-3000:] + "\n--- stderr ---\n" + r.stderr[-3000:]
-    for stage in ('"stage": "training"', '"stage": "restore"', '"stage": "render_sets"', '"stage": "fused_ply_video"'):
+    for stage in ('"stage": "training"', '"stage": "restore"', '"stage": "render_sets"', '"stage": "fused_ply_video"', '"stage": "idu_pseudo_cameras"'):
         assert stage in r.stdout
