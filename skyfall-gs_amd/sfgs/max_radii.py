@@ -90,7 +90,17 @@ class MaskedMax(_Note):
         return torch.max(self.a.materialise(), self.b.materialise())
 
 
-class VisMask(torch.Tensor):
+class _PlainCopies:
+    """Copies and pickles of the two marked tensors are ordinary tensors (the marks describe one frame's objects, not data)."""
+
+    def __deepcopy__(self, memo):
+        return _plain(self).clone()
+
+    def __reduce_ex__(self, proto):
+        return _plain(self).__reduce_ex__(proto)
+
+
+class VisMask(_PlainCopies, torch.Tensor):
     """`radii > 0`: a real bool tensor that additionally recognises being used as the sole index of a tensor."""
 
     @classmethod
@@ -122,7 +132,7 @@ class VisMask(torch.Tensor):
         return _strip(out)
 
 
-class RadiiTensor(torch.Tensor):
+class RadiiTensor(_PlainCopies, torch.Tensor):
     """The rasterizer's `radii` [N] int32: an ordinary tensor whose `> 0` is a VisMask."""
 
     @classmethod

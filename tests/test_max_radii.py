@@ -81,6 +81,16 @@ def test_every_other_use_sees_ordinary_tensors(on):
     # radii: everything but `> 0` is plain
     assert type(r + 1) is torch.Tensor and type(r > 1) is torch.Tensor and type(r.float()) is torch.Tensor
     assert torch.equal(r[vf], radii[vf]) and int(r.max()) == int(radii.max())
+    # copies and pickles are ordinary tensors (a checkpoint or a deepcopy of render()'s result must not carry the marks)
+    import copy
+    import io
+    assert type(copy.deepcopy(r)) is torch.Tensor and type(copy.deepcopy(v)) is torch.Tensor and type(r.clone()) is torch.Tensor
+    buf = io.BytesIO()
+    torch.save({"r": r, "v": v}, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=True)
+    assert type(back["r"]) is torch.Tensor and torch.equal(back["r"], radii) and torch.equal(back["v"], vf)
+    assert r.numpy().tolist() == radii.tolist() and torch.equal(torch.where(v)[0], torch.where(vf)[0])
     # a mask of another length is not the pattern
     short = torch.zeros(7)
     assert torch.equal(short[mr.wrap_radii(torch.arange(7, dtype=torch.int32)) > 0], short[1:])
