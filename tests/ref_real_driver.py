@@ -160,24 +160,24 @@ def loss_fn(loss_utils, image, depth, cam, lambda_dssim=0.2, lambda_depth=0.5):
 
 # ---- hooks -------------------------------------------------------------------------------------------------------------
 def hook_modules():
-    from sfgs import adam, compact, densify, densify_stats, filter3d, max_radii, prepass, sh
-    return prepass, filter3d, densify_stats, adam, compact, densify, sh, max_radii
+    from sfgs import adam, appearance, compact, densify, densify_stats, filter3d, max_radii, prepass, sh
+    return prepass, filter3d, densify_stats, adam, compact, densify, sh, max_radii, appearance
 
 
 def install_all(GaussianModel, renderer):
-    prepass, filter3d, densify_stats, adam, compact, densify, sh, max_radii = hook_modules()
+    prepass, filter3d, densify_stats, adam, compact, densify, sh, max_radii, appearance = hook_modules()
     prepass.install(GaussianModel, fold=True)              # + sfgs.features (get_features) and sfgs.viewdirs (get_xyz)
-    for mod in (filter3d, densify_stats, adam, compact, max_radii):
+    for mod in (filter3d, densify_stats, adam, compact, max_radii, appearance):
         mod.install(GaussianModel)
     densify.install(GaussianModel)
     sh.install(renderer, fold=True)
 
 
 def uninstall_all(GaussianModel, renderer):
-    prepass, filter3d, densify_stats, adam, compact, densify, sh, max_radii = hook_modules()
+    prepass, filter3d, densify_stats, adam, compact, densify, sh, max_radii, appearance = hook_modules()
     sh.uninstall(renderer)
     densify.uninstall(GaussianModel)
-    for mod in (max_radii, compact, adam, densify_stats, filter3d):
+    for mod in (appearance, max_radii, compact, adam, densify_stats, filter3d):
         mod.uninstall(GaussianModel)
     prepass.uninstall(GaussianModel)
 

@@ -54,8 +54,9 @@ def install_hooks(gaussian_model_cls, fused=True, shared_mlp=False, zcurve_order
     if PKG not in sys.path:
         sys.path.insert(0, PKG)
     if fused:
-        from sfgs import adam, compact, densify, densify_stats, filter3d, max_radii, prepass
-        for mod in (prepass, filter3d, densify_stats, adam, compact, max_radii):   # max_radii: train.py:314 without its syncs
+        from sfgs import adam, appearance, compact, densify, densify_stats, filter3d, max_radii, prepass
+        # max_radii: train.py:314 without its syncs; appearance: the MLP's weight gradients as a split-K reduction (plain torch)
+        for mod in (prepass, filter3d, densify_stats, adam, compact, max_radii, appearance):
             mod.install(gaussian_model_cls)
         densify.install(gaussian_model_cls, zcurve_order=zcurve_order)   # optionally keeps the rows in Z-curve order
     if shared_mlp and not getattr(gaussian_model_cls, "_sfgs_shared_mlp", False):
