@@ -102,7 +102,7 @@ def real_reference():
                 for _ in range(5):
                     iteration()
                 torch.cuda.synchronize()
-            rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:18]
+            rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:int(os.environ.get('PROFILE_ROWS', '18'))]
             out["top_kernels_fused" if fused else "top_kernels_torch"] = [
                 [e.key[:70], round(e.device_time_total / 5 / 1e3, 3), e.count // 5] for e in rows if e.device_time_total > 0]
         if fused:
