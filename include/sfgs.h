@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFGS_ABI_VERSION 17
+#define SFGS_ABI_VERSION 18
 
 typedef enum SfgsStatus {
   SFGS_OK = 0,
@@ -185,7 +185,7 @@ typedef struct SfgsRasterSizes {
                             arrays, which only the render stage writes */
   size_t image_bytes;    /* f(W,H,D): per-pixel last contributor, final T, raw depth, and one 8-byte
                             blended-entries mask per pixel and 64-entry list batch (for backward) */
-  size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records (backward only)            */
+  size_t dupgrad_bytes;  /* f(D):   per-duplicate 2D gradient records + flags (backward only)    */
   int64_t coarse_bins;   /* number of 32x32-pixel coarse bins of this image (informational)      */
 } SfgsRasterSizes;
 
@@ -310,12 +310,14 @@ int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, const void* ge
 
 /* Backward of the two calls above. dL_dcolor[3,H,W], dL_ddepth[1,H,W], dL_dalpha[1,H,W] may each
  * be NULL (= zeros). Needs the forward's blobs (geom, tiles, bins with the same capacities, image)
- * and radii unchanged. `dupgrad` is scratch: 48 bytes for each duplicate INDEX of the plan -- the indices are handed out
- * from 8 disjoint ranges of [0, dup_capacity), so it spans the capacity, not the count
- * (sfgs_raster_sizes(N, W, H, dup_capacity, ..).dupgrad_bytes; the gaps are never touched). Every gradient tensor in `grads` is
- * fully overwritten. Deterministic (no float atomics). Asynchronous. Writes one word of the `tiles` header (whether
- * this frame's dead list entries were zero-filled in bulk; decided per frame on the device,
- * sfgs_set_option("prefill", "always" | "never") forces either path for tests: the gradients are bit-identical). */
+ * and radii unchanged. `dupgrad` is scratch: a 48-byte record and (ABI 18) a one-byte "record written" flag for each
+ * duplicate INDEX of the plan, plus one line of zeros -- the indices are handed out from 8 disjoint ranges of
+ * [0, dup_capacity), so it spans the capacity, not the count (ask sfgs_raster_sizes(N, W, H, dup_capacity, ..).dupgrad_bytes,
+ * do not compute it; the gaps are never touched; nothing in it need survive the call). Every gradient tensor in `grads` is
+ * fully overwritten. Deterministic (no float atomics). Asynchronous. Writes one word of the `tiles` header: whether this
+ * frame's dead list entries (behind their tile's last contributor) are skipped through the flags or receive zero records
+ * one by one; decided per frame on the device, sfgs_set_option("prefill", "always" | "never") forces either path for
+ * tests: the gradients are bit-identical. */
 int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians* g, const int32_t* radii,
                          const void* geom, const void* tiles, const void* bins, int64_t dup_capacity,
                          int64_t coarse_capacity, int64_t num_duplicates, const void* image, const float* dL_dcolor,

@@ -247,7 +247,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* _
                      const float* __restrict__ final_T, const float* __restrict__ dacc,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, const uint2* __restrict__ hitmask,
-                     const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad,
+                     const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad, uint8_t* __restrict__ live,
                      const unsigned long long* __restrict__ hdr, int not_prefilled) {
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[BWG_WAVES];
@@ -305,8 +305,9 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* _
   // three instructions) and the LDS stage is written with one contiguous ds_write_b128 (float4 index = lane)
   const int g_rec = lane / 3, g_piece = lane - 3 * g_rec;
   constexpr int BPG = 64 / B;   // batches per 64-entry hit-mask group
-  // list entries behind every pixel's last contributor receive zero gradient -- unless dupgrad_prefill_kernel found so
-  // many of them in this frame that it zeroed the whole record array with streaming stores instead
+  // list entries behind every pixel's last contributor receive zero gradient records -- unless dupgrad_prefill_kernel
+  // found so many of them in this frame that it switched the frame to LIVE FLAGS (sfgs_internal.h: prefill_wanted): it
+  // cleared `live`, this kernel sets the byte of every record it writes, and the readers skip the others
   // (not_prefilled: the caller did not launch the prefill kernel for THIS backward -- the header word may still hold the
   // decision of an earlier backward over the same forward state, e.g. retain_graph)
   const bool zero_dead = not_prefilled || prefilled == 0u;
@@ -395,6 +396,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* _
         v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
         *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
       }
+      if (!zero_dead && orow == 0) live[p_dup] = 1;   // (wave-uniform branch; 16 byte stores per batch in live-flag frames only)
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -521,6 +523,7 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* _
       v3f v; v.x = pq0; v.y = pq1; v.z = pq2;
       *reinterpret_cast<v3f*>(reinterpret_cast<float*>(dupgrad) + (size_t)p_dup * 12 + 3 * orow) = v;
     }
+    if (!zero_dead && orow == 0) live[p_dup] = 1;
   }
   // the dead entries' zero records, last: nothing waits for these stores (their duplicate indices arrived with round B)
   if (zero_dead) {
@@ -542,10 +545,10 @@ void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8,
                           const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
                           const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
                           const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,
-                          float4* dupgrad, const unsigned long long* hdr, int not_prefilled) {
+                          float4* dupgrad, uint8_t* live, const unsigned long long* hdr, int not_prefilled) {
   hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(grid), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX, SY, tile_range,
                      sorted_id, sorted_dup, rec, n_contrib, final_T, dacc, dL_dcolor, dL_ddepth, dL_dalpha, hitmask, tile_kmax,
-                     dupgrad, hdr, not_prefilled);
+                     dupgrad, live, hdr, not_prefilled);
 }
 
 }  // namespace sfgs

@@ -18,16 +18,23 @@
 
 namespace sfgs {
 
-// Dead list entries -- behind their tile's last contributor: opaque surfaces seen at a low angle leave a third to a
-// half of every list dead, near-camera overdraw 95 % -- still own a gradient record that preprocess_bwd adds up, so it
-// has to read zero. One scattered 48-byte store per dead entry costs ~38 ps (near-camera regime: 4.4 of 4.8 ms of
-// composite_bwd); zeroing the WHOLE array with streaming stores costs ~10 ps per entry, dead or alive. The training
-// forward leaves every tile's dead-entry count (tile_dead); this kernel sums them, fills when prefill_wanted() says
-// so, and publishes the decision in hdr[HDR_PREFILLED] for composite_bwd, which then skips its zero records.
+// Dead list entries -- behind their tile's last contributor: opaque surfaces seen at a low angle leave a third to four
+// fifths of every list dead, near-camera overdraw 95 % -- own a gradient record like every other entry, and preprocess_bwd
+// adds up a Gaussian's records. Three ways to make a dead record read as zero, in the order they were built:
+//   * composite_bwd stores a zero record per dead entry: ~38 ps each (near-camera regime: 4.4 of 4.8 ms of composite_bwd);
+//   * (rounds 2 - 5) zero the WHOLE record array with streaming stores when more than 30 % are dead: ~10 ps per entry, dead
+//     or alive -- and preprocess_bwd still READS all of it (low elevation, 2 M Gaussians: 79 % of 17.4 M entries dead,
+//     0.83 GB written and 0.83 GB read back for nothing);
+//   * (round 6) LIVE FLAGS: one byte per duplicate index behind the records. This kernel clears the bytes (1 / 48 of the
+//     array), composite_bwd sets the byte of every record it writes and writes nothing for the dead, and the readers
+//     (dupgrad_reduce_kernel, preprocess_bwd) fetch a record only where the byte is set -- everything else is read from
+//     one line of zeros. Sums are bit-identical: the skipped addends were +0.
+// The training forward leaves every tile's dead-entry count (tile_dead); this kernel sums them, decides
+// (prefill_wanted), and publishes the decision in hdr[HDR_PREFILLED] for the three kernels behind it.
 // (On the headline scene 0.1 % are dead: the kernel returns after the sum.)
 __global__ void __launch_bounds__(256)
 dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned long long n_dup, int mode,
-                       float4* __restrict__ dupgrad, unsigned long long* __restrict__ hdr,
+                       uint4* __restrict__ live16, uint4* __restrict__ zero_line, unsigned long long* __restrict__ hdr,
                        unsigned long long* __restrict__ feedback, const unsigned long long* __restrict__ dup_pool,
                        unsigned long long dup_capacity, unsigned npools) {
   __shared__ unsigned part[4];
@@ -56,12 +63,15 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
     if (feedback) feedback[FB_PREFILLED] = fill ? 1ull : 0ull;   // for the next frame's plan (SfgsFrame.feedback)
   }
   if (!fill) return;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && threadIdx.x < 16) zero_line[threadIdx.x] = zero4;
   const unsigned long long R = dup_capacity / npools;   // the used part of every pool's index range (sfgs_internal.h)
   for (unsigned q = 0; q < npools; ++q) {
-    const size_t n4 = (size_t)min(dup_pool[q * DP_STRIDE], R) * DG_F4;
-    float4* dst = dupgrad + (size_t)q * R * DG_F4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = zero4;
+    // whole 16-byte words around the pool's used byte range (a word shared with the next pool's range is cleared twice:
+    // every flag of a used range starts at zero, the gaps are never read)
+    const unsigned long long b0 = (unsigned long long)q * R, b1 = b0 + min(dup_pool[q * DP_STRIDE], R);
+    const size_t w0 = (size_t)(b0 / 16), w1 = (size_t)((b1 + 15) / 16);
+    for (size_t i = w0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < w1; i += (size_t)gridDim.x * 256) live16[i] = zero4;
   }
 }
 
@@ -69,10 +79,12 @@ dupgrad_prefill_kernel(int T8, const uint16_t* __restrict__ tile_dead, unsigned 
 // workgroup per 1024-record chunk sums the chunk in a fixed order and overwrites the chunk's FIRST record with the sum.
 __global__ void __launch_bounds__(256)
 dupgrad_reduce_kernel(const unsigned long long* __restrict__ hdr, const uint2* __restrict__ big_chunks,
-                      unsigned chunk_cap, const uint2* __restrict__ dup, float4* __restrict__ dupgrad) {
+                      unsigned chunk_cap, const uint2* __restrict__ dup, float4* __restrict__ dupgrad,
+                      const uint8_t* __restrict__ live) {
   constexpr int NF = DUPGRAD_FLOATS;   // every float of the record is summed in place (padding floats are zeros)
   __shared__ float part[4][NF];
   const unsigned n_chunks = (unsigned)min(hdr[HDR_BIG_CHUNKS], (unsigned long long)chunk_cap);
+  const bool flags = live != nullptr && hdr[HDR_PREFILLED] != 0ull;   // live-flag frame: unflagged records hold garbage
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (unsigned j = blockIdx.x; j < n_chunks; j += gridDim.x) {
     const uint2 gc = big_chunks[j];
@@ -83,7 +95,17 @@ dupgrad_reduce_kernel(const unsigned long long* __restrict__ hdr, const uint2* _
     float v[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) v[i] = 0.f;
-    for (unsigned i = threadIdx.x; i < n; i += 256) {
+    static_assert(BWD_CHUNK == 4 * 256, "four records per thread");
+    bool take[4];   // (the four flags of a thread in flight together, then the records of the flagged ones)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned i = threadIdx.x + 256u * j;
+      take[j] = i < n && (!flags || live[d0 + min(i, n - 1u)] != 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!take[j]) continue;
+      const unsigned i = threadIdx.x + 256u * j;
 #pragma unroll
       for (int q = 0; q < DG_F4; ++q) {
         const float4 x = dupgrad[(d0 + i) * DG_F4 + q];
@@ -147,7 +169,8 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
                       int raw_mask, const float* __restrict__ shs, const float* __restrict__ shs_rest,
                       const float* __restrict__ sh_dirs, int dirs_are_centers,
                       const int* __restrict__ radii,
-                      const uint2* __restrict__ dup, const float4* __restrict__ dupgrad,
+                      const uint2* __restrict__ dup, const float4* __restrict__ dupgrad, const uint8_t* __restrict__ live,
+                      size_t zero_f4, const unsigned long long* __restrict__ hdr,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_scales,
                       float* __restrict__ g_rots, void* __restrict__ g_opac_, float* __restrict__ g_colors,
                       float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_sh_dirs) {
@@ -167,6 +190,9 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
   const bool vis = valid && radii[g] > 0;
   unsigned d0 = 0, cnt = 0;
   if (vis) { const uint2 dr = dup[g]; d0 = dr.x; cnt = dr.y; }
+  // live-flag frame (dupgrad_prefill_kernel above): a record is fetched only where its flag is set; the others read
+  // float4 `zero_f4` of the blob, a line of zeros (all the lanes of a dead stretch share ONE request)
+  const bool flags = live != nullptr && hdr[HDR_PREFILLED] != 0ull;
   DupAcc acc;
   acc.zero();
   if (cnt > BWD_BIG) {   // pre-reduced by dupgrad_reduce_kernel: add the chunk heads (<= a few dozen)
@@ -196,8 +222,22 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
       // vmcnt(0) behind it: six serialised round trips to memory per chunk -- found by reading the ISA, round 3.)
       constexpr int NLD = PB_CHUNK * DG_F4 / 64;
       float4 tmp[NLD];
+      size_t src[NLD];   // float4 index of this lane's k-th piece
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) tmp[k] = dupgrad[(size_t)c0 * DG_F4 + min((unsigned)(k * 64 + lane), n4 - 1u)];
+      for (int k = 0; k < NLD; ++k) src[k] = (size_t)c0 * DG_F4 + min((unsigned)(k * 64 + lane), n4 - 1u);
+      if (flags) {   // (wave-uniform. The flag loads and the selects live in this block, the record loads below are common
+                     // to both kinds of frame: with two sets of loads the compiler moved `tmp` to scratch memory)
+        static_assert(DG_F4 == 3, "piece -> record: u / 3");
+        unsigned char lv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) lv[k] = live[(size_t)c0 + min((unsigned)(k * 64 + lane), n4 - 1u) / 3u];
+        unsigned any = 0;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { src[k] = lv[k] ? src[k] : zero_f4; any |= lv[k]; }
+        if (__ballot(any != 0u) == 0ull) continue;   // a stretch without a single record: nothing to fetch, nothing to add
+      }
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) tmp[k] = dupgrad[src[k]];
 #pragma unroll
       for (int k = 0; k < NLD; ++k) stage[k * 64 + lane] = tmp[k];   // unconditional too (the stage holds PB_CHUNK records;
                                                                      // its tail beyond n4 is never read): a predicated
@@ -217,7 +257,26 @@ preprocess_bwd_kernel(KFrame kf, int N, const float* __restrict__ means3D, const
     const unsigned b0 = (unsigned)__shfl((int)d0, src), bn = (unsigned)__shfl((int)cnt, src);
     DupAcc w;
     w.zero();
-    for (unsigned i = lane; i < bn; i += 64) w.add(dupgrad + (size_t)(b0 + i) * DG_F4);
+    if (flags) {   // four flags per lane and round trip; a round without a record (big splats are dead over whole regions of
+                   // the image) is skipped, the others fetch under the flags
+      constexpr int U = 4;
+      for (unsigned r = 0; r < bn; r += 64 * U) {
+        bool lv[U];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const unsigned i = r + 64u * j + lane;
+          lv[j] = live[(size_t)b0 + min(i, bn - 1u)] != 0 && i < bn;
+          any |= lv[j];
+        }
+        if (__ballot(any) == 0ull) continue;
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+          if (lv[j]) w.add(dupgrad + (size_t)(b0 + r + 64u * j + lane) * DG_F4);
+      }
+    } else {
+      for (unsigned i = lane; i < bn; i += 64) w.add(dupgrad + (size_t)(b0 + i) * DG_F4);
+    }
 #pragma unroll
     for (int i = 0; i < DG_F4; ++i) {
 #pragma unroll
@@ -366,28 +425,34 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
   const int TX8 = (W + TILE_BIN - 1) / TILE_BIN, TY8 = (H + TILE_BIN - 1) / TILE_BIN;
   constexpr int BE = composite_block_edge<BWG_WAVES>();
   const int SX = (TX8 + BE - 1) / BE, SY = (TY8 + BE - 1) / BE;
+  // the live flags behind the records (sfgs_internal.h: dupgrad_bytes). Without the prefill kernel its decision word keeps
+  // the plan's zero -- or an EARLIER backward's decision over the same forward state: the readers then get no flag pointer
+  // and composite_bwd writes the zero records itself
+  const bool no_prefill = (frame->launch_hints & SFGS_HINT_NO_PREFILL) != 0;
+  uint8_t* live = (uint8_t*)dupgrad + dupgrad_flags_offset(dup_capacity);
+  const uint8_t* live_r = no_prefill ? nullptr : live;
+  const size_t zero_f4 = dupgrad_zero_offset(dup_capacity) / 16;
   { ProfScope ps_(KID_COMPOSITE_BWD, stream);
-    // (without the prefill kernel its decision word keeps the plan's zero: composite_bwd writes the zero records itself)
-    if (!(frame->launch_hints & SFGS_HINT_NO_PREFILL))
+    if (!no_prefill)
     hipLaunchKernelGGL(dupgrad_prefill_kernel, dim3(512), dim3(256), 0, stream, TX8 * TY8, iv.tile_dead,
-                       (unsigned long long)num_duplicates, prefill_mode(), (float4*)dupgrad, tv.hdr,
+                       (unsigned long long)num_duplicates, prefill_mode(), (uint4*)live, (uint4*)((char*)dupgrad + dupgrad_zero_offset(dup_capacity)), tv.hdr,
                        (unsigned long long*)frame->feedback, (const unsigned long long*)tv.dup_pool,
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
     launch_composite_bwd(composite_grid(SX, SY, BE * BE / BWG_WAVES), stream, kf, TX8, TY8, SX, SY, tv.tile_range, bv.sorted_id,
                          bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth, dL_dalpha, iv.hitmask,
-                         iv.tile_kmax, (float4*)dupgrad, tv.hdr, (frame->launch_hints & SFGS_HINT_NO_PREFILL) ? 1 : 0);
+                         iv.tile_kmax, (float4*)dupgrad, live, tv.hdr, no_prefill ? 1 : 0);
   }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);
   { ProfScope ps_(KID_PREPROCESS_BWD, stream);
     if (!(frame->launch_hints & SFGS_HINT_NO_BIG_CHUNKS))   // the caller read num_big_chunks == 0 from this frame's plan
     hipLaunchKernelGGL(dupgrad_reduce_kernel, dim3(1024), dim3(256), 0, stream, tv.hdr, bv.big_chunks,
-                       (unsigned)big_chunk_capacity(dup_capacity), gv.dup, (float4*)dupgrad);
+                       (unsigned)big_chunk_capacity(dup_capacity), gv.dup, (float4*)dupgrad, live_r);
 #define SFGS_LAUNCH_PBWD_(K, D, RAW, CM)                                                                               \
   hipLaunchKernelGGL((preprocess_bwd_kernel<K, D, RAW, CM>), dim3(NB), dim3(PRE_BLOCK), 0, stream, kf, N, g->means3D,  \
                      g->scales, g->rotations, (const void*)g->opacities, g->filter_3D, (int)g->raw_f64_mask, g->shs,   \
                      g->shs_rest, g->sh_dirs ? g->sh_dirs : g->sh_centers, g->sh_centers ? 1 : 0, radii, gv.dup,       \
-                     (const float4*)dupgrad, grads->means3D, grads->means2D,                                           \
+                     (const float4*)dupgrad, live_r, zero_f4, tv.hdr, grads->means3D, grads->means2D,                  \
                      grads->scales, grads->rotations, (void*)grads->opacities, grads->colors_precomp, grads->shs,      \
                      grads->shs_rest, grads->sh_dirs)
 #define SFGS_LAUNCH_PBWD(K, D)                                                                                         \

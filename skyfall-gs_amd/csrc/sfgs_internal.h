@@ -341,8 +341,9 @@ static inline ImageView image_view(void* base, int W, int H, int64_t D) {
   return v;
 }
 
-// Backward: do the dead entries make up more than 30 % of the frame's duplicates? Then dupgrad_prefill_kernel zeroes
-// the whole record array with streaming stores and composite_bwd skips its per-entry zero records.
+// Backward: do the dead entries make up more than 30 % of the frame's duplicates? Then the frame runs in LIVE-FLAG mode:
+// dupgrad_prefill_kernel clears one byte per duplicate index, composite_bwd sets the byte of every record it writes and
+// writes nothing for the dead entries, and the readers (dupgrad_reduce_kernel, preprocess_bwd) fetch only flagged records.
 __host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned long long n_dup) { return dead * 10ull > n_dup * 3ull; }
 
 // per-duplicate gradient record. DG_F4 = 3: 48 bytes, floats in Grad2D order. 4: 64 bytes, float 3 k + r of the
@@ -350,7 +351,10 @@ __host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned
 // 16-byte quarter and the four lanes of an entry write a full 64-byte sector with ONE store instruction
 constexpr int DG_F4 = 3;
 constexpr int DUPGRAD_FLOATS = 4 * DG_F4;
-static inline size_t dupgrad_bytes(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
+// the backward's scratch blob: [D records][D live flags, one byte each][one line of zeros (what a dead record reads as)]
+static inline size_t dupgrad_flags_offset(int64_t D) { return align_up((size_t)D * DUPGRAD_FLOATS * 4, 256); }
+static inline size_t dupgrad_zero_offset(int64_t D) { return dupgrad_flags_offset(D) + align_up((size_t)D, 256); }
+static inline size_t dupgrad_bytes(int64_t D) { return dupgrad_zero_offset(D) + 256; }
 
 // pools in use for a frame of NB preprocess workgroups: small frames (few workgroups: their totals would not spread evenly
 // over the pools) draw from one pool that owns the whole index space
@@ -554,6 +558,6 @@ void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8,
                           const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
                           const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
                           const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,
-                          float4* dupgrad, const unsigned long long* hdr, int not_prefilled);
+                          float4* dupgrad, uint8_t* live, const unsigned long long* hdr, int not_prefilled);
 
 }  // namespace sfgs

@@ -114,16 +114,6 @@ def _zero(dev):
     return z
 
 
-def _dupgrad_record_bytes(lib):
-    """bytes of one per-duplicate gradient record, as the library lays them out (asked once through the C ABI)."""
-    b = _stats.get("dupgrad_record_bytes")
-    if b is None:
-        sizes = L.SfgsRasterSizes(C_sizeof(L.SfgsRasterSizes))
-        L.check(lib.sfgs_raster_sizes(1, 8, 8, 1024, 256, L.C.byref(sizes)))
-        b = _stats["dupgrad_record_bytes"] = int(sizes.dupgrad_bytes) // 1024
-    return b
-
-
 def _pinned_counters(dev, raw_stream):
     """This thread's (pinned counter buffer, event, buffer address, raw event handle, decoded-counters struct) for
     (device, stream): frames on different streams or from different host threads never share one."""
@@ -416,7 +406,7 @@ class _Rasterize(torch.autograd.Function):
             global _last_counters
             _last_counters = dict(num_duplicates=D, num_duplicates_ref=int(cnt.num_duplicates_ref),
                                   num_visible=int(cnt.num_visible), max_coarse_bin=cmax, max_bin_items=int(cnt.max_bin_items),
-                                  num_huge_splats=int(cnt.num_huge_splats), plan_attempts=attempts,
+                                  num_huge_splats=int(cnt.num_huge_splats), num_big_chunks=int(cnt.num_big_chunks), plan_attempts=attempts,
                                   max_tile_list=int(cnt.max_tile_list), N=N, W=W, H=H, dup_capacity=cap,
                                   coarse_capacity=ccap, fwd_hints=int(fwd_hints))   # published by reference assignment (atomic)
         finally:

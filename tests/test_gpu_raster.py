@@ -320,20 +320,36 @@ def test_random_configurations(i):
                                  mx=parity.GRAD_RTOL_MAX * scale * few * (6.0 if flipped else 1.0))
 
 
-def test_dead_entry_prefill_paths_bit_identical(sfgs_option):
-    """Entries behind a tile's last contributor get zero gradient records either one by one (composite_bwd) or from the
-    streaming prefill (dupgrad_prefill_kernel, chosen per frame on the device when > 30 % are dead). Both forced in
-    turn: every gradient must come out bit-identical, and identical to the automatic choice."""
-    frame, g = scene(400, 256, 192, seed=11, zrange=(3., 6.), scale_range=(0.3, 2.0))   # heavy overdraw: most entries dead
-    gc, gd = upstream_grads(256, 192, 3)
+@pytest.mark.parametrize("case", ["overdraw_256x192", "screen_filling_640x480", "mixed_sizes_512x384"])
+def test_dead_entry_prefill_paths_bit_identical(sfgs_option, case):
+    """Entries behind a tile's last contributor either get zero gradient records one by one (composite_bwd) or are skipped
+    through the live flags (dupgrad_prefill_kernel clears one byte per duplicate, composite_bwd sets the byte of every record
+    it writes, dupgrad_reduce_kernel / preprocess_bwd fetch flagged records only; chosen per frame on the device when > 30 %
+    are dead). Both forced in turn: every gradient must come out bit-identical, and identical to the automatic choice.
+    The three scenes put Gaussians on each summation route of preprocess_bwd: <= 32 records (streamed through LDS), 33 .. 2048
+    (the wave strides over them), > 2048 (pre-reduced chunks: `num_big_chunks` of the forward's counters)."""
+    if case == "overdraw_256x192":      # heavy overdraw: most entries dead
+        W, H = 256, 192
+        frame, g = scene(400, W, H, seed=11, zrange=(3., 6.), scale_range=(0.3, 2.0))
+    elif case == "screen_filling_640x480":   # 4800 tiles, splats that cover most of them: > 2048 records per Gaussian
+        W, H = 640, 480
+        frame, g = scene(60, W, H, seed=12, zrange=(3., 6.), scale_range=(1.5, 4.0), opacity_range=(0.5, 0.95))
+    else:                               # small splats in front of big ones: all three routes in one frame
+        W, H = 512, 384
+        frame, g = scene(3000, W, H, seed=13, zrange=(3., 60.), scale_range=(0.02, 3.0), opacity_range=(0.3, 0.95))
+    gc, gd = upstream_grads(W, H, 3)
     outs = {}
     for mode in ("always", "never", ""):
         sfgs_option("prefill", mode or "auto")
-        outs[mode] = run_hip(frame, g, gc, gd)["grads"]
-    for k in outs["always"]:
-        np.testing.assert_array_equal(outs["always"][k], outs["never"][k], err_msg=k)
-        np.testing.assert_array_equal(outs["always"][k], outs[""][k], err_msg=k)
-    assert np.abs(outs["always"]["means3D"]).max() > 0
+        outs[mode] = run_hip(frame, g, gc, gd)
+    a = outs["always"]["grads"]
+    for k in a:
+        np.testing.assert_array_equal(a[k], outs["never"]["grads"][k], err_msg=k)
+        np.testing.assert_array_equal(a[k], outs[""]["grads"][k], err_msg=k)
+        assert np.isfinite(a[k]).all(), k     # an unflagged record is uninitialised memory: it must never be read
+    assert np.abs(a["means3D"]).max() > 0
+    big = outs["always"]["counters"]["num_big_chunks"]
+    assert (big > 0) == (case != "overdraw_256x192"), (case, big)
 
 
 def test_storage_order_is_a_relabelling():

@@ -99,7 +99,8 @@ def test_gpu_free_entry_points_and_error_convention():
     assert lib.sfgs_raster_sizes(2_000_000, 1920, 1080, 7_000_000, 8192, C.byref(sizes)) == 0
     assert sizes.geom_bytes >= 2_000_000 * 56 and sizes.bins_bytes >= 7_000_000 * 24 + sizes.coarse_bins * 8192 * 16
     assert sizes.coarse_bins == 60 * 34
-    assert sizes.dupgrad_bytes == 7_000_000 * 48 and sizes.image_bytes >= 1920 * 1080 * 12
+    # 48-byte records, one flag byte per duplicate index (256-byte aligned regions), one line of zeros
+    assert sizes.dupgrad_bytes == 7_000_000 * 48 + (7_000_000 + 255) // 256 * 256 + 256 and sizes.image_bytes >= 1920 * 1080 * 12
     # errors: negative status + thread-local message, never an exception or exit
     bad = L.SfgsRasterSizes(4)
     assert lib.sfgs_raster_sizes(10, 64, 64, 0, 0, C.byref(bad)) == -1

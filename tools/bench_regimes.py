@@ -36,6 +36,8 @@ REGIMES = {
 }
 dev = torch.device("cuda:0")
 only = sys.argv[1:]
+for kv in filter(None, os.environ.get("SFGS_OPTIONS", "").split(",")):   # route options for A/B runs, e.g. SFGS_OPTIONS=prefill=always
+    L.set_option(*kv.split("="))
 for name, c in REGIMES.items():
     if only and name not in only:
         continue

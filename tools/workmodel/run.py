@@ -29,8 +29,8 @@ def main():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", SO,
                            os.path.join(HERE, "workmodel.cpp")])
     lib = C.CDLL(SO)
-    kw = dict(pitch_deg=a.pitch, zrange=(0.0, 40.0)) if a.pitch else {}
-    frame, g = scene(a.n, a.width, a.height, seed=0)
+    kw = dict(pitch_deg=a.pitch, zrange=(40.0, 400.0)) if a.pitch else {}   # --pitch 45: tools/bench_regimes.py's low elevation
+    frame, g = scene(a.n, a.width, a.height, seed=0, **kw)
     f32 = lambda t: np.ascontiguousarray(t.numpy(), np.float32)
     keep = [f32(frame[k]) for k in ("bg", "view", "proj", "campos")]
     fr = WmFrame(a.width, a.height, frame["tanfovx"], frame["tanfovy"], frame["kernel_size"], 1.0,
