@@ -37,6 +37,11 @@ def _frames():
     return out
 
 
+def diff_gauss_last_backward_hints():
+    import diff_gauss
+    return diff_gauss.last_backward_hints()
+
+
 def _run(frames, reps):
     from diff_gauss import GaussianRasterizationSettings, GaussianRasterizer, last_counters
     dev = torch.device("cuda:0")
@@ -61,6 +66,7 @@ def _run(frames, reps):
                        radii=radii.cpu().numpy(), m2=m2.grad.cpu().numpy(),
                        **{"g_" + k: v.grad.cpu().numpy() for k, v in t.items()})
             rec["counters"] = last_counters()
+            rec["bwd_hints"] = diff_gauss_last_backward_hints()
             res.append(rec)
     return res
 
@@ -86,7 +92,7 @@ def test_hints_never_change_a_result(monkeypatch):
     assert state["fb"] is not None and int(state["fb"][0]) == 1 and state["huge"] == 0
     for a, b in zip(ref, got):
         for k in a:
-            if k in ("name", "counters"):
+            if k in ("name", "counters", "bwd_hints"):
                 continue
             np.testing.assert_array_equal(np.nan_to_num(a[k], nan=-1.0), np.nan_to_num(b[k], nan=-1.0),
                                           err_msg=f"{a['name']}: {k}")
@@ -113,6 +119,44 @@ def test_huge_splat_hint_waits_for_a_quiet_period(monkeypatch):
     # frame 0: nothing known; 1: calm after calm -> hinted; 2: the huge frame was planned WITH the hint, found out, redone
     # without it; 3 .. 7: quiet period (re-armed by frame 4); 8: three calm frames (5, 6, 7) later the hint is back
     assert hinted == [False, True, False, False, False, False, False, False, True, True], hinted
+
+
+def test_dead_entry_kernel_stays_in_while_some_views_need_it(monkeypatch):
+    """The backward's dupgrad_prefill_kernel decides per frame, on the device, whether the frame runs on live flags; the
+    wrapper skips its launch (NO_PREFILL) only after PREFILL_QUIET "no"s in a row -- a view that needs the flags and is not
+    given them costs 30 % (profiles/r6_live_flags_ab.txt), the kernel 3 us -- and then probes every PREFILL_PROBE_EVERY-th
+    backward. A view full of dead entries (screen-filling splats: a pixel saturates after a dozen of its 3 000 entries) between
+    calm ones keeps the kernel in for the calm views that follow."""
+    import diff_gauss
+    from diff_gauss import HINT_NO_PREFILL
+    monkeypatch.setattr(diff_gauss, "PREFILL_QUIET", 3)
+    monkeypatch.setattr(diff_gauss, "PREFILL_PROBE_EVERY", 1000)
+    fr = {n: (f, g) for n, f, g in _frames()}
+    calm, city = ("calm",) + fr["calm"], ("huge_splats",) + fr["huge_splats"]
+    diff_gauss._hint_state.clear()
+    res = _run([calm, calm, calm, city, calm, city, calm, calm, calm, calm, calm], 1)
+    skipped = [bool(r["bwd_hints"] & HINT_NO_PREFILL) for r in res]
+    # backward 0: nothing known, launched (state 1 -> 0 is seen by the NEXT forward's plan); 1, 2: hinted away. The probe
+    # interval is out of reach here, so the heavy view of backward 3 runs without the kernel -- and nothing learns from it.
+    assert skipped[:4] == [False, True, True, True], skipped
+    # ... which is why the default probes every 32nd backward. Now with a probe at every backward:
+    monkeypatch.setattr(diff_gauss, "PREFILL_PROBE_EVERY", 1)
+    diff_gauss._hint_state.clear()
+    res = _run([calm, calm, city, calm, city, calm, calm, calm, calm, calm], 1)
+    state = [r["bwd_hints"] & HINT_NO_PREFILL for r in res]
+    assert not any(state), state    # probing every backward = always launched
+    hs = next(iter(diff_gauss._hint_state.values()))
+    # after the last heavy view (backward 4) five calm ones said no; the last one's answer arrives with the next plan:
+    # 3 -> 2 -> 1 -> 0 -> 0
+    assert hs["prefilled"] == 0, hs["prefilled"]
+    # the quiet period itself: a "yes" re-arms it
+    monkeypatch.setattr(diff_gauss, "PREFILL_PROBE_EVERY", 1000)
+    diff_gauss._hint_state.clear()
+    res = _run([city, calm, calm, calm, calm, calm, calm], 1)
+    skipped = [bool(r["bwd_hints"] & HINT_NO_PREFILL) for r in res]
+    # 0: launched, says yes (state 3, known from plan 1 on); 1, 2, 3: launched, "no" x 3 -> 2, 1, 0 (known from plans 2, 3, 4);
+    # backward 4 onwards: hinted away
+    assert skipped == [False, False, False, False, True, True, True], skipped
 
 
 def test_capacities_shrink_slowly_so_alternating_views_plan_once():

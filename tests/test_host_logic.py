@@ -189,6 +189,13 @@ def test_capacity_and_huge_splat_hints_follow_their_rules():
         seq.append(h)
     q = dg.HUGE_QUIET_FRAMES
     assert seq == [0, 0, q, q - 1, q - 2, q - 3] and q >= 8
+    # the dead-entry kernel of the backward: launched while the state is > 0; one "yes" keeps it in for PREFILL_QUIET "no"s
+    p, seq = 1, []
+    for yes in (False, False, True, False, False, True, False):
+        p = dg._next_prefilled(p, yes)
+        seq.append(p)
+    q = dg.PREFILL_QUIET
+    assert seq == [0, 0, q, q - 1, q - 2, q, q - 1] and q >= 64
 
 
 def test_route_options_are_set_through_the_abi_not_the_environment():

@@ -5,7 +5,7 @@ import argparse, ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "skyfall-gs_amd"))
-from sfgs.synth import scene  # noqa: E402
+from sfgs.synth import city_scene, orbit_scene, scene  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "_build", "libworkmodel.so")
@@ -24,13 +24,20 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--window", type=int, default=24, help="window of window x window tiles at the image centre")
     ap.add_argument("--pitch", type=float, default=0.0)
+    ap.add_argument("--city", type=float, default=0.0, help="tools/bench_regimes.py's opaque city at this elevation (degrees)")
+    ap.add_argument("--orbit", type=float, default=0.0, help="... its orbit view at this elevation")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", SO,
                            os.path.join(HERE, "workmodel.cpp")])
     lib = C.CDLL(SO)
     kw = dict(pitch_deg=a.pitch, zrange=(40.0, 400.0)) if a.pitch else {}   # --pitch 45: tools/bench_regimes.py's low elevation
-    frame, g = scene(a.n, a.width, a.height, seed=0, **kw)
+    if a.city:
+        frame, g = city_scene(a.n, a.width, a.height, a.city, seed=0)
+    elif a.orbit:
+        frame, g = orbit_scene(a.n, a.width, a.height, a.orbit, seed=0)
+    else:
+        frame, g = scene(a.n, a.width, a.height, seed=0, **kw)
     f32 = lambda t: np.ascontiguousarray(t.numpy(), np.float32)
     keep = [f32(frame[k]) for k in ("bg", "view", "proj", "campos")]
     fr = WmFrame(a.width, a.height, frame["tanfovx"], frame["tanfovy"], frame["kernel_size"], 1.0,
