@@ -131,6 +131,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: initialise torch.distributed over RCCL (backend nccl, world size 1) and run the "
                          "24 966-float device all-reduce every step, as the N > 1 runs do")
+    ap.add_argument("--pin-cores", type=int, default=4,
+                    help="confine each rank's process to this many CPUs of one L3 domain (sfgs.affinity.pin: what tools/launch_scenes.py "
+                         "does per rank; the JSON line reports it as host.pinned_to). Neutral at the headline (GPU-bound); host-bound sizes, "
+                         "below ~500 k Gaussians, run 35-45 %% faster and reproducibly that way. 0 = leave the affinity alone. Lifted again "
+                         "before the CPU-baseline legs, which use every host core")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-only", action="store_true", help="run only the CPU-baseline legs and print them")
     argv = sys.argv[1:]
@@ -167,6 +172,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    from sfgs import affinity
+    host = {"cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "pinned_to": None}
+    if args.pin_cores > 0:
+        host["pinned_to"] = affinity.pin(local_rank=local_rank, cores=args.pin_cores)
     # SFGS_BENCH_BACKEND=gloo: test hook that exercises the multi-rank control flow (spawn, barriers, per-rank gather,
     # JSON) on a box with fewer GPUs than ranks -- ranks then share GPUs and the collectives run on host tensors.
     backend = pick_backend(world, torch.cuda.device_count(), os.environ)   # "nccl" is RCCL on ROCm
@@ -465,6 +474,7 @@ def main():
             roofline_step["traffic_gbs"] = round(tot / (ms_step * 1e-3) / 1e9, 1)
             roofline_step["traffic_source"] = traffic_source
 
+    affinity.unpin()   # (the CPU legs use every host core)
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only and args.config == "cfg2":
         cpu_baseline = run_cpu_baseline(N, W, H)
@@ -485,7 +495,7 @@ def main():
                        "collective_backend": backend if dist is not None else None,
                        "prewarm_steps": args.prewarm_steps, "settle_steps": args.settle_steps, "order": args.order},
             "subpixel_offset": args.subpixel_offset, "kernel_ms_brackets": "raw",   # not comparable with r1-r4 lines otherwise
-            "box": box,
+            "box": box, "host": host,
             "train_shaped": train_shaped,
             "roofline": roofline, "roofline_composite_pair": roofline_pair, "roofline_step": roofline_step,
             "cpu_baseline": cpu_baseline,

@@ -1,0 +1,136 @@
+"""Keep a training process on a few neighbouring CPU cores (optional; host logic, no kernel of ours).
+
+Below ~500 k Gaussians a step is bound by the HOST: torch's dispatch and autograd engine, this library's one C call per
+direction with its dozen launches, the plan's one wait. That work bounces between three threads -- the caller, autograd's
+device thread, the HIP runtime's -- and on a 2 x 64-core host the scheduler spreads them over the machine: every hand-over
+then wakes a core in another L3 domain. Measured on the GPU box (tools/diag_numa.py, bench.py --n N; profiles/
+r6_cpu_affinity_small_scenes.txt): the same step takes 0.154 ms at N = 1 000 and 0.178 ms at N = 100 000 with the process
+confined to <= 8 cores of ONE L3 domain (a CCD), and 0.23 - 0.34 ms, bimodal from process to process, with 16 cores or more --
+whether those are on the GPU's NUMA node or not makes no difference. From 500 k Gaussians up the GPU is the bottleneck and
+the CPU set does not show (0.31 ms either way; the 2 M headline 0.897 either way).
+
+The reference starts one training process per scene and GPU (scripts/run_jax.py:52-87); nothing in it sets an affinity.
+`pin()` is what tools/launch_scenes.py calls per rank and what a user adds as the first line of train.py's process:
+
+    import sfgs.affinity; sfgs.affinity.pin(local_rank=int(os.environ.get("LOCAL_RANK", 0)))
+
+It changes the CALLING process's CPU set (os.sched_setaffinity): threads and worker processes started afterwards inherit
+it (and torch's intra-op pool, if torch is already imported, is resized to the chosen set), so give it more cores (cores=8)
+when the process also decodes images in workers. `unpin()` restores the set found at the first call. Never called implicitly: importing sfgs / diff_gauss does not touch the affinity."""
+import os
+import sys
+
+__all__ = ["pin", "unpin", "parse_cpulist", "l3_domains", "choose_cores", "gpu_local_cpus"]
+
+_ORIGINAL = None
+_ORIGINAL_THREADS = None
+
+
+def parse_cpulist(s):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in str(s).strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def l3_domains(cpus, sysfs="/sys/devices/system/cpu"):
+    """The allowed CPUs grouped by the last-level cache they share, each group as (physical cores first, then their SMT
+    siblings), groups in order of their lowest CPU. Without the sysfs entries: one group of everything."""
+    cpus = sorted(cpus)
+    allowed = set(cpus)
+    groups, seen = [], set()
+    for c in cpus:
+        if c in seen:
+            continue
+        shared = _read(f"{sysfs}/cpu{c}/cache/index3/shared_cpu_list")
+        members = [x for x in (parse_cpulist(shared) if shared else cpus) if x in allowed and x not in seen]
+        if not members:
+            members = [c]
+        seen.update(members)
+        first, rest = [], []
+        for x in members:   # a core's first hardware thread before anybody's second
+            sib = _read(f"{sysfs}/cpu{x}/topology/thread_siblings_list")
+            sibs = [y for y in (parse_cpulist(sib) if sib else [x]) if y in allowed]
+            (first if not sibs or x == min(sibs) else rest).append(x)
+        groups.append(first + rest)
+    return groups
+
+
+def choose_cores(domains, local_rank=0, cores=4):
+    """`cores` CPUs of ONE L3 domain for this rank: rank r takes domain r (modulo their number), so the ranks of a node do not
+    share a domain while there are enough of them; within the domain physical cores come first. Domains too small for the
+    request give what they have."""
+    domains = [d for d in domains if d]
+    if not domains:
+        return []
+    d = domains[int(local_rank) % len(domains)]
+    return sorted(d[:max(1, int(cores))])
+
+
+def gpu_local_cpus(device_index=0):
+    """CPUs of the NUMA node the GPU hangs on (sysfs local_cpulist of its PCI function), or None when that cannot be read.
+    (Locality made no measurable difference to the step floor; it is used to spread the ranks of a node sensibly.)"""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}.0"
+    except Exception:
+        return None
+    s = _read(f"/sys/bus/pci/devices/{bdf}/local_cpulist")
+    return parse_cpulist(s) if s else None
+
+
+def pin(local_rank=0, cores=4, device_index=None, min_cpus=16):
+    """Confine this process to `cores` CPUs of one L3 domain (see the module text). Returns the chosen CPU list, or None when
+    nothing was changed: SFGS_PIN=0 in the environment, a platform without sched_setaffinity, or fewer than `min_cpus`
+    allowed CPUs (somebody -- a container, taskset, a job scheduler -- already chose)."""
+    global _ORIGINAL, _ORIGINAL_THREADS
+    if os.environ.get("SFGS_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    if _ORIGINAL is None:
+        _ORIGINAL = allowed
+    if len(allowed) < min_cpus:
+        return None
+    pool = allowed
+    if device_index is not None:
+        local = gpu_local_cpus(device_index)
+        if local:
+            near = [c for c in allowed if c in set(local)]
+            if len(near) >= cores:
+                pool = near
+    chosen = choose_cores(l3_domains(pool), local_rank, cores)
+    if not chosen:
+        return None
+    os.sched_setaffinity(0, chosen)
+    torch = sys.modules.get("torch")
+    if torch is not None:   # its intra-op pool was sized for the CPUs it saw at import
+        if _ORIGINAL_THREADS is None:
+            _ORIGINAL_THREADS = torch.get_num_threads()
+        torch.set_num_threads(len(chosen))
+    return chosen
+
+
+def unpin():
+    """Back to the CPU set (and torch intra-op thread count) found by the first pin()."""
+    global _ORIGINAL, _ORIGINAL_THREADS
+    if _ORIGINAL is not None and hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, _ORIGINAL)
+        _ORIGINAL = None
+    torch = sys.modules.get("torch")
+    if torch is not None and _ORIGINAL_THREADS is not None:
+        torch.set_num_threads(_ORIGINAL_THREADS)
+    _ORIGINAL_THREADS = None

@@ -111,11 +111,17 @@ def _drain_without_bucket():
 
 # ---- worker: one process, one GPU, its scenes one after the other ------------------------------------------------------
 def worker(args, cmd):
-    import torch
-    import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if PKG not in sys.path:
         sys.path.insert(0, PKG)                  # diff_gauss / fused_ssim / simple_knn resolve to the HIP drop-ins
+    if args.pin_cores > 0:
+        # before torch sizes its thread pools: this rank's process on a few cores of ONE L3 domain, a domain per rank (scenes
+        # below ~500 k Gaussians are host-bound and 35 - 45 % faster that way: sfgs/affinity.py)
+        from sfgs import affinity
+        cpus = affinity.pin(local_rank=rank, cores=args.pin_cores)
+        print(f"[launch_scenes rank {rank}] cpus: {cpus if cpus is not None else 'left as they are'}", flush=True)
+    import torch
+    import torch.distributed as dist
     sharing = world > 1 and args.shared_mlp     # independent scenes (the default) need no process group at all
     if sharing:
         # "nccl" is RCCL on ROCm; SFGS_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
@@ -178,6 +184,8 @@ def main():
     ap.add_argument("--zcurve-order", action="store_true",
                     help="re-sort the Gaussians along a Z-curve after every densify_and_prune (a relabelling; faster binning)")
     ap.add_argument("--no-plyfile-standin", action="store_true")
+    ap.add_argument("--pin-cores", type=int, default=4,
+                    help="CPUs of one L3 domain each rank's process is confined to (sfgs.affinity.pin; 0 = leave the affinity alone)")
     ap.add_argument("--model-module", default="scene.gaussian_model")
     ap.add_argument("--model-class", default="GaussianModel")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
