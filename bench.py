@@ -132,10 +132,11 @@ def main():
                     help="with --gpus 1: initialise torch.distributed over RCCL (backend nccl, world size 1) and run the "
                          "24 966-float device all-reduce every step, as the N > 1 runs do")
     ap.add_argument("--pin-cores", type=int, default=4,
-                    help="confine each rank's process to this many CPUs of one L3 domain (sfgs.affinity.pin: what tools/launch_scenes.py "
-                         "does per rank; the JSON line reports it as host.pinned_to). Neutral at the headline (GPU-bound); host-bound sizes, "
-                         "below ~500 k Gaussians, run 35-45 %% faster and reproducibly that way. 0 = leave the affinity alone. Lifted again "
-                         "before the CPU-baseline legs, which use every host core")
+                    help="sfgs.affinity.auto(cores=K), what tools/launch_scenes.py does per rank: the process is confined to K CPUs of "
+                         "one L3 domain while the scene has fewer than 500 k Gaussians (host-bound sizes run 35-45 %% faster and "
+                         "reproducibly that way) and left alone above (the 2 M headline is GPU-bound and is NEVER pinned: confinement "
+                         "costs it 1-5 %%); reported as host{} in the JSON line. 0 = off")
+    ap.add_argument("--pin-below", type=int, default=500_000, help="the size below which --pin-cores applies (released above 1.6 x this)")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-only", action="store_true", help="run only the CPU-baseline legs and print them")
     argv = sys.argv[1:]
@@ -173,9 +174,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     from sfgs import affinity
-    host = {"cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "pinned_to": None}
-    if args.pin_cores > 0:
-        host["pinned_to"] = affinity.pin(local_rank=local_rank, cores=args.pin_cores)
+    host = {"cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    affinity.auto(local_rank=local_rank, cores=args.pin_cores, below=args.pin_below, above=int(args.pin_below * 1.6))   # (cores 0: off)
     # SFGS_BENCH_BACKEND=gloo: test hook that exercises the multi-rank control flow (spawn, barriers, per-rank gather,
     # JSON) on a box with fewer GPUs than ranks -- ranks then share GPUs and the collectives run on host tensors.
     backend = pick_backend(world, torch.cuda.device_count(), os.environ)   # "nccl" is RCCL on ROCm
@@ -474,6 +474,8 @@ def main():
             roofline_step["traffic_gbs"] = round(tot / (ms_step * 1e-3) / 1e9, 1)
             roofline_step["traffic_source"] = traffic_source
 
+    host.update(affinity.state())   # what the timed region ran under
+    affinity.auto(cores=0)
     affinity.unpin()   # (the CPU legs use every host core)
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0 and not args.forward_only and args.config == "cfg2":

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from sfgs import _lib as L
 from sfgs import features as _features, max_radii as _max_radii, prepass, sh as _sh, viewdirs as _viewdirs   # the hooks' handle types
+from sfgs import affinity as _affinity   # (opt-in: does nothing unless the process called sfgs.affinity.auto())
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_counters",
            "last_backward_hints", "collect_full_counters"]
@@ -282,6 +283,8 @@ class _Rasterize(torch.autograd.Function):
         dev = means3D.device
         di = dev.index
         N = int(means3D.shape[0])
+        if _affinity._AUTO is not None:   # sfgs.affinity.auto(): a few cores of one L3 domain while the scene is small
+            _affinity.on_frame(N)
         H, W = int(settings.image_height), int(settings.image_width)
         sh_coeffs = 0 if shs is None else int(shs.shape[2] if sh_channel_major else shs.shape[1])
         if shs_rest is not None:

@@ -70,3 +70,44 @@ def test_pin_and_unpin_on_this_host(monkeypatch):
         os.sched_setaffinity(0, before)
         torch.set_num_threads(threads)
         A._ORIGINAL = A._ORIGINAL_THREADS = None
+
+
+@pytest.mark.skipif(not hasattr(os, "sched_setaffinity"), reason="no sched_setaffinity on this platform")
+def test_auto_pins_small_scenes_and_releases_grown_ones():
+    """auto(): on_frame(N) -- called by diff_gauss with every forward's Gaussian count -- pins below `below`, releases above
+    `above`, does nothing in between (hysteresis) and nothing at all when the mechanism is off."""
+    import threading
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        A.on_frame(10)                                   # off: nothing happens
+        assert A.state() == {"policy": None, "pinned_to": None}
+        A.auto(local_rank=0, cores=1, below=1000, above=2000, min_cpus=1)
+        assert "1 cores" in A.state()["policy"]
+        A.on_frame(5000)
+        assert A.state()["pinned_to"] is None and sorted(os.sched_getaffinity(0)) == before
+        # a second thread that already exists must follow the switch too (autograd's device thread, the HIP runtime's)
+        seen, go, done = {}, threading.Event(), threading.Event()
+
+        def other():
+            go.wait(10)
+            seen["cpus"] = sorted(os.sched_getaffinity(0))
+            done.set()
+        t = threading.Thread(target=other)
+        t.start()
+        A.on_frame(500)
+        got = A.state()["pinned_to"]
+        assert got is not None and len(got) == 1 and sorted(os.sched_getaffinity(0)) == got
+        go.set(); done.wait(10); t.join()
+        assert seen["cpus"] == got
+        A.on_frame(1500)                                 # between the thresholds: stays as it is
+        assert A.state()["pinned_to"] == got
+        A.on_frame(2500)
+        assert A.state()["pinned_to"] is None and sorted(os.sched_getaffinity(0)) == before
+        A.auto(cores=0)
+        A.on_frame(10)
+        assert A.state() == {"policy": None, "pinned_to": None}
+    finally:
+        A.auto(cores=0)
+        A.unpin()
+        os.sched_setaffinity(0, before)
+        A._ORIGINAL = A._ORIGINAL_THREADS = A._PINNED = None

@@ -38,7 +38,7 @@ dev = torch.device("cuda:0")
 only = sys.argv[1:]
 if int(os.environ.get("PIN_CORES", "4")) > 0:   # as bench.py / tools/launch_scenes.py: the host-bound regimes (tiny scene) depend on it
     from sfgs import affinity
-    affinity.pin(cores=int(os.environ.get("PIN_CORES", "4")))
+    affinity.auto(cores=int(os.environ.get("PIN_CORES", "4")))   # (pinned only while a regime's scene has < 500 k Gaussians)
 for kv in filter(None, os.environ.get("SFGS_OPTIONS", "").split(",")):   # route options for A/B runs, e.g. SFGS_OPTIONS=prefill=always
     L.set_option(*kv.split("="))
 for name, c in REGIMES.items():

@@ -115,11 +115,11 @@ def worker(args, cmd):
     if PKG not in sys.path:
         sys.path.insert(0, PKG)                  # diff_gauss / fused_ssim / simple_knn resolve to the HIP drop-ins
     if args.pin_cores > 0:
-        # before torch sizes its thread pools: this rank's process on a few cores of ONE L3 domain, a domain per rank (scenes
-        # below ~500 k Gaussians are host-bound and 35 - 45 % faster that way: sfgs/affinity.py)
+        # this rank's process on a few cores of ONE L3 domain (a domain per rank) while its scene is small -- scenes below
+        # ~500 k Gaussians are host-bound and 35 - 45 % faster that way -- and released once it has grown (sfgs/affinity.py)
         from sfgs import affinity
-        cpus = affinity.pin(local_rank=rank, cores=args.pin_cores)
-        print(f"[launch_scenes rank {rank}] cpus: {cpus if cpus is not None else 'left as they are'}", flush=True)
+        affinity.auto(local_rank=rank, cores=args.pin_cores)
+        print(f"[launch_scenes rank {rank}] cpu policy: {affinity.state()['policy']}", flush=True)
     import torch
     import torch.distributed as dist
     sharing = world > 1 and args.shared_mlp     # independent scenes (the default) need no process group at all
@@ -185,7 +185,7 @@ def main():
                     help="re-sort the Gaussians along a Z-curve after every densify_and_prune (a relabelling; faster binning)")
     ap.add_argument("--no-plyfile-standin", action="store_true")
     ap.add_argument("--pin-cores", type=int, default=4,
-                    help="CPUs of one L3 domain each rank's process is confined to (sfgs.affinity.pin; 0 = leave the affinity alone)")
+                    help="CPUs of one L3 domain each rank's process is confined to WHILE ITS SCENE IS SMALL (sfgs.affinity.auto; 0 = leave the affinity alone)")
     ap.add_argument("--model-module", default="scene.gaussian_model")
     ap.add_argument("--model-class", default="GaussianModel")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
