@@ -165,7 +165,11 @@ def unpin():
 def auto(local_rank=0, cores=4, below=500_000, above=800_000, device_index=None, min_cpus=16):
     """Pinned while the scene is small, released once it has grown: from now on every forward of the rasterizer reports its
     Gaussian count (diff_gauss -> on_frame) and the process is confined (pin) when a frame has fewer than `below` Gaussians,
-    released (unpin) when one has more than `above`. cores <= 0 switches the mechanism off again."""
+    released (unpin) when one has more than `above`. cores <= 0 switches the mechanism off again.
+    The defaults are those of a bare rasterizer loop (bench.py: host-bound below ~500 k). A TRAINING iteration issues ~100
+    torch launches around the rasterizer and stays host-sensitive much longer -- the reference's real classes with the hooks:
+    1.41 -> 1.17 ms at 100 k, 1.44 -> 1.16 at 500 k, 1.45 -> 1.22 at 1 M, 1.85 -> 1.68 at 2 M, even at 4 M -- so
+    tools/launch_scenes.py passes below = 2.5 M, above = 3.5 M."""
     global _AUTO
     if cores <= 0 or os.environ.get("SFGS_PIN", "1") == "0":
         _AUTO = None

@@ -118,7 +118,9 @@ def worker(args, cmd):
         # this rank's process on a few cores of ONE L3 domain (a domain per rank) while its scene is small -- scenes below
         # ~500 k Gaussians are host-bound and 35 - 45 % faster that way -- and released once it has grown (sfgs/affinity.py)
         from sfgs import affinity
-        affinity.auto(local_rank=rank, cores=args.pin_cores)
+        # (thresholds of a TRAINING iteration, ~100 torch launches around the rasterizer: pinned it is 16 - 19 % faster up to
+        # 1 M Gaussians, 9 % at 2 M, even at 4 M: profiles/r6_cpu_affinity_small_scenes.txt section 6)
+        affinity.auto(local_rank=rank, cores=args.pin_cores, below=args.pin_below, above=int(args.pin_below * 1.4))
         print(f"[launch_scenes rank {rank}] cpu policy: {affinity.state()['policy']}", flush=True)
     import torch
     import torch.distributed as dist
@@ -184,6 +186,8 @@ def main():
     ap.add_argument("--zcurve-order", action="store_true",
                     help="re-sort the Gaussians along a Z-curve after every densify_and_prune (a relabelling; faster binning)")
     ap.add_argument("--no-plyfile-standin", action="store_true")
+    ap.add_argument("--pin-below", type=int, default=2_500_000,
+                    help="Gaussian count below which --pin-cores applies (released again above 1.4 x this)")
     ap.add_argument("--pin-cores", type=int, default=4,
                     help="CPUs of one L3 domain each rank's process is confined to WHILE ITS SCENE IS SMALL (sfgs.affinity.auto; 0 = leave the affinity alone)")
     ap.add_argument("--model-module", default="scene.gaussian_model")
