@@ -341,10 +341,11 @@ static inline ImageView image_view(void* base, int W, int H, int64_t D) {
   return v;
 }
 
-// Backward: do the dead entries make up more than 30 % of the frame's duplicates? Then the frame runs in LIVE-FLAG mode:
+// Backward: do the dead entries make up more than a quarter of the frame's duplicates? (Measured break-even on near-nadir city
+// views, profiles/r6_live_flags_ab.txt: 18 % dead -> flags +1.5 %, 23 % -> equal, 33 % -> -2 %.) Then the frame runs in LIVE-FLAG mode:
 // dupgrad_prefill_kernel clears one byte per duplicate index, composite_bwd sets the byte of every record it writes and
 // writes nothing for the dead entries, and the readers (dupgrad_reduce_kernel, preprocess_bwd) fetch only flagged records.
-__host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned long long n_dup) { return dead * 10ull > n_dup * 3ull; }
+__host__ __device__ inline bool prefill_wanted(unsigned long long dead, unsigned long long n_dup) { return dead * 4ull > n_dup; }
 
 // per-duplicate gradient record. DG_F4 = 3: 48 bytes, floats in Grad2D order. 4: 64 bytes, float 3 k + r of the
 // record at position 4 r + k (every fourth float is padding): lane (entry, row r) of composite_bwd then owns one whole

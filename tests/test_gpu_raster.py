@@ -324,7 +324,7 @@ def test_random_configurations(i):
 def test_dead_entry_prefill_paths_bit_identical(sfgs_option, case):
     """Entries behind a tile's last contributor either get zero gradient records one by one (composite_bwd) or are skipped
     through the live flags (dupgrad_prefill_kernel clears one byte per duplicate, composite_bwd sets the byte of every record
-    it writes, dupgrad_reduce_kernel / preprocess_bwd fetch flagged records only; chosen per frame on the device when > 30 %
+    it writes, dupgrad_reduce_kernel / preprocess_bwd fetch flagged records only; chosen per frame on the device when > 25 %
     are dead). Both forced in turn: every gradient must come out bit-identical, and identical to the automatic choice.
     The three scenes put Gaussians on each summation route of preprocess_bwd: <= 32 records (streamed through LDS), 33 .. 2048
     (the wave strides over them), > 2048 (pre-reduced chunks: `num_big_chunks` of the forward's counters)."""

@@ -25,6 +25,11 @@ REGIMES = {
     # every tile list lies behind the last contributor
     "city_e45_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=45.0),
     "city_e25_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=25.0),
+    # near-nadir views of the same city (the satellite cameras the first training stage uses): 18 - 33 % of the list entries
+    # lie behind their tile's last contributor, the zone where the backward's live-flag choice is decided
+    "city_e60_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=60.0),
+    "city_e75_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=75.0),
+    "city_e89_2M_1080p": dict(n=2_000_000, W=1920, H=1080, city=89.0),
     "near_big_splats_200k": dict(n=200_000, W=1920, H=1080, kw=dict(zrange=(3.0, 6.0), scale_range=(0.01, 0.3))),
     "screen_filling_2k": dict(n=2_000, W=1920, H=1080, kw=dict(zrange=(3.0, 6.0), scale_range=(0.5, 3.0), opacity_range=(0.01, 0.05))),
     "tiny_scene_1k": dict(n=1_000, W=1920, H=1080, kw={}),
