@@ -72,7 +72,8 @@ HINT_MEDIUM_LISTS = 32
 # once lists take its long-list path (a second scan of the slab per long tile)
 SHORT_LIST_MAX, SHORT_BIN_MAX = 512, 8192
 MEDIUM_LIST_MAX = 1024     # MEDIUM_LISTS: the same kernel with room for lists of 513 .. 1 024 entries (low-elevation views)
-MEDIUM_TILE_SHARE = 4      # ... asked for when at least a quarter of the frame's tiles had more than 512 entries
+MEDIUM_TILE_SHARE = 10     # ... asked for when at least a tenth of the frame's tiles had more than 512 entries
+MEDIUM_MEAN_MAX = 640      # ... and either no list exceeds 1 024 entries or the MEAN list is at most this long (see _sort_hints)
 HUGE_QUIET_FRAMES = 32     # frames without a huge splat before NO_HUGE_SPLATS is asserted again
 PREFILL_PROBE_EVERY = 32   # backward passes between two launches of the dead-entry prefill kernel while it keeps saying no
 PREFILL_QUIET = 256        # ... and it has to say no this many times in a row first (see _next_prefilled)
@@ -88,6 +89,25 @@ def _binning_direct():
 
 def _medium_on():
     return os.environ.get("SFGS_MEDIUM_LISTS", "1") != "0"   # A/B switch: 0 = frames with lists of 513 .. 1 024 take the split route
+
+
+def _sort_hints(long_tiles, maxlist, cmax, over512, mean_list, tiles, medium_on=True):
+    """SHORT_LISTS / MEDIUM_LISTS bits for the next frame from the previous frame's list statistics (performance only: every
+    route builds the same lists; the fused kernels' long-list path takes whatever exceeds their capacity).
+    * no list beyond 512 entries, small coarse bins: the fused kernel (headline, orbits, UHD);
+    * at least a tenth of the tiles beyond 512 entries: its 1 024-entry form -- when no list exceeds 1 024 (low elevation,
+      dense 8 M: 2.71 -> 2.53 ms against the split route), and ALSO when some do but the mean list is short: an opaque city
+      has a few hundred very long lists (up to 3 361 entries along facades seen edge-on) among 30 000 ordinary ones, and
+      the split route's two extra passes over everything cost more than the stragglers' slow path (round 6, city at
+      25 / 45 / 60 degrees 1.01 -> 0.96, 1.12 -> 1.10, 1.145 -> 1.13 ms; 5 M Gaussians at 1080p 2.24 -> 2.16). Where most lists
+      exceed 1 024 entries (16 M Gaussians: mean 1 700) the split route stays (2.66 against 3.00 ms);
+    * otherwise the split route (fine_bin + the size-class sorts)."""
+    if long_tiles == 0 and maxlist <= SHORT_LIST_MAX and cmax <= SHORT_BIN_MAX:
+        return HINT_SHORT_LISTS
+    if medium_on and maxlist > SHORT_LIST_MAX and over512 * MEDIUM_TILE_SHARE >= tiles and (
+            (maxlist <= MEDIUM_LIST_MAX and cmax <= SHORT_BIN_MAX) or mean_list <= MEDIUM_MEAN_MAX):
+        return HINT_SHORT_LISTS | HINT_MEDIUM_LISTS
+    return 0
 
 
 def _next_huge(prev, num_huge_splats):
@@ -341,14 +361,9 @@ class _Rasterize(torch.autograd.Function):
             fwd_hints = 0
             if hs is not None:
                 fwd_hints = (HINT_NO_HUGE_SPLATS if hs["huge"] == 0 else 0) | (HINT_FEW_LONG_LISTS if hs["long"] == 0 else 0)
-                if hs["long"] == 0 and hs["maxlist"] <= SHORT_LIST_MAX and hs["cmax"] <= SHORT_BIN_MAX:
-                    fwd_hints |= HINT_SHORT_LISTS
-                elif (SHORT_LIST_MAX < hs["maxlist"] <= MEDIUM_LIST_MAX and hs["cmax"] <= SHORT_BIN_MAX and _medium_on()
-                      and hs["over512"] * MEDIUM_TILE_SHARE >= ((W + 7) // 8) * ((H + 7) // 8)):
-                    # the 1 024-entry form runs every tile at half the occupancy: it pays when a sizeable part of the
-                    # frame's lists is that long (low-elevation view 1.676 -> 1.647 ms), not for a few stragglers
-                    # (orbit camera at 25 degrees, a handful of lists up to 852 entries: 1.30 -> 1.38 ms)
-                    fwd_hints |= HINT_SHORT_LISTS | HINT_MEDIUM_LISTS
+                tiles = ((W + 7) // 8) * ((H + 7) // 8)
+                fwd_hints |= _sort_hints(hs["long"], hs["maxlist"], hs["cmax"], hs["over512"], hs.get("D", 1 << 40) / tiles, tiles,
+                                         _medium_on())
                 frame.feedback = hs["fb"].data_ptr()
             pin, ev, pin_ptr, ev_handle, cnt = _pinned_counters(dev, stream)
             outs_ptr = outs.data_ptr()
@@ -410,6 +425,7 @@ class _Rasterize(torch.autograd.Function):
                 # every other frame
                 hs["huge"] = _next_huge(hs["huge"], int(cnt.num_huge_splats))
                 hs["cmax"] = int(cnt.max_bin_items)
+                hs["D"] = D
                 hs["prefill_ran"] = False
             # next frame's capacities: 25 % / 50 % of headroom over this frame, never growing on their own, and SHRINKING
             # slowly (3 % per frame, down to twice / three times this frame's need): an overflowing plan costs a second plan +

@@ -60,7 +60,7 @@ def _record(entry):
 # the route frame 3 must have taken: "short" = fused select_sort_kernel<512> (no list beyond 512 entries), "medium" = its
 # 1 024-entry form (round 4: lists of 513 .. 1 024 entries, the low-elevation cameras), "split" = fine_bin + sort kernels
 EXPECT_ROUTE = {"cfg2_2M_1080p": "short", "cfg3_idu_2M_1024sq": "short", "cfg4_5M_1440p_depth": "short",
-                "cfg2_low_elevation_2M_1080p": "medium", "city_e25_2M_1080p": "split"}
+                "cfg2_low_elevation_2M_1080p": "medium", "city_e25_2M_1080p": "medium"}   # (city: round 6, lists of up to 3 361 entries among short ones)
 HINT_NO_HUGE_SPLATS, HINT_FEW_LONG_LISTS, HINT_NO_PREFILL, HINT_NO_BIG_CHUNKS, HINT_SHORT_LISTS = 1, 2, 4, 8, 16
 HINT_MEDIUM_LISTS = 32
 PARAMS = [(c, None) for c in CASES] + [("cfg2_2M_1080p", "fused"), ("cfg2_2M_1080p", "split")]

@@ -198,6 +198,25 @@ def test_capacity_and_huge_splat_hints_follow_their_rules():
     assert seq == [0, 0, q, q - 1, q - 2, q, q - 1] and q >= 64
 
 
+def test_sort_route_hints_follow_the_list_statistics():
+    """diff_gauss._sort_hints: which fused-sort form the next frame asks for, from the previous frame's list statistics (the
+    measured cases behind the rule: profiles/r6_sort_route_policy.txt). Performance only -- every route builds the same lists."""
+    import diff_gauss as dg
+    S, M, T = dg.HINT_SHORT_LISTS, dg.HINT_SHORT_LISTS | dg.HINT_MEDIUM_LISTS, 32400
+    f = dg._sort_hints   # (long_tiles, maxlist, cmax, over512, mean_list, tiles)
+    assert f(0, 277, 3000, 0, 214, T) == S                         # headline
+    assert f(0, 277, 9000, 0, 214, T) == 0                         # ... with a huge coarse bin: split
+    assert f(25984, 652, 6000, 25984, 536, T) == M                 # low elevation: 80 % of the tiles beyond 512, none beyond 1 024
+    assert f(32400, 1023, 6000, 32400, 858, T) == M                # dense 8 M
+    assert f(7179, 3361, 20000, 7179, 269, T) == M                 # opaque city at 25 degrees: a few very long lists, short mean
+    assert f(4196, 1998, 20000, 4196, 240, T) == M                 # ... at 60 degrees (13 % of the tiles)
+    assert f(2412, 852, 5000, 2412, 164, T) == 0                   # orbit at 25 degrees: 7 % of the tiles -> split
+    assert f(2921, 1575, 20000, 2921, 203, T) == 0                 # city at 89 degrees: 9 %
+    assert f(32400, 3000, 50000, 32400, 1700, T) == 0              # 16 M Gaussians: most lists beyond 1 024 -> split
+    assert f(32400, 1676, 50000, 32400, 1311, T) == 0              # screen-filling splats
+    assert f(7179, 3361, 20000, 7179, 269, T, medium_on=False) == 0
+
+
 def test_route_options_are_set_through_the_abi_not_the_environment():
     """ABI 16: the library no longer calls getenv() on every render. The route options are process-wide
     atomics, read from the environment ONCE at load time and changed only through sfgs_set_option (host code: runs here)."""

@@ -92,7 +92,10 @@ for name, c in REGIMES.items():
         step()
     torch.cuda.synchronize()
     prof = L.profile_collect(); L.profile_enable(False)
-    print(json.dumps({"regime": name, "ms_per_step": round(ms, 3), "windows_ms": [round(w, 3) for w in windows], "N_vis": cnt["num_visible"],
+    import diff_gauss as _dg
+    hs = next(iter(_dg._hint_state.values()), {})
+    print(json.dumps({"regime": name, "ms_per_step": round(ms, 3), "fwd_hints": last_counters().get("fwd_hints"),
+                      "tiles_over_512": hs.get("over512"), "long_tiles": hs.get("long"), "max_bin_items": hs.get("cmax"), "windows_ms": [round(w, 3) for w in windows], "N_vis": cnt["num_visible"],
                       "D_binned": cnt["num_duplicates"], "max_tile_list": cnt["max_tile_list"],
                       "kernel_ms": {k: round(v[0] / 3, 3) for k, v in prof.items() if v[1]}}), flush=True)
     del t, means2D, rast
