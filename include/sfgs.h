@@ -95,6 +95,11 @@ typedef struct SfgsFrame {
  *   MEDIUM_LISTS    render: as SHORT_LISTS, for frames whose lists reach 513 .. 1 024 entries (what the feedback of the
  *                   previous frame reported): the same kernel with twice the list capacity (48 KB of LDS per workgroup,
  *                   the 16-key register network for the lists beyond 512). Always correct; implies the fused route.
+ *   TILE_ORDER      render: the caller expects tile lists of very different lengths (the previous frame's longest list
+ *                   several times its mean: a city seen from above, a few facades edge-on). The compositing kernels then
+ *                   take their tiles longest list first within each XCD's share of the image (two launches of a small
+ *                   ordering kernel) instead of in image order, so that the kernels' last stretch is filled with SHORT
+ *                   lists. Always correct: tiles are independent, the results are the same bits in any order.
  *   NO_PREFILL      backward: do not launch the dead-entry prefill kernel (its decision then reads "no"). Always correct.
  *   NO_BIG_CHUNKS   backward: do not launch the chunk pre-reduction. Only valid when THIS frame's plan reported
  *                   num_big_chunks == 0. */
@@ -104,6 +109,7 @@ typedef struct SfgsFrame {
 #define SFGS_HINT_NO_BIG_CHUNKS 8u
 #define SFGS_HINT_SHORT_LISTS 16u
 #define SFGS_HINT_MEDIUM_LISTS 32u
+#define SFGS_HINT_TILE_ORDER 64u
 
 /* Per-Gaussian inputs = keyword arguments of GaussianRasterizer.__call__
  * (gaussian_renderer/__init__.py:132-140). All float32, contiguous, device memory.
@@ -226,7 +232,7 @@ const char* sfgs_last_error(void);
 
 /* Process-wide ROUTE options (ABI 16; tests and A/B runs -- never needed for correctness: every route builds bit-identical
  * results, tests/test_gpu_raster.py). They replace the getenv() calls the library used to make on every render: the
- * environment is read ONCE, when the library is loaded (SFGS_SORT, SFGS_PLAN_SCAN, SFGS_BINNING, SFGS_PREFILL, SFGS_KNN: same
+ * environment is read ONCE, when the library is loaded (SFGS_SORT, SFGS_PLAN_SCAN, SFGS_BINNING, SFGS_PREFILL, SFGS_KNN, SFGS_TILE_ORDER: same
  * values),
  * and changed afterwards only through this call. Thread-safe: one atomic word per option; a render running on another
  * thread sees the old or the new value, never a mixture.
@@ -235,6 +241,7 @@ const char* sfgs_last_error(void);
  *   key "binning"    "auto" (two-pass below 65 536 coarse bins) | "direct"
  *   key "prefill"    "auto" (dead-entry prefill decided per frame on the device) | "always" | "never"
  *   key "knn"        "auto" (spatial search above 4 096 points) | "brute" (the exact all-pairs kernel at every size)
+ *   key "tile_order" "auto" (SFGS_HINT_TILE_ORDER decides) | "always" | "never": longest-first tile order of the compositing kernels
  * sfgs_set_option returns SFGS_E_ARG for an unknown key or value; sfgs_get_option returns the current value's name
  * (a string constant) or NULL for an unknown key. */
 int sfgs_set_option(const char* key, const char* value);

@@ -30,7 +30,8 @@ static const OptSpec kOpts[OPT_COUNT] = {
     {"plan_scan", "SFGS_PLAN_SCAN", {"fused", "separate", nullptr}},
     {"binning", "SFGS_BINNING", {"auto", "direct", nullptr}},
     {"prefill", "SFGS_PREFILL", {"auto", "always", "never", nullptr}},
-    {"knn", "SFGS_KNN", {"auto", "brute", nullptr}}};
+    {"knn", "SFGS_KNN", {"auto", "brute", nullptr}},
+    {"tile_order", "SFGS_TILE_ORDER", {"auto", "always", "never", nullptr}}};
 static std::atomic<int> g_opt[OPT_COUNT];
 static int opt_value(int which, const char* v) {
   for (int i = 0; v && kOpts[which].values[i]; ++i)

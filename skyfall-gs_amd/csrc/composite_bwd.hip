@@ -248,15 +248,23 @@ composite_bwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* _
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, const uint2* __restrict__ hitmask,
                      const uint32_t* __restrict__ tile_kmax, float4* __restrict__ dupgrad, uint8_t* __restrict__ live,
-                     const unsigned long long* __restrict__ hdr, int not_prefilled) {
+                     const unsigned long long* __restrict__ hdr, int not_prefilled, const uint32_t* __restrict__ order,
+                     unsigned order_P) {
   constexpr int ROW = BwdLds<B>::ROW;
   __shared__ BwdLds<B> lds_all[BWG_WAVES];
   // wave-uniform: wave index, tile, list range and all loop bounds become SGPRs (scalar loads / branches)
-  int sbx, sby, wave, lw;
-  if (!composite_wave_role<BWG_WAVES>(SX, SY, sbx, sby, wave, lw)) return;   // a surplus workgroup of the padded grid
+  int tx, ty, lw;
+  if ((unsigned)hdr[HDR_TILE_ORDER] & 2u) {   // this frame's forward left a longest-first order (raster_fwd.hip: tile_order_kernel)
+    const unsigned ot = ordered_tile<BWG_WAVES>(order, order_P, lw);
+    if (ot == 0xffffffffu) return;
+    ty = (int)(ot / (unsigned)TX8); tx = (int)(ot - (unsigned)ty * (unsigned)TX8);
+  } else {
+    int sbx, sby, wave;
+    if (!composite_wave_role<BWG_WAVES>(SX, SY, sbx, sby, wave, lw)) return;   // a surplus workgroup of the padded grid
+    constexpr int BE = composite_block_edge<BWG_WAVES>();
+    tx = sbx * BE + (wave % BE); ty = sby * BE + (wave / BE);
+  }
   const int lane = threadIdx.x & 63;
-  constexpr int BE = composite_block_edge<BWG_WAVES>();
-  const int tx = sbx * BE + (wave % BE), ty = sby * BE + (wave / BE);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   BwdLds<B>& lds = lds_all[lw];
   const int W = kf.W, H = kf.H;
@@ -545,10 +553,11 @@ void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8,
                           const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
                           const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
                           const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,
-                          float4* dupgrad, uint8_t* live, const unsigned long long* hdr, int not_prefilled) {
+                          float4* dupgrad, uint8_t* live, const unsigned long long* hdr, int not_prefilled,
+                          const uint32_t* order, unsigned order_slots_per_xcd) {
   hipLaunchKernelGGL(composite_bwd_kernel<16>, dim3(grid), dim3(64 * BWG_WAVES), 0, stream, kf, TX8, TY8, SX, SY, tile_range,
                      sorted_id, sorted_dup, rec, n_contrib, final_T, dacc, dL_dcolor, dL_ddepth, dL_dalpha, hitmask, tile_kmax,
-                     dupgrad, live, hdr, not_prefilled);
+                     dupgrad, live, hdr, not_prefilled, order, order_slots_per_xcd);
 }
 
 }  // namespace sfgs

@@ -440,7 +440,8 @@ extern "C" int sfgs_raster_backward(const SfgsFrame* frame, const SfgsGaussians*
                        (unsigned long long)dup_capacity, dup_pools_used(pre_blocks(N)));
     launch_composite_bwd(composite_grid(SX, SY, BE * BE / BWG_WAVES), stream, kf, TX8, TY8, SX, SY, tv.tile_range, bv.sorted_id,
                          bv.sorted_dup, gv.rec, iv.n_contrib, iv.final_T, iv.dacc, dL_dcolor, dL_ddepth, dL_dalpha, iv.hitmask,
-                         iv.tile_kmax, (float4*)dupgrad, live, tv.hdr, no_prefill ? 1 : 0);
+                         iv.tile_kmax, (float4*)dupgrad, live, tv.hdr, no_prefill ? 1 : 0,
+                         tv.tile_order + (size_t)8 * order_slots(W, H), (unsigned)order_slots(W, H));
   }
   SFGS_POST_LAUNCH("composite_bwd", stream, frame->debug);
   const int NB = (int)pre_blocks(N);

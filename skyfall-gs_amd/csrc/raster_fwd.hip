@@ -1669,6 +1669,64 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
   }
 }
 
+// Longest-first tile order of the compositing kernels (SFGS_HINT_TILE_ORDER; round 6). A compositing wave owns one tile from
+// its first to its last list entry, and a frame is only ~4 rounds of such waves deep: whatever is still running when the
+// queue is empty runs alone. On a uniform frame that tail is one average tile; on a city seen from above -- lists of 200
+// entries everywhere, 1 500 along the facades that are seen edge-on -- the wave timeline (tools/timeline.py) has composite_fwd
+// drain for 70 of its 240 us, and list scheduling of the measured tile times longest first (within each XCD's share of the
+// image, which keeps the chunked XCD mapping and its L2 sharing) predicts 187 us; composite_bwd 405 -> 370.
+// One workgroup per XCD: a counting sort of the XCD's tiles by key (list length / last contributor) into 64 classes of 16
+// entries, longest first; tiles without work last (a 4-wave workgroup of composite_bwd then holds four lists of one class
+// and returns its LDS when all four are done -- in image order 28 % of that frame's tiles have nothing to blend and their
+// workgroup-mates keep the LDS). Inside a class the order is whatever the LDS atomics make it: tiles are independent, any
+// order composites the same bits. (A STABLE sort -- image order inside a class, in runs of 64 tiles -- was built and measured
+// worse: city at 75 degrees 1.21 -> 1.10 ms instead of -> 1.04, composite_fwd 0.235 instead of 0.208 ms. And uniform frames lose
+// with either: a class is a sparse subset of the image, the tiles in flight no longer share records in the L2 -- headline
+// +6 %, dense 8 M +12 % when forced on -- which is why the order is a HINT the caller only gives for frames whose longest list is
+// several times their mean.)
+template <bool PAIRS>   // PAIRS: key = tile_range[t].y (uint2 array), else a plain uint32 array (tile_kmax)
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(int TX8, int TY8, int SX, int SY, const void* __restrict__ keys_, uint32_t* __restrict__ order, unsigned P,
+                  unsigned long long* __restrict__ hdr, unsigned bit) {
+  __shared__ unsigned hist[65], base[65];
+  const unsigned x = blockIdx.x;
+  if (threadIdx.x < 65) hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const unsigned SXc = (unsigned)(SX + CHUNK_BX - 1) / CHUNK_BX, SYc = (unsigned)(SY + CHUNK_BY - 1) / CHUNK_BY;
+  const unsigned nch = SXc * SYc;
+  constexpr unsigned PERCH = CHUNK_BX * CHUNK_BY * 4;   // tiles per chunk
+  auto tile_of = [&](unsigned i, unsigned* cls) -> unsigned {   // slot i of this XCD in image (chunk) order -> tile, class
+    const unsigned c = (i / PERCH) * 8u + x, within = i % PERCH;
+    const unsigned st = within >> 2, sub = within & 3u;
+    const unsigned tx = ((c % SXc) * CHUNK_BX + st % CHUNK_BX) * 2u + (sub & 1u);
+    const unsigned ty = ((c / SXc) * CHUNK_BY + st / CHUNK_BX) * 2u + (sub >> 1);
+    if (c >= nch || tx >= (unsigned)TX8 || ty >= (unsigned)TY8) { *cls = 64u; return 0xffffffffu; }
+    const unsigned t = ty * (unsigned)TX8 + tx;
+    const unsigned key = PAIRS ? static_cast<const uint2*>(keys_)[t].y : static_cast<const uint32_t*>(keys_)[t];
+    *cls = key == 0u ? 63u : 62u - min(62u, (key - 1u) >> 4);   // class 0: more than 992 entries ... class 62: 1 .. 16; 63: none
+    return t;
+  };
+  for (unsigned i = threadIdx.x; i < P; i += 1024) {
+    unsigned cls;
+    tile_of(i, &cls);
+    atomicAdd(&hist[cls], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int k = 0; k < 65; ++k) { base[k] = run; run += hist[k]; }
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < P; i += 1024) {
+    unsigned cls;
+    const unsigned t = tile_of(i, &cls);
+    order[(size_t)x * P + atomicAdd(&base[cls], 1u)] = t;
+  }
+  if (x == 0 && threadIdx.x == 0) atomicOr(&hdr[HDR_TILE_ORDER], (unsigned long long)bit);
+}
+
+
+
 // ------------------------------------------------------------------------------------------------
 // K5: compositing. Workgroup = 4 independent waves = a 2x2 block of 8x8 tiles; lane l of
 // a wave owns pixel (l & 7, l >> 3) of its tile. Records of 64 list entries at a time are gathered
@@ -1684,15 +1742,22 @@ composite_fwd_kernel(KFrame kf, int TX8, int TY8, int SX, int SY, const uint2* _
                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
                      uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, float* __restrict__ dacc_out,
                      uint2* __restrict__ hitmask, uint32_t* __restrict__ tile_kmax, uint16_t* __restrict__ tile_dead,
-                     const unsigned long long* __restrict__ hdr) {
+                     const unsigned long long* __restrict__ hdr, const uint32_t* __restrict__ order, unsigned order_P) {
   __shared__ float4 stage[CWG_WAVES][64 * 3];
   __shared__ __attribute__((aligned(8))) unsigned char rowlist[CWG_WAVES][4][64];
   // wave-uniform (readfirstlane / blockIdx): the tile, its list range and every loop bound below are scalars -> scalar
   // loads, SGPR loop counters and s_cbranch instead of exec-mask loops
-  int sbx, sby, wave, lw;
-  if (!composite_wave_role(SX, SY, sbx, sby, wave, lw)) return;   // a surplus workgroup of the padded grid
+  int tx, ty, lw;
+  if (order) {   // (launch-uniform) longest list first within the XCD's share of the image: tile_order_kernel
+    const unsigned ot = ordered_tile<CWG_WAVES>(order, order_P, lw);
+    if (ot == 0xffffffffu) return;
+    ty = (int)(ot / (unsigned)TX8); tx = (int)(ot - (unsigned)ty * (unsigned)TX8);
+  } else {
+    int sbx, sby, wave;
+    if (!composite_wave_role(SX, SY, sbx, sby, wave, lw)) return;   // a surplus workgroup of the padded grid
+    tx = sbx * 2 + (wave & 1); ty = sby * 2 + (wave >> 1);
+  }
   const int lane = threadIdx.x & 63;
-  const int tx = sbx * 2 + (wave & 1), ty = sby * 2 + (wave >> 1);
   if (tx >= TX8 || ty >= TY8 || ty < kf.band0 || ty >= kf.band1) return;
   const int W = kf.W, H = kf.H;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
@@ -2313,16 +2378,27 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   }
   const int SX = (TX8 + 1) / 2, SY = (TY8 + 1) / 2;
   const unsigned cgrid = composite_grid(SX, SY, 4 / CWG_WAVES);
+  // longest-first tile order (tile_order_kernel): asked for by the caller's hint, forced / forbidden by the "tile_order" option
+  const unsigned OP = (unsigned)order_slots(W, H);
+  const bool ordered = option(OPT_TILE_ORDER) == 1 || (option(OPT_TILE_ORDER) == 0 && (frame->launch_hints & SFGS_HINT_TILE_ORDER));
+  const uint32_t* ord = ordered ? tv.tile_order : nullptr;
   { ProfScope ps_(KID_COMPOSITE_FWD, stream);
+    if (ordered)
+      hipLaunchKernelGGL(tile_order_kernel<true>, dim3(8), dim3(1024), 0, stream, TX8, TY8, SX, SY, (const void*)tv.tile_range,
+                         tv.tile_order, OP, tv.hdr, 1u);
     if (image) {
       const ImageView iv = image_view(image, W, H, dup_capacity);
       hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(cgrid), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX, SY,
                          tv.tile_range, bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, iv.n_contrib, iv.final_T,
-                         iv.dacc, iv.hitmask, iv.tile_kmax, iv.tile_dead, tv.hdr);
+                         iv.dacc, iv.hitmask, iv.tile_kmax, iv.tile_dead, tv.hdr, ord, OP);
+      if (ordered)   // the backward's order, by last contributor (known now)
+        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(8), dim3(1024), 0, stream, TX8, TY8, SX, SY, (const void*)iv.tile_kmax,
+                           tv.tile_order + (size_t)8 * OP, OP, tv.hdr, 2u);
     } else {
       hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(cgrid), dim3(64 * CWG_WAVES), 0, stream, kf, TX8, TY8, SX, SY,
                          tv.tile_range, bv.sorted_id, gv.rec, out_color, out_depth, out_alpha, (uint32_t*)nullptr,
-                         (float*)nullptr, (float*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr, tv.hdr);
+                         (float*)nullptr, (float*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr, tv.hdr,
+                         ord, OP);
     } }
   SFGS_POST_LAUNCH("composite_fwd", stream, frame->debug);
   return SFGS_OK;

@@ -37,7 +37,7 @@ enum KernelId {
   KID_COUNT
 };
 // process-wide route options (include/sfgs.h: sfgs_set_option; api.cpp): one relaxed atomic load per query
-enum { OPT_SORT, OPT_PLAN_SCAN, OPT_BINNING, OPT_PREFILL, OPT_KNN, OPT_COUNT };
+enum { OPT_SORT, OPT_PLAN_SCAN, OPT_BINNING, OPT_PREFILL, OPT_KNN, OPT_TILE_ORDER, OPT_COUNT };
 enum { SORT_AUTO = 0, SORT_FUSED = 1, SORT_FUSED1024 = 2, SORT_SPLIT = 3 };
 enum { PREFILL_AUTO = 0, PREFILL_ALWAYS = 1, PREFILL_NEVER = 2 };
 int option(int which);
@@ -127,7 +127,8 @@ enum HeaderSlot {
   HDR_PREFILLED = 11,    // backward: 1 when dupgrad_prefill_kernel zeroed the whole record array (composite_bwd then
                          // skips the entries behind a tile's last contributor), else 0
   HDR_CSR_CURSOR = 12,   // two-pass binning: items handed out of BinsView::csr so far (bin_rank_kernel: one atomic per 16 bins)
-  HDR_MAX_BIN_ITEMS = 13 // fullest coarse bin counting ALL its items (slab + csr run): what the sort route is chosen from
+  HDR_MAX_BIN_ITEMS = 13, // fullest coarse bin counting ALL its items (slab + csr run): what the sort route is chosen from
+  HDR_TILE_ORDER = 14    // bit 0 / 1: TilesView::tile_order holds this frame's longest-first tile order for composite_fwd / _bwd
 };
 
 // float4s per compositing record in global memory: 3 = packed 48-byte records; 4 = 64-byte stride (the fourth is never
@@ -201,6 +202,9 @@ struct TilesView {
   // two-pass binning without device atomics: per (scatter workgroup, coarse bin) the workgroup's items, their tile hits
   // and -- after the column scan -- the first slab rank of its run ([scatter_groups(N)][N_cb] each, fully rewritten per frame)
   uint32_t *sc_cnt, *sc_hits, *sc_base;
+  // longest-first tile order of the compositing kernels (tile_order_kernel, SFGS_HINT_TILE_ORDER): [2][8][order_slots], the
+  // forward's (by list length) and the backward's (by last contributor); 0xffffffff = no tile
+  uint32_t* tile_order;
 };
 constexpr int SCATTER_BLOCKS = 32;   // preprocess workgroups per scatter workgroup
 static inline int tiles8_x(int W) { return (W + TILE_BIN - 1) / TILE_BIN; }
@@ -211,6 +215,13 @@ static inline int coarse_y(int H) { return (tiles8_y(H) + COARSE - 1) / COARSE; 
 static inline int64_t coarse_bins(int W, int H) { return (int64_t)coarse_x(W) * coarse_y(H); }
 static inline int64_t pre_blocks(int64_t N) { return (N + PRE_BLOCK - 1) / PRE_BLOCK; }
 static inline int64_t scatter_groups(int64_t N) { return (pre_blocks(N) + SCATTER_BLOCKS - 1) / SCATTER_BLOCKS; }
+// tile slots per XCD of the compositing kernels' chunked mapping (composite_wave_role below): chunks of 8 x 4 blocks of 2 x 2 tiles,
+// every eighth chunk to an XCD
+static inline int64_t order_slots(int W, int H) {
+  const int64_t SX = (tiles8_x(W) + 1) / 2, SY = (tiles8_y(H) + 1) / 2;
+  const int64_t nch = ((SX + 7) / 8) * ((SY + 3) / 4);
+  return (nch + 7) / 8 * 128;
+}
 static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* total) {
   TilesView t;
   const int64_t T8 = tiles8(W, H), NB = pre_blocks(N) + 1, NCB = coarse_bins(W, H);
@@ -228,6 +239,7 @@ static inline TilesView tiles_view(void* base, int W, int H, int64_t N, size_t* 
   t.sc_cnt = (uint32_t*)(p + off); off += msz;
   t.sc_hits = (uint32_t*)(p + off); off += msz;
   t.sc_base = (uint32_t*)(p + off); off += msz;
+  t.tile_order = (uint32_t*)(p + off); off += align_up((size_t)(2 * 8 * order_slots(W, H)) * 4, 256);
   if (total) *total = off;
   return t;
 }
@@ -400,7 +412,8 @@ template <int WAVES> constexpr int composite_block_edge() { return WAVES > 4 ? 4
 // finish composite_fwd after 13 us and another after 299 us. Now the image is cut into CHUNKS of 8 x 4 blocks (128 x 64 pixels
 // with 2 x 2-tile blocks; 32 workgroups that run back to back on ONE XCD and share its L2 like before) and the chunks are
 // dealt to the XCDs round-robin in row-major order: every XCD gets every eighth chunk, spread over the whole frame.
-constexpr int CHUNK_BX = 8, CHUNK_BY = 4;
+constexpr int CHUNK_BX = 8, CHUNK_BY = 4;   // (order_slots above spells these out: it is needed before this point)
+static_assert(CHUNK_BX == 8 && CHUNK_BY == 4, "order_slots(): 8 x 4 blocks of 2 x 2 tiles = 128 tiles per chunk");
 static inline unsigned composite_grid(int SX, int SY, int per_block) {   // workgroups to launch (padded: surplus ones return at once)
   const unsigned nch = (unsigned)((SX + CHUNK_BX - 1) / CHUNK_BX) * (unsigned)((SY + CHUNK_BY - 1) / CHUNK_BY);
   return (nch + 7u) / 8u * 8u * (unsigned)(CHUNK_BX * CHUNK_BY * per_block);
@@ -423,6 +436,17 @@ __device__ __forceinline__ bool composite_wave_role(int SX, int SY, int& sbx, in
   lw = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   wave = (int)(within % PER) * WAVES + lw;
   return sbx < SX && sby < SY;
+}
+
+// With a tile ORDER (TilesView::tile_order, one list per XCD: the tiles of the XCD's chunks, longest list first) the workgroup
+// on XCD x at position p of that XCD takes order[x * P + p] instead; a 4-wave workgroup takes four consecutive entries
+// (lists of similar length: the workgroup's LDS is released when all four are done). Returns the tile or 0xffffffff.
+template <int WAVES>
+__device__ __forceinline__ unsigned ordered_tile(const uint32_t* __restrict__ order, unsigned P, int& lw) {
+  const unsigned b = blockIdx.x;
+  lw = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned p = (b >> 3) * (unsigned)WAVES + (unsigned)lw;
+  return p < P ? order[(size_t)(b & 7u) * P + p] : 0xffffffffu;
 }
 
 // the same idea in one dimension (select_sort_kernel: workgroups = rows of four tiles of the coarse bins, 4 per bin): chunks of
@@ -559,6 +583,7 @@ void launch_composite_bwd(unsigned grid, hipStream_t stream, KFrame kf, int TX8,
                           const uint2* tile_range, const uint32_t* sorted_id, const uint32_t* sorted_dup, const float4* rec,
                           const uint32_t* n_contrib, const float* final_T, const float* dacc, const float* dL_dcolor,
                           const float* dL_ddepth, const float* dL_dalpha, const uint2* hitmask, const uint32_t* tile_kmax,
-                          float4* dupgrad, uint8_t* live, const unsigned long long* hdr, int not_prefilled);
+                          float4* dupgrad, uint8_t* live, const unsigned long long* hdr, int not_prefilled,
+                          const uint32_t* order, unsigned order_slots_per_xcd);
 
 }  // namespace sfgs

@@ -170,7 +170,7 @@ def ptr(t):
 
 def set_option(key, value):
     """Process-wide route option of the library (include/sfgs.h: sfgs_set_option): "sort", "plan_scan", "binning",
-    "prefill", "knn". Tests and A/B runs only -- every route builds bit-identical results. Returns the previous value."""
+    "prefill", "knn", "tile_order". Tests and A/B runs only -- every route builds bit-identical results. Returns the previous value."""
     lib = load()
     old = lib.sfgs_get_option(str(key).encode())
     check(lib.sfgs_set_option(str(key).encode(), str(value).encode()))   # raises for an unknown key or value

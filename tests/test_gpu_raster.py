@@ -394,6 +394,30 @@ def test_skewed_workgroups_and_the_duplicate_index_pools():
     assert share > 0   # the big splats are on screen
 
 
+@pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "ragged_130x77", "uhd_two_bin_rounds", "skewed_far_view"])
+def test_tile_order_is_a_relabelling_of_workgroups(case, sfgs_option):
+    """ROUTE-EQUALITY test (HIP vs HIP). With SFGS_HINT_TILE_ORDER (here forced through the "tile_order" option) the
+    compositing kernels take their tiles longest list first inside each XCD's share of the image (tile_order_kernel) instead of in
+    image order. A tile is composited by one wave from its own list: every output and every gradient must be the same bits,
+    whatever the order (forward by list length, backward by last contributor; tiles without work, a ragged image edge,
+    workgroups of four tiles in the backward)."""
+    c = CASES.get(case) or BINNING_CASES.get(case)
+    if c is None:
+        c = dict(n=5000, W=130, H=77, kw=dict(zrange=(2., 50.), scale_range=(0.01, 2.0)))
+    frame, g = scene(c["n"], c["W"], c["H"], seed=21, **c["kw"])
+    gc, gd = upstream_grads(c["W"], c["H"], 5)
+    outs = {}
+    for mode in ("never", "always"):
+        sfgs_option("tile_order", mode)
+        outs[mode] = run_hip(frame, g, gc, gd)
+    a, b = outs["never"], outs["always"]
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(np.nan_to_num(a[k], nan=-1.0), np.nan_to_num(b[k], nan=-1.0), err_msg=k)
+    for k in a["grads"]:
+        np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
+    assert np.abs(a["grads"]["means3D"]).max() > 0
+
+
 @pytest.mark.parametrize("case", ["cfg2_like", "big_splats", "lists_800", "cfg4_like_1440p", "uhd_two_bin_rounds",
                                   "mid_splats_many_items", "skewed_far_view"])
 def test_two_pass_binning_equals_the_direct_path(case, sfgs_option):

@@ -158,7 +158,8 @@ def test_launch_hint_bits_match_the_c_header():
     bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SFGS_HINT_([A-Z_]+)\s+(\d+)u", hdr)}
     assert bits == {"NO_HUGE_SPLATS": diff_gauss.HINT_NO_HUGE_SPLATS, "FEW_LONG_LISTS": diff_gauss.HINT_FEW_LONG_LISTS,
                     "NO_PREFILL": diff_gauss.HINT_NO_PREFILL, "NO_BIG_CHUNKS": diff_gauss.HINT_NO_BIG_CHUNKS,
-                    "SHORT_LISTS": diff_gauss.HINT_SHORT_LISTS, "MEDIUM_LISTS": diff_gauss.HINT_MEDIUM_LISTS}
+                    "SHORT_LISTS": diff_gauss.HINT_SHORT_LISTS, "MEDIUM_LISTS": diff_gauss.HINT_MEDIUM_LISTS,
+                    "TILE_ORDER": diff_gauss.HINT_TILE_ORDER}
     vals = sorted(bits.values())
     assert all(v & (v - 1) == 0 for v in vals) and len(set(vals)) == len(vals)
     assert diff_gauss.SHORT_LIST_MAX <= 512 and diff_gauss.MEDIUM_LIST_MAX <= 1024   # what select_sort_kernel<512 / 1024> sort
@@ -215,6 +216,11 @@ def test_sort_route_hints_follow_the_list_statistics():
     assert f(32400, 3000, 50000, 32400, 1700, T) == 0              # 16 M Gaussians: most lists beyond 1 024 -> split
     assert f(32400, 1676, 50000, 32400, 1311, T) == 0              # screen-filling splats
     assert f(7179, 3361, 20000, 7179, 269, T, medium_on=False) == 0
+    # longest-first tile order: only for frames whose longest list is several times the mean, and big enough to matter
+    o, O = dg._order_hint, dg.HINT_TILE_ORDER
+    assert o(277, 214, 6_945_415) == 0 and o(652, 536, 17_361_927) == 0 and o(1023, 858, 27_801_544) == 0   # headline, low elevation, dense
+    assert o(1575, 203, 6_590_021) == O and o(3361, 269, 8_722_904) == O and o(852, 164, 5_321_148) == O    # city 89 / 25, orbit 25
+    assert o(3, 0.1, 3530) == 0 and o(1 << 30, 214, 6_945_415) == 0                                          # tiny scene; first frame (nothing known)
 
 
 def test_route_options_are_set_through_the_abi_not_the_environment():
@@ -223,7 +229,8 @@ def test_route_options_are_set_through_the_abi_not_the_environment():
     import subprocess
     import sys
     for key, values in (("sort", ["auto", "fused", "fused1024", "split"]), ("plan_scan", ["fused", "separate"]),
-                        ("binning", ["auto", "direct"]), ("prefill", ["auto", "always", "never"]), ("knn", ["auto", "brute"])):
+                        ("binning", ["auto", "direct"]), ("prefill", ["auto", "always", "never"]), ("knn", ["auto", "brute"]),
+                        ("tile_order", ["auto", "always", "never"])):
         first = L.get_option(key)
         assert first == values[0]                       # the defaults (this process's environment sets none)
         for v in values[::-1]:

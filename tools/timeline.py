@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--out", default=None)
     ap.add_argument("--kernel", default="bwd", choices=["bwd", "fwd"], help="composite_bwd or composite_fwd<TRAIN> (batches of 64 entries)")
-    ap.add_argument("--regime", default="headline", choices=["headline", "city_e25", "city_e45", "orbit_e25", "low_elevation"],
+    ap.add_argument("--regime", default="headline", choices=["headline", "city_e25", "city_e45", "city_e60", "city_e75", "city_e89", "orbit_e25", "orbit_e45", "low_elevation"],
                     help="scene / camera (tools/bench_regimes.py's geometry)")
     a = ap.parse_args()
     import numpy as np
