@@ -1683,9 +1683,9 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
 // worse: city at 75 degrees 1.21 -> 1.10 ms instead of -> 1.04, composite_fwd 0.235 instead of 0.208 ms. And uniform frames lose
 // with either: a class is a sparse subset of the image, the tiles in flight no longer share records in the L2 -- headline
 // +6 %, dense 8 M +12 % when forced on -- which is why the order is a HINT the caller only gives for frames whose longest list is
-// several times their mean. Dealing the CHUNKS to the XCDs by work as well -- the XCDs still finish 4 - 8 % apart -- gave composite_bwd
-// 2 - 6 % and cost composite_fwd 25 %: select_sort uses the same chunked XCD mapping, so with the fixed deal a chunk's sorted lists are
-// still in the L2 of the XCD that composites them. profiles/r6_tile_order_ab.txt, section 5.)
+// several times their mean. Dealing the CHUNKS to the XCDs by work as well -- the XCDs still finish 4 - 8 % apart -- was built
+// (tools/variants/chunk_deal_by_work_r6.patch) and bought the two kernels 1.4 / 2.4 % by rocprofv3, less than its own two extra
+// passes cost: not kept. profiles/r6_tile_order_ab.txt, section 5.)
 template <bool PAIRS>   // PAIRS: key = tile_range[t].y (uint2 array), else a plain uint32 array (tile_kmax)
 __global__ void __launch_bounds__(1024)
 tile_order_kernel(int TX8, int TY8, int SX, int SY, const void* __restrict__ keys_, uint32_t* __restrict__ order, unsigned P,
