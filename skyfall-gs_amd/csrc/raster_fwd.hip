@@ -1681,8 +1681,9 @@ sort_tiles_long_kernel(int lo, const uint32_t* __restrict__ long_tiles, const un
 // workgroup-mates keep the LDS). Inside a class the order is whatever the LDS atomics make it: tiles are independent, any
 // order composites the same bits. (A STABLE sort -- image order inside a class, in runs of 64 tiles -- was built and measured
 // worse: city at 75 degrees 1.21 -> 1.10 ms instead of -> 1.04, composite_fwd 0.235 instead of 0.208 ms. And uniform frames lose
-// with either -- headline +6 %, dense 8 M +12 % when forced on, almost all of it in composite_bwd; the likely reason (not verified
-// with counters): a class is a sparse subset of the image, the tiles in flight no longer gather the same records -- which is why
+// with either -- headline +6 %, dense 8 M +12 % when forced on, almost all of it in composite_bwd: a class is a sparse subset of
+// the image, the tiles in flight no longer gather the same records (FETCH_SIZE on the dense frame: composite_bwd 1.65 -> 2.27 GB
+// per launch, 788 -> 1 161 us; composite_fwd 1.22 -> 2.17 GB at an unchanged 440 us) -- which is why
 // the order is a HINT the caller only gives for frames whose longest list is several times their mean. Dealing the CHUNKS to the XCDs by work as well -- the XCDs still finish 4 - 8 % apart -- was built
 // (tools/variants/chunk_deal_by_work_r6.patch) and bought the two kernels 1.4 / 2.4 % by rocprofv3, less than its own two extra
 // passes cost: not kept. profiles/r6_tile_order_ab.txt, section 5.)
