@@ -443,6 +443,7 @@ __device__ __forceinline__ bool composite_wave_role(int SX, int SY, int& sbx, in
 // (lists of similar length: the workgroup's LDS is released when all four are done). Returns the tile or 0xffffffff.
 template <int WAVES>
 __device__ __forceinline__ unsigned ordered_tile(const uint32_t* __restrict__ order, unsigned P, int& lw) {
+  static_assert(WAVES <= 4 && composite_block_edge<WAVES>() == 2, "order_slots() counts tiles of 2 x 2-tile blocks: grid x WAVES == 8 P");
   const unsigned b = blockIdx.x;
   lw = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned p = (b >> 3) * (unsigned)WAVES + (unsigned)lw;
