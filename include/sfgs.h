@@ -95,6 +95,9 @@ typedef struct SfgsFrame {
  *   MEDIUM_LISTS    render: as SHORT_LISTS, for frames whose lists reach 513 .. 1 024 entries (what the feedback of the
  *                   previous frame reported): the same kernel with twice the list capacity (48 KB of LDS per workgroup,
  *                   the 16-key register network for the lists beyond 512). Always correct; implies the fused route.
+ *   LISTS_768       render, with MEDIUM_LISTS: the fused kernel with room for 768 instead of 1 024 entries per list (36 KB of LDS
+ *                   per workgroup: four instead of three workgroups per CU) -- for frames whose lists exceed 512 but (almost)
+ *                   never 768 entries; the few longer ones take the long-list kernels. Always correct.
  *   TILE_ORDER      render: the caller expects tile lists of very different lengths (the previous frame's longest list
  *                   several times its mean: a city seen from above, a few facades edge-on). The compositing kernels then
  *                   take their tiles longest list first within each XCD's share of the image (two launches of a small
@@ -110,6 +113,7 @@ typedef struct SfgsFrame {
 #define SFGS_HINT_SHORT_LISTS 16u
 #define SFGS_HINT_MEDIUM_LISTS 32u
 #define SFGS_HINT_TILE_ORDER 64u
+#define SFGS_HINT_LISTS_768 128u
 
 /* Per-Gaussian inputs = keyword arguments of GaussianRasterizer.__call__
  * (gaussian_renderer/__init__.py:132-140). All float32, contiguous, device memory.
@@ -236,7 +240,7 @@ const char* sfgs_last_error(void);
  * values),
  * and changed afterwards only through this call. Thread-safe: one atomic word per option; a render running on another
  * thread sees the old or the new value, never a mixture.
- *   key "sort"       "auto" (the frame's launch hints decide) | "fused" | "fused1024" | "split"
+ *   key "sort"       "auto" (the frame's launch hints decide) | "fused" | "fused768" | "fused1024" | "split"
  *   key "plan_scan"  "fused" (the plan's epilogues ride in the scatter launch) | "separate"
  *   key "binning"    "auto" (two-pass below 65 536 coarse bins) | "direct"
  *   key "prefill"    "auto" (dead-entry prefill decided per frame on the device) | "always" | "never"

@@ -24,9 +24,9 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- route options (sfgs_set_option) ----------------------------------------------------------------
-struct OptSpec { const char* key; const char* env; const char* values[5]; };
+struct OptSpec { const char* key; const char* env; const char* values[6]; };
 static const OptSpec kOpts[OPT_COUNT] = {
-    {"sort", "SFGS_SORT", {"auto", "fused", "fused1024", "split", nullptr}},
+    {"sort", "SFGS_SORT", {"auto", "fused", "fused1024", "split", "fused768", nullptr}},
     {"plan_scan", "SFGS_PLAN_SCAN", {"fused", "separate", nullptr}},
     {"binning", "SFGS_BINNING", {"auto", "direct", nullptr}},
     {"prefill", "SFGS_PREFILL", {"auto", "always", "never", nullptr}},

@@ -1941,9 +1941,10 @@ static int sort_fused(uint32_t launch_hints) {
     case SORT_SPLIT: return 0;
     case SORT_FUSED: return 512;
     case SORT_FUSED1024: return 1024;
+    case SORT_FUSED768: return 768;
     default: break;
   }
-  if (launch_hints & SFGS_HINT_MEDIUM_LISTS) return 1024;
+  if (launch_hints & SFGS_HINT_MEDIUM_LISTS) return (launch_hints & SFGS_HINT_LISTS_768) ? 768 : 1024;
   return (launch_hints & SFGS_HINT_SHORT_LISTS) ? 512 : 0;
 }
 
@@ -2331,8 +2332,13 @@ extern "C" int sfgs_raster_forward_render(const SfgsFrame* frame, int32_t N, con
   const bool fused = fused_cap != 0;
   if (fused) {
     { ProfScope ps_(KID_SORT_SMALL, stream);
-      if (fused_cap > 512)
+      if (fused_cap > 768)
         hipLaunchKernelGGL(select_sort_kernel<1024>, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX,
+                           (int)NCB, tv.coarse_count, bv.csr, bv.slabs, (unsigned)coarse_capacity,
+                           (unsigned long long)dup_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id,
+                           bv.sorted_dup);
+      else if (fused_cap > 512)   // 36 KB of LDS per workgroup: four workgroups per CU instead of three
+        hipLaunchKernelGGL(select_sort_kernel<768>, dim3((unsigned)NCB * COARSE), dim3(256), 0, stream, TX8, TY8, CX,
                            (int)NCB, tv.coarse_count, bv.csr, bv.slabs, (unsigned)coarse_capacity,
                            (unsigned long long)dup_capacity, tv.tile_range, bv.items, tv.long_tiles, tv.hdr, bv.sorted_id,
                            bv.sorted_dup);

@@ -38,7 +38,7 @@ enum KernelId {
 };
 // process-wide route options (include/sfgs.h: sfgs_set_option; api.cpp): one relaxed atomic load per query
 enum { OPT_SORT, OPT_PLAN_SCAN, OPT_BINNING, OPT_PREFILL, OPT_KNN, OPT_TILE_ORDER, OPT_COUNT };
-enum { SORT_AUTO = 0, SORT_FUSED = 1, SORT_FUSED1024 = 2, SORT_SPLIT = 3 };
+enum { SORT_AUTO = 0, SORT_FUSED = 1, SORT_FUSED1024 = 2, SORT_SPLIT = 3, SORT_FUSED768 = 4 };
 enum { PREFILL_AUTO = 0, PREFILL_ALWAYS = 1, PREFILL_NEVER = 2 };
 int option(int which);
 bool prof_enabled();

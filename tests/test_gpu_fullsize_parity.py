@@ -89,7 +89,7 @@ def test_full_size_oracle_parity(case, sort_route, monkeypatch, sfgs_option):
     out = run_hip(frame, g, gc, gd, debug=False, full_counters=False)    # frame 3: the timed configuration
     fh, bh = out["counters"]["fwd_hints"], diff_gauss.last_backward_hints()
     route = {0: "split", HINT_SHORT_LISTS: "short", HINT_SHORT_LISTS | HINT_MEDIUM_LISTS: "medium"}.get(
-        fh & (HINT_SHORT_LISTS | HINT_MEDIUM_LISTS))
+        fh & (HINT_SHORT_LISTS | HINT_MEDIUM_LISTS))   # ("medium": the 1 024- or, low elevation, the 768-entry form)
     assert route == EXPECT_ROUTE[case], (case, fh)
     if route == "short":   # bench.py's steady state: every optional kernel hinted away
         assert fh == HINT_NO_HUGE_SPLATS | HINT_FEW_LONG_LISTS | HINT_SHORT_LISTS, (case, fh)

@@ -485,7 +485,7 @@ def test_a_skewed_frame_needs_no_per_bin_capacity():
     assert int(lay.total_bytes) < 128 << 20    # (of which ~55 MB is list-slot index space: 1 088 slots per coarse bin)
 
 
-@pytest.mark.parametrize("route", ["fused", "fused1024"])
+@pytest.mark.parametrize("route", ["fused", "fused768", "fused1024"])
 @pytest.mark.parametrize("case", ["precomp_small", "sh1_ragged", "cfg2_like", "big_splats", "screen_filling", "lists_800",
                                   "lists_2k", "lists_6k", "lists_10k", "cfg2_200k_1080p", "uhd_two_bin_rounds"])
 def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, sfgs_option):
@@ -496,7 +496,8 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, sfgs_option):
     duplicate indices; only WHERE a tile's list sits inside its bin's slot range may differ -- so images, radii,
     counters (incl. the longest list) and every gradient are equal bit for bit. Long lists (> 512) take the second scan
     and the long-list kernels in the fused route. route fused1024 = the MEDIUM_LISTS form of the kernel (lists up to 1 024
-    entries stay in LDS and are sorted by the 16-key network: case lists_800)."""
+    entries stay in LDS and are sorted by the 16-key network: case lists_800); fused768 = its LISTS_768 form (round 6: lists of
+    769 .. 1 024 entries -- case lists_800 has them -- go to the long-list kernels)."""
     c = CASES.get(case) or BINNING_CASES[case]
     frame, g = scene(c["n"], c["W"], c["H"], seed=5, **c["kw"])
     gc, gd = upstream_grads(c["W"], c["H"], 2)
@@ -512,7 +513,7 @@ def test_fused_select_sort_equals_fine_bin_plus_sort(case, route, sfgs_option):
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k], err_msg=k)
 
 
-@pytest.mark.parametrize("route", ["fused", "fused1024"])
+@pytest.mark.parametrize("route", ["fused", "fused768", "fused1024"])
 def test_equal_depths_keep_the_id_order_on_every_route(route, sfgs_option):
     """Clones sit exactly on their parents until the optimiser moves them (scene/gaussian_model.py: densify_and_clone):
     every Gaussian here exists three times with the same mean, i.e. the same depth bits, in lists of ~800 entries. The

@@ -155,11 +155,11 @@ def test_launch_hint_bits_match_the_c_header():
     is only asked for inside what the fused kernel's register sort takes (lists of at most 512 entries)."""
     import diff_gauss
     hdr = open(os.path.join(ROOT, "include", "sfgs.h")).read()
-    bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SFGS_HINT_([A-Z_]+)\s+(\d+)u", hdr)}
+    bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SFGS_HINT_([A-Z_0-9]+)\s+(\d+)u", hdr)}
     assert bits == {"NO_HUGE_SPLATS": diff_gauss.HINT_NO_HUGE_SPLATS, "FEW_LONG_LISTS": diff_gauss.HINT_FEW_LONG_LISTS,
                     "NO_PREFILL": diff_gauss.HINT_NO_PREFILL, "NO_BIG_CHUNKS": diff_gauss.HINT_NO_BIG_CHUNKS,
                     "SHORT_LISTS": diff_gauss.HINT_SHORT_LISTS, "MEDIUM_LISTS": diff_gauss.HINT_MEDIUM_LISTS,
-                    "TILE_ORDER": diff_gauss.HINT_TILE_ORDER}
+                    "TILE_ORDER": diff_gauss.HINT_TILE_ORDER, "LISTS_768": diff_gauss.HINT_LISTS_768}
     vals = sorted(bits.values())
     assert all(v & (v - 1) == 0 for v in vals) and len(set(vals)) == len(vals)
     assert diff_gauss.SHORT_LIST_MAX <= 512 and diff_gauss.MEDIUM_LIST_MAX <= 1024   # what select_sort_kernel<512 / 1024> sort
@@ -207,7 +207,7 @@ def test_sort_route_hints_follow_the_list_statistics():
     f = dg._sort_hints   # (long_tiles, maxlist, cmax, over512, mean_list, tiles)
     assert f(0, 277, 3000, 0, 214, T) == S                         # headline
     assert f(0, 277, 9000, 0, 214, T) == 0                         # ... with a huge coarse bin: split
-    assert f(25984, 652, 6000, 25984, 536, T) == M                 # low elevation: 80 % of the tiles beyond 512, none beyond 1 024
+    assert f(25984, 652, 6000, 25984, 536, T) == M | dg.HINT_LISTS_768   # low elevation: 80 % of the tiles beyond 512, none beyond 768
     assert f(32400, 1023, 6000, 32400, 858, T) == M                # dense 8 M
     assert f(7179, 3361, 20000, 7179, 269, T) == M                 # opaque city at 25 degrees: a few very long lists, short mean
     assert f(4196, 1998, 20000, 4196, 240, T) == M                 # ... at 60 degrees (13 % of the tiles)
@@ -228,7 +228,7 @@ def test_route_options_are_set_through_the_abi_not_the_environment():
     atomics, read from the environment ONCE at load time and changed only through sfgs_set_option (host code: runs here)."""
     import subprocess
     import sys
-    for key, values in (("sort", ["auto", "fused", "fused1024", "split"]), ("plan_scan", ["fused", "separate"]),
+    for key, values in (("sort", ["auto", "fused", "fused768", "fused1024", "split"]), ("plan_scan", ["fused", "separate"]),
                         ("binning", ["auto", "direct"]), ("prefill", ["auto", "always", "never"]), ("knn", ["auto", "brute"]),
                         ("tile_order", ["auto", "always", "never"])):
         first = L.get_option(key)
