@@ -74,6 +74,7 @@ def _run(frames, reps):
 def test_hints_never_change_a_result(monkeypatch):
     import diff_gauss
     monkeypatch.setattr(diff_gauss, "HUGE_QUIET_FRAMES", 1)   # no hysteresis: the sequence below must hit the violated-hint redo
+    monkeypatch.setattr(diff_gauss, "ORDER_MIN_DUP", 0)       # the tile-order hint at these frame sizes too
     frames = _frames()
     old = os.environ.get("SFGS_HINTS")
     try:
@@ -99,6 +100,10 @@ def test_hints_never_change_a_result(monkeypatch):
     # the sequence did exercise what it claims to
     by = {r["name"]: r["counters"] for r in got}
     assert by["long_lists#1"]["num_duplicates"] > 10 * by["calm#1"]["num_duplicates"]
+    hinted = {r["name"]: r["counters"]["fwd_hints"] for r in got}
+    assert any(h & diff_gauss.HINT_TILE_ORDER for h in hinted.values()), hinted          # longest-first tile order
+    assert any(h & diff_gauss.HINT_MEDIUM_LISTS for h in hinted.values()), hinted
+    assert not any(r["counters"]["fwd_hints"] for r in ref)
 
 
 def test_huge_splat_hint_waits_for_a_quiet_period(monkeypatch):
