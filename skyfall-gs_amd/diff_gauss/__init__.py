@@ -105,6 +105,8 @@ def _sort_hints(long_tiles, maxlist, cmax, over512, mean_list, tiles, medium_on=
       the split route's two extra passes over everything cost more than the stragglers' slow path (round 6, city at
       25 / 45 / 60 degrees 1.01 -> 0.96, 1.12 -> 1.10, 1.145 -> 1.13 ms; 5 M Gaussians at 1080p 2.24 -> 2.16). Where most lists
       exceed 1 024 entries (16 M Gaussians: mean 1 700) the split route stays (2.66 against 3.00 ms);
+    * a few long lists (less than a tenth of the tiles) among short ones: the 512-entry fused kernel, the stragglers through the
+      long-list kernels;
     * otherwise the split route (fine_bin + the size-class sorts)."""
     if long_tiles == 0 and maxlist <= SHORT_LIST_MAX and cmax <= SHORT_BIN_MAX:
         return HINT_SHORT_LISTS
@@ -113,6 +115,11 @@ def _sort_hints(long_tiles, maxlist, cmax, over512, mean_list, tiles, medium_on=
         # ... with room for 768 entries when no list was longer (36 instead of 48 KB of LDS per workgroup, four instead of
         # three per CU: low elevation 1.21 -> 1.17 ms; with longer lists about it loses: city e25 +3 %, dense 8 M +18 %)
         return HINT_SHORT_LISTS | HINT_MEDIUM_LISTS | (HINT_LISTS_768 if maxlist <= 768 else 0)
+    if 0 < over512 * MEDIUM_TILE_SHARE < tiles and mean_list <= MEDIUM_MEAN_MAX:
+        # a FEW long lists among short ones (less than a tenth of the tiles: a city from straight above, small scenes): the 512-entry
+        # fused kernel at its full occupancy, the stragglers through the long-list kernels -- against the split route -2.3 % (city
+        # e82), -2.5 % (e89), -3 % (1 M Gaussians at e45), -1 % (1 M at e80), +-0 (orbit e35), +1.5 % (orbit e25: the one loss)
+        return HINT_SHORT_LISTS
     return 0
 
 

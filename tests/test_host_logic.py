@@ -211,8 +211,10 @@ def test_sort_route_hints_follow_the_list_statistics():
     assert f(32400, 1023, 6000, 32400, 858, T) == M                # dense 8 M
     assert f(7179, 3361, 20000, 7179, 269, T) == M                 # opaque city at 25 degrees: a few very long lists, short mean
     assert f(4196, 1998, 20000, 4196, 240, T) == M                 # ... at 60 degrees (13 % of the tiles)
-    assert f(2412, 852, 5000, 2412, 164, T) == 0                   # orbit at 25 degrees: 7 % of the tiles -> split
-    assert f(2921, 1575, 20000, 2921, 203, T) == 0                 # city at 89 degrees: 9 %
+    assert f(2412, 852, 5000, 2412, 164, T) == S                   # orbit at 25 degrees: 7 % of the tiles beyond 512 -> the 512 form + long-list kernels
+    assert f(2921, 1575, 20000, 2921, 203, T) == S                 # city at 89 degrees: 9 %
+    assert f(658, 1269, 6452, 658, 130, T) == S                    # 1 M Gaussians, city at 45 degrees: 2 %
+    assert f(3000, 1600, 9000, 3000, 900, T) == 0                  # ... but not when the mean list is long
     assert f(32400, 3000, 50000, 32400, 1700, T) == 0              # 16 M Gaussians: most lists beyond 1 024 -> split
     assert f(32400, 1676, 50000, 32400, 1311, T) == 0              # screen-filling splats
     assert f(7179, 3361, 20000, 7179, 269, T, medium_on=False) == 0

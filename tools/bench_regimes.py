@@ -39,6 +39,7 @@ REGIMES = {
     # exactly what the reference's render() passes when ray jitter is off: an all-zero [H,W,2] tensor
     "zero_subpixel_tensor_2M_1080p": dict(n=2_000_000, W=1920, H=1080, kw={}, zero_subpix=True),
 }
+REGIMES.update(json.loads(os.environ.get("EXTRA_REGIMES", "{}")))   # e.g. {"city_e35_4M": {"n": 4000000, "W": 1920, "H": 1080, "city": 35.0}}
 dev = torch.device("cuda:0")
 only = sys.argv[1:]
 if int(os.environ.get("PIN_CORES", "4")) > 0:   # as bench.py / tools/launch_scenes.py: the host-bound regimes (tiny scene) depend on it
